@@ -1,0 +1,209 @@
+"""ctypes front-end of the CPU oracle (oracle/dgr_oracle.cpp).
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+# DGR_ORACLE_CMATH=1 selects the build whose exp/sqrt/ceil bind to the C double functions
+# (reproduces SURVEY.md Appendix C digit for digit); default is the float-overload build.
+_SO = "libdgr_oracle_cmath.so" if os.environ.get("DGR_ORACLE_CMATH") == "1" else "libdgr_oracle.so"
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, _SO)
+    src = os.path.join(_HERE, "dgr_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "all"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.dgro_state_new.restype = C.c_void_p
+        _LIB.dgro_state_free.argtypes = [C.c_void_p]
+        _LIB.dgro_state_get.restype = C.c_long
+        _LIB.dgro_state_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        _LIB.dgro_state_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
+        _LIB.dgro_state_set_dims.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _LIB.dgro_state_num_rendered.argtypes = [C.c_void_p]
+    return _LIB
+
+
+def _p(a):
+    """float32/int32 numpy array (or None) -> void pointer (NULL for None / empty)."""
+    if a is None or a.size == 0:
+        return C.c_void_p(None)
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+def _f(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+_DTYPES = {
+    "depths": np.float32, "means2D": np.float32, "cov3D": np.float32, "conic_opacity": np.float32,
+    "rgb": np.float32, "clamped": np.uint8, "radii": np.int32, "tiles_touched": np.uint32,
+    "point_offsets": np.uint32, "keys_unsorted": np.uint64, "keys": np.uint64,
+    "point_list_unsorted": np.uint32, "point_list": np.uint32, "ranges": np.uint32,
+    "n_contrib": np.uint32, "n_valid_contrib": np.uint32, "final_T": np.float32,
+    "dgndcs_dview": np.float32, "dg_camd": np.float32,
+}
+
+
+class OracleState:
+    """Owns the Geometry/Binning/Image state of one forward call (opaque byte buffers in the reference)."""
+
+    def __init__(self):
+        self._l = lib()
+        self._h = C.c_void_p(self._l.dgro_state_new())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._l.dgro_state_free(self._h)
+            self._h = None
+
+    def get(self, name):
+        ptr, elem = C.c_void_p(), C.c_int()
+        n = self._l.dgro_state_get(self._h, name.encode(), C.byref(ptr), C.byref(elem))
+        if n < 0:
+            raise KeyError(name)
+        dt = np.dtype(_DTYPES[name])
+        assert dt.itemsize == elem.value
+        if n == 0:
+            return np.zeros(0, dt)
+        buf = (C.c_char * (n * dt.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    def set(self, name, arr):
+        arr = np.ascontiguousarray(arr, dtype=_DTYPES[name])
+        if self._l.dgro_state_set(self._h, name.encode(), C.c_void_p(arr.ctypes.data), arr.size):
+            raise KeyError(name)
+
+    def set_dims(self, P, W, H):
+        self._l.dgro_state_set_dims(self._h, P, W, H)
+
+    @property
+    def num_rendered(self):
+        return self._l.dgro_state_num_rendered(self._h)
+
+
+def mark_visible(means, view, proj):
+    means, view, proj = _f(means), _f(view), _f(proj)
+    out = np.zeros(means.shape[0], np.uint8)
+    lib().dgro_mark_visible(C.c_int(means.shape[0]), _p(means), _p(view), _p(proj), C.c_void_p(out.ctypes.data))
+    return out.astype(bool)
+
+
+def _common(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix, campos):
+    means3D = _f(means3D)
+    shs, colors_precomp, cov3D_precomp = _f(shs), _f(colors_precomp), _f(cov3D_precomp)
+    opacities, scales, rotations = _f(opacities), _f(scales), _f(rotations)
+    P = means3D.shape[0]
+    M = shs.shape[1] if shs is not None and shs.size else 0
+    return (P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+            _f(viewmatrix), _f(projmatrix), _f(campos))
+
+
+def preprocess(st, W, H, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+               viewmatrix, projmatrix, campos, tanfovx, tanfovy, sh_degree, prefiltered=False):
+    (P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+     campos) = _common(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                       projmatrix, campos)
+    return lib().dgro_preprocess(st._h, P, sh_degree, M, W, H, _p(means3D), _p(shs), _p(colors_precomp),
+                                 _p(opacities), _p(scales), C.c_float(scale_modifier), _p(rotations),
+                                 _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos), C.c_float(tanfovx),
+                                 C.c_float(tanfovy), int(prefiltered))
+
+
+def binning(st):
+    return lib().dgro_binning(st._h)
+
+
+def light_render_forward(st, bg, colors_precomp, gt_depth):
+    W, H, P = _dims(st)
+    bg, colors_precomp, gt_depth = _f(bg), _f(colors_precomp), _f(gt_depth)
+    out = dict(color=np.zeros((3, H, W), np.float32), depth=np.zeros((1, H, W), np.float32),
+               depth_median=np.zeros((1, H, W), np.float32), depth_var=np.zeros((1, H, W), np.float32),
+               opacity_map=np.zeros((1, H, W), np.float32), gau_uncertainty=np.zeros((P, 1), np.float32),
+               gau_related_pixels=np.zeros((P, 1), np.int32))
+    lib().dgro_light_render_forward(st._h, _p(bg), _p(colors_precomp), _p(gt_depth), _p(out["color"]), _p(out["depth"]),
+                                    _p(out["depth_median"]), _p(out["opacity_map"]), _p(out["depth_var"]),
+                                    _p(out["gau_uncertainty"]), _p(out["gau_related_pixels"]))
+    return out
+
+
+def _dims(st):
+    ptr, elem = C.c_void_p(), C.c_int()
+    P = lib().dgro_state_get(st._h, b"radii", C.byref(ptr), C.byref(elem))
+    return st._W, st._H, P
+
+
+def light_forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+                  viewmatrix, gt_depth, projmatrix, tanfovx, tanfovy, H, W, shs, sh_degree, campos,
+                  prefiltered=False):
+    """Argument order of `_C.rasterize_gaussians` (L/rasterize_points.h:18-39).  Returns (state, dict)."""
+    (P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+     campos) = _common(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                       projmatrix, campos)
+    bg, gt_depth = _f(bg), _f(gt_depth)
+    st = OracleState()
+    st._W, st._H = W, H
+    out = dict(color=np.zeros((3, H, W), np.float32), depth=np.zeros((1, H, W), np.float32),
+               depth_median=np.zeros((1, H, W), np.float32), depth_var=np.zeros((1, H, W), np.float32),
+               opacity_map=np.zeros((1, H, W), np.float32), radii=np.zeros(P, np.int32),
+               gau_uncertainty=np.zeros((P, 1), np.float32), gau_related_pixels=np.zeros((P, 1), np.int32))
+    R = 0
+    if P:
+        R = lib().dgro_light_forward(
+            st._h, P, sh_degree, M, _p(bg), W, H, _p(means3D), _p(shs), _p(colors_precomp), _p(opacities),
+            _p(scales), C.c_float(scale_modifier), _p(rotations), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix),
+            _p(campos), C.c_float(tanfovx), C.c_float(tanfovy), int(prefiltered), _p(out["color"]), _p(out["depth"]),
+            _p(out["depth_median"]), _p(out["opacity_map"]), _p(gt_depth), _p(out["depth_var"]),
+            _p(out["gau_uncertainty"]), _p(out["gau_related_pixels"]), _p(out["radii"]))
+        if R < 0:
+            raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    out["num_rendered"] = R
+    return st, out
+
+
+def light_backward(st, bg, means3D, colors_precomp, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                   projmatrix, tanfovx, tanfovy, dL_dcolor, dL_ddepth, dL_dmedian, dL_dvar, gt_depth, shs,
+                   sh_degree, campos, alphas, perspec_matrix, track_off=False, map_off=False, per_pixel_pose=False):
+    """Argument meaning of `_C.rasterize_gaussians_backward` (L/rasterize_points.h:41-72); the saved
+    byte buffers are the OracleState.  Returns the 9 gradients with grad_viewmatrix already [4,4]."""
+    (P, M, means3D, shs, colors_precomp, _, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+     campos) = _common(means3D, shs, colors_precomp, None, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                       campos)
+    W, H = st._W, st._H
+    g = dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dcolors=np.zeros((P, 3), np.float32),
+             dL_ddepths=np.zeros((P, 1), np.float32), dL_dconic=np.zeros((P, 2, 2), np.float32),
+             dL_dopacity=np.zeros((P, 1), np.float32), dL_dmeans3D=np.zeros((P, 3), np.float32),
+             dL_dcov3D=np.zeros((P, 6), np.float32), dL_dsh=np.zeros((P, M, 3), np.float32),
+             dL_dscales=np.zeros((P, 3), np.float32), dL_drotations=np.zeros((P, 4), np.float32),
+             dL_dview=np.zeros((4, 4), np.float32))
+    pix = np.zeros((H * W, 4, 4), np.float32) if per_pixel_pose else None
+    if P:
+        lib().dgro_light_backward(
+            st._h, P, sh_degree, M, _p(_f(bg)), _p(means3D), _p(shs), _p(colors_precomp), _p(_f(alphas)), _p(scales),
+            C.c_float(scale_modifier), _p(rotations), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos),
+            C.c_float(tanfovx), C.c_float(tanfovy), _p(_f(dL_dcolor)), _p(_f(dL_ddepth)), _p(_f(dL_dmedian)),
+            _p(_f(dL_dvar)), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]), _p(g["dL_dcolors"]),
+            _p(g["dL_ddepths"]), _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]), _p(g["dL_dsh"]), _p(g["dL_dscales"]),
+            _p(g["dL_drotations"]), _p(_f(perspec_matrix)), _p(pix), _p(g["dL_dview"]), _p(_f(gt_depth)),
+            int(track_off), int(map_off))
+    if per_pixel_pose:
+        g["dL_dview_pix"] = pix
+    return g
