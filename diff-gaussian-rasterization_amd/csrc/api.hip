@@ -1,0 +1,324 @@
+// api.hip -- C-ABI entry points (include/dgr_hip.h) and host orchestration.
+//
+// Replaces CudaRasterizer::Rasterizer::{forward, backward, markVisible}
+// (L/cuda_rasterizer/rasterizer_impl.cu:141-153, 197-350, 354-495).  Stage order per view:
+//   forward : zero histogram -> preprocess (+ per-tile histogram) -> scan tiles -> emit keys ->
+//             per-tile sort -> blend
+//   backward: zero accumulator rows -> blend backward -> fused per-Gaussian backward -> pose reduce
+// Nothing here touches the CPU oracle; a missing GPU or a failed launch is reported, never papered over.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/dgr_hip.h"
+#include "dgr_common.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error = "";
+
+int hip_fail(hipError_t e, const char* what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return DGR_ERR_HIP;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return hip_fail(_e, #expr); \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct FwdCommon {
+    int P, D, M, W, H;
+    const float *background, *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    float scale_modifier;
+    const float *viewmatrix, *projmatrix, *cam_pos;
+    float tan_fovx, tan_fovy;
+    int prefiltered;
+    float *out_color, *out_depth, *out_median_depth, *out_alpha;
+    const float* gt_depth;
+    float *out_depth_var, *gau_uncertainty;
+    int *gau_related_pixels, *radii;
+};
+
+// P == 0: the reference launches nothing and returns zero-filled outputs (L/rasterize_points.cu:88).
+int zero_outputs(const FwdCommon& c, hipStream_t st) {
+    const size_t N = (size_t)c.W * c.H;
+    HIP_TRY(hipMemsetAsync(c.out_color, 0, 3 * N * 4, st));
+    HIP_TRY(hipMemsetAsync(c.out_depth, 0, N * 4, st));
+    HIP_TRY(hipMemsetAsync(c.out_median_depth, 0, N * 4, st));
+    HIP_TRY(hipMemsetAsync(c.out_alpha, 0, N * 4, st));
+    HIP_TRY(hipMemsetAsync(c.out_depth_var, 0, N * 4, st));
+    return DGR_OK;
+}
+
+// preprocess + tile scan; afterwards img.status[0] = num_rendered, ranges are final
+int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, int capacity, hipStream_t st) {
+    const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
+    // status, tile_count and tile_fill are adjacent: one memset
+    HIP_TRY(hipMemsetAsync(img.status, 0, (char*)img.ranges - (char*)img.status, st));
+    HIP_TRY(hipMemsetAsync(c.gau_uncertainty, 0, (size_t)c.P * 4, st));
+    HIP_TRY(hipMemsetAsync(c.gau_related_pixels, 0, (size_t)c.P * 4, st));
+    dgr::PreprocessFwdArgs a{};
+    a.P = c.P; a.D = c.D; a.M = c.M; a.W = c.W; a.H = c.H; a.grid_x = gx; a.grid_y = gy;
+    a.means3D = c.means3D; a.scales = c.scales; a.scale_modifier = c.scale_modifier; a.rotations = c.rotations;
+    a.opacities = c.opacities; a.shs = c.shs; a.cov3D_precomp = c.cov3D_precomp; a.colors_precomp = c.colors_precomp;
+    a.view = c.viewmatrix; a.proj = c.projmatrix; a.campos = c.cam_pos;
+    a.tan_fovx = c.tan_fovx; a.tan_fovy = c.tan_fovy;
+    a.focal_y = c.H / (2.0f * c.tan_fovy);  // rasterizer_impl.cu:228-229
+    a.focal_x = c.W / (2.0f * c.tan_fovx);
+    a.prefiltered = c.prefiltered;
+    a.sh_vec_ok = aligned16(c.shs);
+    a.geom = geom; a.radii_out = c.radii; a.tile_count = img.tile_count; a.status = img.status;
+    HIP_TRY(dgr::launch_preprocess_fwd(a, st));
+    HIP_TRY(dgr::launch_scan_tiles(img, tiles, capacity, st));
+    return DGR_OK;
+}
+
+int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, bool have_instances,
+                 hipStream_t st) {
+    const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
+    if (have_instances) {
+        HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st));
+        HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st));
+    }
+    dgr::RenderFwdLightArgs r{};
+    r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
+    r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background; r.gt_depth = c.gt_depth;
+    r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_median = c.out_median_depth; r.out_alpha = c.out_alpha;
+    r.out_depth_var = c.out_depth_var; r.n_contrib = img.n_contrib; r.gau_uncertainty = c.gau_uncertainty;
+    r.gau_related_pixels = c.gau_related_pixels;
+    HIP_TRY(dgr::launch_render_fwd_light(r, st));
+    return DGR_OK;
+}
+
+int check_common(const FwdCommon& c) {
+    if (c.P < 0 || c.W <= 0 || c.H <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
+    if (c.P > 0 && !c.shs && !c.colors_precomp) { g_last_error = "need SHs or precomputed colours"; return DGR_ERR_BAD_ARGUMENT; }
+    if (c.P > 0 && !c.cov3D_precomp && (!c.scales || !c.rotations)) { g_last_error = "need scale/rotation or cov3D"; return DGR_ERR_BAD_ARGUMENT; }
+    if (dgr::tiles_x(c.W) > 65535 || dgr::tiles_y(c.H) > 65535) { g_last_error = "image too large"; return DGR_ERR_BAD_ARGUMENT; }
+    return DGR_OK;
+}
+
+// ---- state export (tests / profiling) ----
+enum ExportKind { EX_MEANS2D, EX_CONIC_OPACITY, EX_RGB, EX_CLAMPED, EX_TILES_TOUCHED, EX_KEYS };
+
+__global__ void export_geom_kernel(int kind, int P, dgr::GeometryView g, void* dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const bool vis = g.radii[i] > 0;
+    switch (kind) {
+        case EX_MEANS2D: {
+            const float4 q = g.rec[3 * (size_t)i];
+            ((float2*)dst)[i] = vis ? make_float2(q.x, q.y) : make_float2(0, 0);
+        } break;
+        case EX_CONIC_OPACITY: {
+            const float4 q0 = g.rec[3 * (size_t)i], q1 = g.rec[3 * (size_t)i + 1];
+            ((float4*)dst)[i] = vis ? make_float4(q1.x, q1.y, q1.z, q0.w) : make_float4(0, 0, 0, 0);
+        } break;
+        case EX_RGB: {
+            const float4 q = g.rec[3 * (size_t)i + 2];
+            float* d = (float*)dst + 3 * (size_t)i;
+            d[0] = vis ? q.x : 0; d[1] = vis ? q.y : 0; d[2] = vis ? q.z : 0;
+        } break;
+        case EX_CLAMPED: {
+            const uint8_t c = vis ? g.clamped[i] : 0;
+            uint8_t* d = (uint8_t*)dst + 3 * (size_t)i;
+            d[0] = c & 1; d[1] = (c >> 1) & 1; d[2] = (c >> 2) & 1;
+        } break;
+        case EX_TILES_TOUCHED: {
+            const ushort4 r = g.rect[i];
+            ((uint32_t*)dst)[i] = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
+        } break;
+    }
+}
+// the reference's sorted 64-bit keys: tile id << 32 | depth bits (rasterizer_impl.cu:97-100)
+__global__ void export_keys_kernel(dgr::ImageView img, dgr::BinningView bin, uint64_t* dst) {
+    const int tile = blockIdx.x;
+    const uint2 rg = img.ranges[tile];
+    for (uint32_t i = rg.x + threadIdx.x; i < rg.y; i += blockDim.x)
+        dst[i] = ((uint64_t)tile << 32) | (bin.keys[i] >> 32);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dgr_last_error(void) { return g_last_error.c_str(); }
+const char* dgr_version(void) { return "dgr_hip 0.1 gfx950"; }
+
+size_t dgr_geometry_bytes(int P) { return dgr::carve_geometry(nullptr, P).bytes; }
+size_t dgr_image_bytes(int width, int height) { return dgr::carve_image(nullptr, width, height).bytes; }
+size_t dgr_binning_bytes(int cap, int, int) { return dgr::carve_binning(nullptr, (size_t)(cap > 0 ? cap : 0)).bytes; }
+size_t dgr_light_backward_scratch_bytes(int P, int, int) { return dgr::carve_backward_scratch(nullptr, P).bytes; }
+
+int dgr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present) {
+    HIP_TRY(dgr::launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream));
+    return DGR_OK;
+}
+
+int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binning_buffer, int binning_capacity,
+                               char* image_buffer, int* status, int P, int D, int M, const float* background,
+                               int width, int height, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* opacities, const float* scales,
+                               float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                               const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                               float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth,
+                               float* out_median_depth, float* out_alpha, const float* gt_depth,
+                               float* out_depth_var, float* gau_uncertainty, int* gau_related_pixels, int* radii) {
+    hipStream_t st = (hipStream_t)stream;
+    FwdCommon c{P, D, M, width, height, background, means3D, shs, colors_precomp, opacities, scales, rotations,
+                cov3D_precomp, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+                out_color, out_depth, out_median_depth, out_alpha, gt_depth, out_depth_var, gau_uncertainty,
+                gau_related_pixels, radii};
+    int rc = check_common(c);
+    if (rc) return rc;
+    if (P == 0) {
+        if (status) HIP_TRY(hipMemsetAsync(status, 0, 16, st));
+        return zero_outputs(c, st);
+    }
+    dgr::GeometryView geom = dgr::carve_geometry(geometry_buffer, P);
+    dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
+    dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
+    if ((rc = forward_front(c, geom, img, binning_capacity, st))) return rc;
+    if ((rc = forward_back(c, geom, img, bin, binning_capacity > 0, st))) return rc;
+    if (status) HIP_TRY(hipMemcpyAsync(status, img.status, 16, hipMemcpyDeviceToDevice, st));
+    return DGR_OK;
+}
+
+int dgr_light_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn binningBuffer, dgr_alloc_fn imageBuffer,
+                      void* alloc_user, int P, int D, int M, const float* background, int width, int height,
+                      const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                      float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_median_depth,
+                      float* out_alpha, const float* gt_depth, float* out_depth_var, float* gau_uncertainty,
+                      int* gau_related_pixels, int* radii, int debug) {
+    hipStream_t st = (hipStream_t)stream;
+    FwdCommon c{P, D, M, width, height, background, means3D, shs, colors_precomp, opacities, scales, rotations,
+                cov3D_precomp, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+                out_color, out_depth, out_median_depth, out_alpha, gt_depth, out_depth_var, gau_uncertainty,
+                gau_related_pixels, radii};
+    int rc = check_common(c);
+    if (rc) return rc;
+    if (P == 0) return zero_outputs(c, st);
+    char* gptr = geometryBuffer(dgr_geometry_bytes(P), alloc_user);
+    char* iptr = imageBuffer(dgr_image_bytes(width, height), alloc_user);
+    if (!gptr || !iptr) { g_last_error = "allocation callback returned NULL"; return DGR_ERR_ALLOC; }
+    dgr::GeometryView geom = dgr::carve_geometry(gptr, P);
+    dgr::ImageView img = dgr::carve_image(iptr, width, height);
+    if ((rc = forward_front(c, geom, img, INT_MAX, st))) return rc;
+    // the one blocking read the reference also has (rasterizer_impl.cu:287): num_rendered sizes the binning buffer
+    int status[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(status, img.status, sizeof(status), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (status[2]) { g_last_error = "Point is filtered although prefiltered is set. This shouldn't happen!"; return DGR_ERR_PREFILTERED; }
+    const int R = status[0];
+    char* bptr = nullptr;
+    if (R > 0) {
+        bptr = binningBuffer(dgr_binning_bytes(R, width, height), alloc_user);
+        if (!bptr) { g_last_error = "allocation callback returned NULL"; return DGR_ERR_ALLOC; }
+    } else {
+        binningBuffer(0, alloc_user);
+    }
+    dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
+    if ((rc = forward_back(c, geom, img, bin, R > 0, st))) return rc;
+    if (debug) HIP_TRY(hipStreamSynchronize(st));  // CHECK_CUDA(..., debug): L/cuda_rasterizer/auxiliary.h:166-173
+    return R;
+}
+
+int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
+                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                       float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                       const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_median_depth,
+                       const float* dL_dpix_depth_var, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                       float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                       float* dL_dscale, float* dL_drot, int debug, float* dgndcs_dviewmatrix,
+                       const float* perspec_matrix, float* dL_dview, float* dg_camd_dviewmatrix,
+                       const float* gt_depth, int track_off, int map_off, char* scratch, size_t scratch_bytes) {
+    (void)R; (void)dgndcs_dviewmatrix; (void)dg_camd_dviewmatrix; (void)colors_precomp;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
+    if (P == 0) {  // L/rasterize_points.cu:188: nothing runs, gradients stay zero
+        HIP_TRY(hipMemsetAsync(dL_dview, 0, 16 * 4, st));
+        return DGR_OK;
+    }
+    if (scratch_bytes < dgr_light_backward_scratch_bytes(P, width, height) || !scratch) {
+        g_last_error = "backward scratch too small";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    dgr::GeometryView geom = dgr::carve_geometry(geom_buffer, P);
+    dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
+    dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
+    const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
+    HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st));
+
+    dgr::RenderBwdLightArgs r{};
+    r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
+    r.ranges = img.ranges; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
+    r.gt_depth = gt_depth; r.alphas = alphas; r.n_contrib = img.n_contrib; r.dL_dpix = dL_dpix;
+    r.dL_dpix_depth = dL_dpix_depth; r.dL_dpix_median = dL_dpix_median_depth; r.dL_dpix_var = dL_dpix_depth_var;
+    r.means3D = means3D; r.view = viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
+    HIP_TRY(dgr::launch_render_bwd_light(r, st));
+
+    dgr::PreprocessBwdArgs b{};
+    b.P = P; b.D = D; b.M = M; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs; b.scales = scales;
+    b.rotations = rotations; b.scale_modifier = scale_modifier; b.cov3D_precomp = cov3D_precomp; b.view = viewmatrix;
+    b.proj = projmatrix; b.campos = campos; b.perspec = perspec_matrix; b.tan_fovx = tan_fovx; b.tan_fovy = tan_fovy;
+    b.focal_y = height / (2.0f * tan_fovy);
+    b.focal_x = width / (2.0f * tan_fovx);
+    b.sh_vec_ok = aligned16(shs) && aligned16(dL_dsh);
+    b.track_off = track_off; b.map_off = map_off; b.geom = geom; b.acc = sc.acc;
+    b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor;
+    b.dL_ddepth = dL_ddepth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
+    b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part;
+    HIP_TRY(dgr::launch_preprocess_bwd(b, dL_dview, st));
+    if (debug) HIP_TRY(hipStreamSynchronize(st));
+    return DGR_OK;
+}
+
+long dgr_state_export(void* stream, const char* name, int P, int width, int height, int num_rendered,
+                      const char* geom_buffer, const char* binning_buffer, const char* image_buffer, void* dst) {
+    hipStream_t st = (hipStream_t)stream;
+    dgr::GeometryView g = dgr::carve_geometry(const_cast<char*>(geom_buffer), P);
+    dgr::ImageView img = dgr::carve_image(const_cast<char*>(image_buffer), width, height);
+    dgr::BinningView bin = dgr::carve_binning(const_cast<char*>(binning_buffer), (size_t)num_rendered);
+    const size_t tiles = (size_t)dgr::tiles_x(width) * dgr::tiles_y(height), N = (size_t)width * height;
+    auto copy = [&](const void* src, size_t bytes) -> int {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    auto geomk = [&](int kind) -> int {
+        if (P > 0) hipLaunchKernelGGL(export_geom_kernel, dim3((P + 255) / 256), dim3(256), 0, st, kind, P, g, dst);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    const std::string n(name);
+    if (n == "depths") return copy(g.depths, 4 * (size_t)P) ? -1 : P;
+    if (n == "radii") return copy(g.radii, 4 * (size_t)P) ? -1 : P;
+    if (n == "cov3D") return copy(g.cov3D, 24 * (size_t)P) ? -1 : 6L * P;
+    if (n == "means2D") return geomk(EX_MEANS2D) ? -1 : 2L * P;
+    if (n == "conic_opacity") return geomk(EX_CONIC_OPACITY) ? -1 : 4L * P;
+    if (n == "rgb") return geomk(EX_RGB) ? -1 : 3L * P;
+    if (n == "clamped") return geomk(EX_CLAMPED) ? -1 : 3L * P;
+    if (n == "tiles_touched") return geomk(EX_TILES_TOUCHED) ? -1 : P;
+    if (n == "point_list") return copy(bin.point_list, 4 * (size_t)num_rendered) ? -1 : num_rendered;
+    if (n == "keys") {
+        hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)tiles), dim3(256), 0, st, img, bin, (uint64_t*)dst);
+        if (hipGetLastError() != hipSuccess) return -1;
+        return num_rendered;
+    }
+    if (n == "ranges") return copy(img.ranges, 8 * tiles) ? -1 : (long)(2 * tiles);
+    if (n == "n_contrib") return copy(img.n_contrib, 4 * N) ? -1 : (long)N;
+    g_last_error = "unknown state array: " + n;
+    return -1;
+}
+
+}  // extern "C"

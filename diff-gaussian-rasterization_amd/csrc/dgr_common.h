@@ -1,0 +1,113 @@
+// dgr_common.h -- state-buffer layouts and small device helpers shared by the gfx950 kernels.
+//
+// The reference carves GeometryState / BinningState / ImageState out of three byte buffers
+// (L/cuda_rasterizer/rasterizer_impl.h:29-72, rasterizer_impl.cu:155-193).  The buffers stay
+// opaque at the boundary, so the layout here is chosen for the MI355X kernels instead:
+//   geometry : one 48-byte render record per Gaussian (3 x float4, gathered as whole 16-B
+//              pieces by the blend kernels), depth, radius, cov3D, tile rect (4 x u16), clamp bits
+//   image    : per-tile {count, fill, range} + per-pixel n_contrib (+ full: final T, n_valid)
+//   binning  : per-instance 64-bit sort keys (depth bits << 32 | gaussian id) and the sorted id list
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DGR_BLOCK_X 16  // cuda_rasterizer/config.h:16-17 -- fixes the tile-key layout
+#define DGR_BLOCK_Y 16
+#define DGR_TILE_PIX 256
+#define DGR_NEAR 0.2f  // cuda_rasterizer/auxiliary.h:152
+
+namespace dgr {
+
+__host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- render record ---------------------------------------------------------------------------
+// q0 = {x_pix, y_pix, depth, opacity}   (means2D, depths, conic_opacity.w of the reference)
+// q1 = {conic a, conic b, conic c, 0}
+// q2 = {r, g, b, 0}                     (geomState.rgb, or a copy of colors_precomp)
+struct GeometryView {
+    float4* rec;        // [3P]
+    float* depths;      // [P]
+    int* radii;         // [P] internal copy (the caller's `radii` may be NULL)
+    float* cov3D;       // [6P]
+    ushort4* rect;      // [P] {xmin, ymin, xmax, ymax} in tiles; all-zero when culled
+    uint8_t* clamped;   // [P] bit c set <=> channel c was clamped at 0
+    size_t bytes;
+};
+__host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
+    GeometryView g;
+    size_t o = 0;
+    g.rec = (float4*)(base + o);      o = align_up(o + sizeof(float4) * 3 * (size_t)P, 256);
+    g.depths = (float*)(base + o);    o = align_up(o + sizeof(float) * (size_t)P, 256);
+    g.radii = (int*)(base + o);       o = align_up(o + sizeof(int) * (size_t)P, 256);
+    g.cov3D = (float*)(base + o);     o = align_up(o + sizeof(float) * 6 * (size_t)P, 256);
+    g.rect = (ushort4*)(base + o);    o = align_up(o + sizeof(ushort4) * (size_t)P, 256);
+    g.clamped = (uint8_t*)(base + o); o = align_up(o + (size_t)P, 256);
+    g.bytes = o;
+    return g;
+}
+
+struct ImageView {
+    int* status;          // [4] {num_rendered, overflow, prefiltered violation, reserved}
+    uint32_t* tile_count; // [tiles] instances per tile (histogram filled by preprocess)
+    uint32_t* tile_fill;  // [tiles] slot allocator used while emitting instances
+    uint2* ranges;        // [tiles] {start, end} into point_list
+    uint32_t* n_contrib;  // [N]
+    float* final_T;       // [N]   (full variant)
+    uint32_t* n_valid;    // [N]   (full variant)
+    size_t bytes;
+};
+__host__ __device__ inline int tiles_x(int W) { return (W + DGR_BLOCK_X - 1) / DGR_BLOCK_X; }
+__host__ __device__ inline int tiles_y(int H) { return (H + DGR_BLOCK_Y - 1) / DGR_BLOCK_Y; }
+__host__ __device__ inline ImageView carve_image(char* base, int W, int H) {
+    ImageView v;
+    const size_t tiles = (size_t)tiles_x(W) * tiles_y(H), N = (size_t)W * H;
+    size_t o = 0;
+    v.status = (int*)(base + o);          o = align_up(o + 4 * sizeof(int), 256);
+    v.tile_count = (uint32_t*)(base + o); o = align_up(o + tiles * 4, 256);
+    v.tile_fill = (uint32_t*)(base + o);  o = align_up(o + tiles * 4, 256);
+    v.ranges = (uint2*)(base + o);        o = align_up(o + tiles * 8, 256);
+    v.n_contrib = (uint32_t*)(base + o);  o = align_up(o + N * 4, 256);
+    v.final_T = (float*)(base + o);       o = align_up(o + N * 4, 256);
+    v.n_valid = (uint32_t*)(base + o);    o = align_up(o + N * 4, 256);
+    v.bytes = o;
+    return v;
+}
+
+struct BinningView {
+    uint32_t* point_list;  // [cap] sorted gaussian ids (binningState.point_list); at offset 0 so that the
+                           //       backward can find it without knowing the capacity
+    uint64_t* keys;        // [cap] (depth bits << 32 | gaussian id), grouped by tile, sorted in place
+    size_t bytes;
+};
+__host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
+    BinningView b;
+    size_t o = 0;
+    b.point_list = (uint32_t*)(base + o); o = align_up(o + 4 * cap, 256);
+    b.keys = (uint64_t*)(base + o);       o = align_up(o + 8 * cap, 256);
+    b.bytes = o;
+    return b;
+}
+
+// ---- backward scratch --------------------------------------------------------------------------
+// One 64-byte accumulator row per Gaussian so that every atomic of a (pixel, Gaussian) pair lands
+// in a single cache line:
+//  [0..2] dL/dcolour  [3] dL/ddepth (blend + variance terms)  [4..5] dL/dmean2D
+//  [6..8] dL/dconic (xx, xy, yy)  [9] dL/dopacity  [10..12] median-depth term of dL/dmean3D
+//  [13] sum of the blend-only depth term (pose gradient)  [14..15] unused
+#define DGR_ACC_STRIDE 16
+struct BackwardScratch {
+    float* acc;         // [P * 16]
+    float* pose_part;   // [blocks * 12] per-block partial sums of the pose gradient
+    size_t bytes;
+};
+__host__ __device__ inline BackwardScratch carve_backward_scratch(char* base, int P) {
+    BackwardScratch s;
+    size_t o = 0;
+    s.acc = (float*)(base + o);       o = align_up(o + sizeof(float) * DGR_ACC_STRIDE * (size_t)P, 256);
+    const size_t blocks = ((size_t)P + 255) / 256;
+    s.pose_part = (float*)(base + o); o = align_up(o + sizeof(float) * 12 * blocks, 256);
+    s.bytes = o;
+    return s;
+}
+
+}  // namespace dgr

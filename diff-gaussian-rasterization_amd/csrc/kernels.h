@@ -1,0 +1,109 @@
+// kernels.h -- argument blocks and launch entry points of the gfx950 kernels (internal).
+#pragma once
+#include "dgr_common.h"
+
+namespace dgr {
+
+struct PreprocessFwdArgs {
+    int P, D, M, W, H, grid_x, grid_y;
+    const float* means3D;
+    const float* scales;
+    float scale_modifier;
+    const float* rotations;
+    const float* opacities;
+    const float* shs;
+    const float* cov3D_precomp;
+    const float* colors_precomp;
+    const float* view;
+    const float* proj;
+    const float* campos;
+    float tan_fovx, tan_fovy, focal_x, focal_y;
+    int prefiltered;
+    bool sh_vec_ok;
+    GeometryView geom;
+    int* radii_out;        // caller's radii tensor (may be NULL)
+    uint32_t* tile_count;  // zeroed before launch
+    int* status;
+};
+
+struct PreprocessBwdArgs {
+    int P, D, M;
+    const float* means3D;
+    const int* radii;
+    const float* shs;
+    const float* scales;
+    const float* rotations;
+    float scale_modifier;
+    const float* cov3D_precomp;
+    const float* view;
+    const float* proj;
+    const float* campos;
+    const float* perspec;
+    float tan_fovx, tan_fovy, focal_x, focal_y;
+    bool sh_vec_ok;
+    int track_off, map_off;
+    GeometryView geom;
+    const float* acc;   // [P,16] sums written by the blend backward
+    float* dL_dmean2D;  // [P,3]
+    float* dL_dconic;   // [P,4] optional
+    float* dL_dopacity; // [P]
+    float* dL_dcolor;   // [P,3] optional
+    float* dL_ddepth;   // [P]   optional
+    float* dL_dmean3D;  // [P,3]
+    float* dL_dcov3D;   // [P,6]
+    float* dL_dsh;      // [P,M,3] optional (M == 0)
+    float* dL_dscale;   // [P,3]
+    float* dL_drot;     // [P,4]
+    float* pose_part;   // [blocks,12]
+};
+
+struct RenderFwdLightArgs {
+    int W, H, grid_x, grid_y;
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float4* rec;
+    const float* bg;
+    const float* gt_depth;
+    float* out_color;
+    float* out_depth;
+    float* out_median;
+    float* out_alpha;
+    float* out_depth_var;
+    uint32_t* n_contrib;
+    float* gau_uncertainty;
+    int* gau_related_pixels;
+};
+
+struct RenderBwdLightArgs {
+    int W, H, grid_x, grid_y;
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float4* rec;
+    const float* bg;
+    const float* gt_depth;
+    const float* alphas;
+    const uint32_t* n_contrib;
+    const float* dL_dpix;
+    const float* dL_dpix_depth;
+    const float* dL_dpix_median;
+    const float* dL_dpix_var;
+    const float* means3D;
+    const float* view;
+    float* acc;  // [P,16]
+    int track_off, map_off;
+};
+
+// ---- launchers (each enqueues on `stream` and returns the hipError_t of the launch) ----
+hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream);
+hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hipStream_t stream);
+hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream);
+
+// binning: tile_count -> ranges (+ total in status[0], overflow in status[1]); emit keys; sort tiles
+hipError_t launch_scan_tiles(ImageView img, int tiles, int capacity, hipStream_t stream);
+hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream);
+hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);
+
+hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream);
+hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stream);
+
+}  // namespace dgr

@@ -1,0 +1,609 @@
+// preprocess.hip -- per-Gaussian kernels for gfx950: forward preprocess, fused backward
+// preprocess (+ pose-gradient reduction) and the frustum mark.
+//
+// Replaces, on the hot path:
+//   forward : preprocessCUDA + computeCov3D + computeCov2D + computeColorFromSH
+//             (*/cuda_rasterizer/forward.cu:20-256) and the per-tile histogram that stands in for
+//             tiles_touched + InclusiveSum (L/cuda_rasterizer/rasterizer_impl.cu:283)
+//   backward: computeCov2DCUDA + preprocessCUDA + computeColorFromSH + computeCov3D
+//             (L/cuda_rasterizer/backward.cu:20-416) and pose_gradient_preCUDA (:701-751)
+//   checkFrustum (L/cuda_rasterizer/rasterizer_impl.cu:54-66)
+//
+// Both kernels are HBM-bound (one thread per Gaussian, ~250-500 B of traffic each), so the
+// arithmetic is written in the reference's association order with FMA contraction OFF: radii,
+// tile rects and depth bits -- the integer path -- then agree bit for bit with the CPU oracle.
+#include "dgr_common.h"
+#include "kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace dgr {
+namespace {
+
+// column-major 3x3: m[c][r]; (A*B)[c][r] = A[0][r]B[c][0] + A[1][r]B[c][1] + A[2][r]B[c][2]
+struct M3 {
+    float m[3][3];
+};
+__device__ __forceinline__ M3 mul(const M3& A, const M3& B) {
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+    return R;
+}
+__device__ __forceinline__ M3 transpose(const M3& A) {
+    M3 R;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) R.m[c][r] = A.m[r][c];
+    return R;
+}
+__device__ __forceinline__ float dot3(float3 a, float3 b) {
+    float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z;
+    return tx + ty + tz;
+}
+
+__device__ __forceinline__ float3 xform4x3(float3 p, const float* m) {
+    return make_float3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14]);
+}
+__device__ __forceinline__ float4 xform4x4(float3 p, const float* m) {
+    return make_float4(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12], m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+                       m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14], m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15]);
+}
+
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+__device__ __forceinline__ void get_rect(float px, float py, int r, int gx, int gy, int& x0, int& y0, int& x1, int& y1) {
+    x0 = min(gx, max(0, (int)((px - (float)r) / (float)DGR_BLOCK_X)));
+    y0 = min(gy, max(0, (int)((py - (float)r) / (float)DGR_BLOCK_Y)));
+    x1 = min(gx, max(0, (int)((px + (float)r + (float)DGR_BLOCK_X - 1.0f) / (float)DGR_BLOCK_X)));
+    y1 = min(gy, max(0, (int)((py + (float)r + (float)DGR_BLOCK_Y - 1.0f) / (float)DGR_BLOCK_Y)));
+}
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ const float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                   -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                   0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                   -0.5900435899266435f};
+
+__device__ __forceinline__ float3 operator+(float3 a, float3 b) { return make_float3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ float3 operator-(float3 a, float3 b) { return make_float3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float3 operator*(float s, float3 a) { return make_float3(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ float3 operator*(float3 a, float s) { return make_float3(a.x * s, a.y * s, a.z * s); }
+
+// Loads the SH coefficients a degree needs into registers.  M == 16 rows are 192 B = 12 x 16 B, so a
+// lane fetches whole 16-B pieces; consecutive lanes cover one contiguous 12 KB span per wave.
+struct SHCoeffs {
+    float3 c[16];
+};
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, int idx, int deg, int M, bool vec_ok, SHCoeffs& s) {
+    const int ncoef = (deg + 1) * (deg + 1);
+    if (vec_ok && M == 16) {
+        const float4* p = reinterpret_cast<const float4*>(shs + (size_t)idx * 48);
+        float f[48];
+        const int nvec = (3 * ncoef + 3) >> 2;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            float4 v = (i < nvec) ? p[i] : make_float4(0, 0, 0, 0);
+            f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) s.c[k] = make_float3(f[3 * k], f[3 * k + 1], f[3 * k + 2]);
+    } else {
+        const float* p = shs + (size_t)idx * M * 3;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            s.c[k] = (k < ncoef && k < M) ? make_float3(p[3 * k], p[3 * k + 1], p[3 * k + 2]) : make_float3(0, 0, 0);
+    }
+}
+
+// */cuda_rasterizer/forward.cu:74-113 up to `cov` (before the +0.3 low-pass), shared with the backward.
+struct Cov2D {
+    float3 t;
+    float txtz, tytz;
+    M3 W, T, Vrk, cov;
+};
+__device__ __forceinline__ void cov2d_common(float3 mean, float fx, float fy, float tanx, float tany, const float* c3,
+                                             const float* v, Cov2D& o) {
+    float3 t = xform4x3(mean, v);
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    o.txtz = t.x / t.z;
+    o.tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, o.txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, o.tytz)) * t.z;
+    o.t = t;
+    M3 J;
+    J.m[0][0] = fx / t.z; J.m[0][1] = 0.0f; J.m[0][2] = -(fx * t.x) / (t.z * t.z);
+    J.m[1][0] = 0.0f; J.m[1][1] = fy / t.z; J.m[1][2] = -(fy * t.y) / (t.z * t.z);
+    J.m[2][0] = 0.0f; J.m[2][1] = 0.0f; J.m[2][2] = 0.0f;
+    o.W.m[0][0] = v[0]; o.W.m[0][1] = v[4]; o.W.m[0][2] = v[8];
+    o.W.m[1][0] = v[1]; o.W.m[1][1] = v[5]; o.W.m[1][2] = v[9];
+    o.W.m[2][0] = v[2]; o.W.m[2][1] = v[6]; o.W.m[2][2] = v[10];
+    o.T = mul(o.W, J);
+    o.Vrk.m[0][0] = c3[0]; o.Vrk.m[0][1] = c3[1]; o.Vrk.m[0][2] = c3[2];
+    o.Vrk.m[1][0] = c3[1]; o.Vrk.m[1][1] = c3[3]; o.Vrk.m[1][2] = c3[4];
+    o.Vrk.m[2][0] = c3[2]; o.Vrk.m[2][1] = c3[4]; o.Vrk.m[2][2] = c3[5];
+    o.cov = mul(mul(transpose(o.T), transpose(o.Vrk)), o.T);
+}
+
+__device__ __forceinline__ void quat_to_R(const float4 q, M3& R) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;  // not normalised (forward.cu:127)
+    R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[0][1] = 2.f * (x * y - r * z); R.m[0][2] = 2.f * (x * z + r * y);
+    R.m[1][0] = 2.f * (x * y + r * z); R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[1][2] = 2.f * (y * z - r * x);
+    R.m[2][0] = 2.f * (x * z - r * y); R.m[2][1] = 2.f * (y * z + r * x); R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+__device__ __forceinline__ M3 diag3(float a, float b, float c) {
+    M3 S;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) S.m[i][j] = 0.0f;
+    S.m[0][0] = a; S.m[1][1] = b; S.m[2][2] = c;
+    return S;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+
+    int radius = 0;
+    ushort4 rect = make_ushort4(0, 0, 0, 0);
+    const float3 p_orig = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+
+    // in_frustum (cuda_rasterizer/auxiliary.h:139-164)
+    const float4 p_hom = xform4x4(p_orig, a.proj);
+    const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+    const float3 p_proj = make_float3(p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w);
+    const float3 p_view = xform4x3(p_orig, a.view);
+    bool live = !(p_view.z <= DGR_NEAR);
+    if (!live && a.prefiltered) a.status[2] = 1;
+
+    if (live) {
+        float c3[6];
+        if (a.cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+            // computeCov3D (forward.cu:118-152): M = S*R, Sigma = M^T M
+            const float3 sc = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+            const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2],
+                                         a.rotations[4 * idx + 3]);
+            M3 R;
+            quat_to_R(q, R);
+            const M3 S = diag3(a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z);
+            const M3 Mm = mul(S, R);
+            const M3 Sigma = mul(transpose(Mm), Mm);
+            c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
+            c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+#pragma unroll
+            for (int i = 0; i < 6; i++) a.geom.cov3D[6 * (size_t)idx + i] = c3[i];
+        }
+        Cov2D c;
+        cov2d_common(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.view, c);
+        const float cx = c.cov.m[0][0] + 0.3f, cy = c.cov.m[0][1], cz = c.cov.m[1][1] + 0.3f;
+        const float det = (cx * cz - cy * cy);
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float3 conic = make_float3(cz * det_inv, -cy * det_inv, cx * det_inv);
+            const float mid = 0.5f * (cx + cz);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float pix = ndc2pix(p_proj.x, a.W), piy = ndc2pix(p_proj.y, a.H);
+            int x0, y0, x1, y1;
+            get_rect(pix, piy, (int)my_radius, a.grid_x, a.grid_y, x0, y0, x1, y1);
+            if ((x1 - x0) * (y1 - y0) != 0) {
+                float3 rgb;
+                if (a.colors_precomp) {
+                    rgb = make_float3(a.colors_precomp[3 * (size_t)idx], a.colors_precomp[3 * (size_t)idx + 1],
+                                      a.colors_precomp[3 * (size_t)idx + 2]);
+                } else {
+                    // computeColorFromSH (forward.cu:20-71)
+                    SHCoeffs s;
+                    load_sh(a.shs, idx, a.D, a.M, a.sh_vec_ok, s);
+                    const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
+                    float3 dir = p_orig - cam;
+                    const float len = sqrtf(dot3(dir, dir));
+                    dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
+                    float3 res = SH_C0 * s.c[0];
+                    if (a.D > 0) {
+                        const float x = dir.x, y = dir.y, z = dir.z;
+                        res = res - SH_C1 * y * s.c[1] + SH_C1 * z * s.c[2] - SH_C1 * x * s.c[3];
+                        if (a.D > 1) {
+                            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                            res = res + SH_C2[0] * xy * s.c[4] + SH_C2[1] * yz * s.c[5] +
+                                  SH_C2[2] * (2.0f * zz - xx - yy) * s.c[6] + SH_C2[3] * xz * s.c[7] +
+                                  SH_C2[4] * (xx - yy) * s.c[8];
+                            if (a.D > 2) {
+                                res = res + SH_C3[0] * y * (3.0f * xx - yy) * s.c[9] + SH_C3[1] * xy * z * s.c[10] +
+                                      SH_C3[2] * y * (4.0f * zz - xx - yy) * s.c[11] +
+                                      SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * s.c[12] +
+                                      SH_C3[4] * x * (4.0f * zz - xx - yy) * s.c[13] +
+                                      SH_C3[5] * z * (xx - yy) * s.c[14] + SH_C3[6] * x * (xx - 3.0f * yy) * s.c[15];
+                            }
+                        }
+                    }
+                    res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+                    a.geom.clamped[idx] = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
+                    rgb = make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
+                }
+                radius = (int)my_radius;
+                rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+                a.geom.depths[idx] = p_view.z;
+                float4* rec = a.geom.rec + 3 * (size_t)idx;
+                rec[0] = make_float4(pix, piy, p_view.z, a.opacities[idx]);
+                rec[1] = make_float4(conic.x, conic.y, conic.z, 0.0f);
+                rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
+                // per-tile histogram: replaces tiles_touched + the scan over P; the order in which
+                // instances later land inside a tile segment is irrelevant because every segment is
+                // sorted on (depth bits, gaussian id).
+                for (int y = y0; y < y1; y++)
+                    for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.grid_x + x], 1u);
+            }
+        }
+    }
+    a.geom.radii[idx] = radius;
+    if (a.radii_out) a.radii_out[idx] = radius;
+    a.geom.rect[idx] = rect;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means,
+                                                           const float* __restrict__ view, uint8_t* present) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float3 p = make_float3(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]);
+    present[idx] = !(xform4x3(p, view).z <= DGR_NEAR);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused per-Gaussian backward.  Order of the dL_dmean3D accumulation follows the reference's kernel
+// order: blend-kernel median term, computeCov2DCUDA, preprocessCUDA (2D mean, depth, SH).
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    float pose[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) pose[i] = 0.0f;
+
+    if (idx < a.P) {
+        const bool vis = a.radii[idx] > 0;
+        float acc[16];
+        if (vis) {
+            const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)idx * DGR_ACC_STRIDE);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float4 v = ap[i];
+                acc[4 * i] = v.x; acc[4 * i + 1] = v.y; acc[4 * i + 2] = v.z; acc[4 * i + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+        }
+        const float3 m = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+
+        // ---- outputs that are plain copies of the blend kernel's sums
+        // (with map_off the blend kernel still sums acc[4], acc[5] for the pose gradient, but the
+        //  reference leaves every per-Gaussian gradient at zero: L/cuda_rasterizer/backward.cu:666)
+        a.dL_dmean2D[3 * (size_t)idx + 0] = a.map_off ? 0.0f : acc[4];
+        a.dL_dmean2D[3 * (size_t)idx + 1] = a.map_off ? 0.0f : acc[5];
+        a.dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
+        a.dL_dopacity[idx] = acc[9];
+        if (a.dL_dcolor) {
+            a.dL_dcolor[3 * (size_t)idx + 0] = acc[0];
+            a.dL_dcolor[3 * (size_t)idx + 1] = acc[1];
+            a.dL_dcolor[3 * (size_t)idx + 2] = acc[2];
+        }
+        if (a.dL_ddepth) a.dL_ddepth[idx] = acc[3];
+        if (a.dL_dconic) {
+            float4* o = reinterpret_cast<float4*>(a.dL_dconic) + idx;
+            *o = make_float4(acc[6], acc[7], 0.0f, acc[8]);
+        }
+
+        float3 dmean = make_float3(acc[10], acc[11], acc[12]);
+        float dcov[6] = {0, 0, 0, 0, 0, 0};
+        float3 dscale = make_float3(0, 0, 0);
+        float4 drot = make_float4(0, 0, 0, 0);
+        const bool do_map = vis && !a.map_off;
+        const int ncoef_out = a.M;
+
+        if (do_map) {
+            // ---------------- computeCov2DCUDA (L/cuda_rasterizer/backward.cu:144-276)
+            float c3[6];
+            const float* c3p = a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : a.geom.cov3D + 6 * (size_t)idx;
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = c3p[i];
+            const float3 dconic = make_float3(acc[6], acc[7], acc[8]);
+            Cov2D c;
+            cov2d_common(m, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.view, c);
+            const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+            const float x_grad_mul = (c.txtz < -limx || c.txtz > limx) ? 0.f : 1.f;
+            const float y_grad_mul = (c.tytz < -limy || c.tytz > limy) ? 0.f : 1.f;
+            const float h_x = a.focal_x, h_y = a.focal_y;
+            const M3& T = c.T; const M3& Vrk = c.Vrk; const M3& W = c.W; const float3 t = c.t;
+            const float ca = c.cov.m[0][0] + 0.3f, cb = c.cov.m[0][1], cc = c.cov.m[1][1] + 0.3f;
+            const float denom = ca * cc - cb * cb;
+            float dL_da = 0, dL_db = 0, dL_dc = 0;
+            const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+            if (denom2inv != 0) {
+                dL_da = denom2inv * (-cc * cc * dconic.x + 2 * cb * cc * dconic.y + (denom - ca * cc) * dconic.z);
+                dL_dc = denom2inv * (-ca * ca * dconic.z + 2 * ca * cb * dconic.y + (denom - ca * cc) * dconic.x);
+                dL_db = denom2inv * 2 * (cb * cc * dconic.x - (denom + 2 * cb * cb) * dconic.y + ca * cb * dconic.z);
+                dcov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
+                dcov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
+                dcov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
+                dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
+                dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
+                dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
+            }
+            const float dL_dT00 = 2 * (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_da +
+                                  (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_db;
+            const float dL_dT01 = 2 * (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_da +
+                                  (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_db;
+            const float dL_dT02 = 2 * (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_da +
+                                  (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_db;
+            const float dL_dT10 = 2 * (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc +
+                                  (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_db;
+            const float dL_dT11 = 2 * (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc +
+                                  (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_db;
+            const float dL_dT12 = 2 * (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc +
+                                  (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_db;
+            const float dL_dJ00 = W.m[0][0] * dL_dT00 + W.m[0][1] * dL_dT01 + W.m[0][2] * dL_dT02;
+            const float dL_dJ02 = W.m[2][0] * dL_dT00 + W.m[2][1] * dL_dT01 + W.m[2][2] * dL_dT02;
+            const float dL_dJ11 = W.m[1][0] * dL_dT10 + W.m[1][1] * dL_dT11 + W.m[1][2] * dL_dT12;
+            const float dL_dJ12 = W.m[2][0] * dL_dT10 + W.m[2][1] * dL_dT11 + W.m[2][2] * dL_dT12;
+            const float tz = 1.f / t.z;
+            const float tz2 = tz * tz;
+            const float tz3 = tz2 * tz;
+            const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+            const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+            const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+            const float* v = a.view;
+            dmean.x += v[0] * dL_dtx + v[1] * dL_dty + v[2] * dL_dtz;
+            dmean.y += v[4] * dL_dtx + v[5] * dL_dty + v[6] * dL_dtz;
+            dmean.z += v[8] * dL_dtx + v[9] * dL_dty + v[10] * dL_dtz;
+
+            // ---------------- preprocessCUDA (L/cuda_rasterizer/backward.cu:348-416)
+            const float* pj = a.proj;
+            const float4 m_hom = xform4x4(m, pj);
+            const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+            const float mul1 = (pj[0] * m.x + pj[4] * m.y + pj[8] * m.z + pj[12]) * m_w * m_w;
+            const float mul2 = (pj[1] * m.x + pj[5] * m.y + pj[9] * m.z + pj[13]) * m_w * m_w;
+            const float g2x = acc[4], g2y = acc[5];
+            float3 d1;
+            d1.x = (pj[0] * m_w - pj[3] * mul1) * g2x + (pj[1] * m_w - pj[3] * mul2) * g2y;
+            d1.y = (pj[4] * m_w - pj[7] * mul1) * g2x + (pj[5] * m_w - pj[7] * mul2) * g2y;
+            d1.z = (pj[8] * m_w - pj[11] * mul1) * g2x + (pj[9] * m_w - pj[11] * mul2) * g2y;
+            dmean.x += d1.x; dmean.y += d1.y; dmean.z += d1.z;
+            const float mul3 = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
+            float3 d2;
+            d2.x = (v[2] - v[3] * mul3) * acc[3];
+            d2.y = (v[6] - v[7] * mul3) * acc[3];
+            d2.z = (v[10] - v[11] * mul3) * acc[3];
+            dmean.x += d2.x; dmean.y += d2.y; dmean.z += d2.z;
+        }
+
+        // ---------------- SH backward (L/cuda_rasterizer/backward.cu:20-139); writes the dense dL_dsh row
+        if (a.dL_dsh && ncoef_out > 0) {
+            float3* out = reinterpret_cast<float3*>(a.dL_dsh) + (size_t)idx * ncoef_out;
+            if (do_map && a.shs) {
+                SHCoeffs s;
+                load_sh(a.shs, idx, a.D, a.M, a.sh_vec_ok, s);
+                const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
+                const float3 dir_orig = m - cam;
+                const float len = sqrtf(dot3(dir_orig, dir_orig));
+                const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
+                const uint8_t cl = a.geom.clamped[idx];
+                float3 dRGB = make_float3(acc[0], acc[1], acc[2]);
+                dRGB.x *= (cl & 1) ? 0 : 1;
+                dRGB.y *= (cl & 2) ? 0 : 1;
+                dRGB.z *= (cl & 4) ? 0 : 1;
+                float3 dRGBdx = make_float3(0, 0, 0), dRGBdy = make_float3(0, 0, 0), dRGBdz = make_float3(0, 0, 0);
+                const float x = dir.x, y = dir.y, z = dir.z;
+                float3 g[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) g[k] = make_float3(0, 0, 0);
+                g[0] = SH_C0 * dRGB;
+                if (a.D > 0) {
+                    g[1] = (-SH_C1 * y) * dRGB;
+                    g[2] = (SH_C1 * z) * dRGB;
+                    g[3] = (-SH_C1 * x) * dRGB;
+                    dRGBdx = -SH_C1 * s.c[3];
+                    dRGBdy = -SH_C1 * s.c[1];
+                    dRGBdz = SH_C1 * s.c[2];
+                    if (a.D > 1) {
+                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                        g[4] = (SH_C2[0] * xy) * dRGB;
+                        g[5] = (SH_C2[1] * yz) * dRGB;
+                        g[6] = (SH_C2[2] * (2.f * zz - xx - yy)) * dRGB;
+                        g[7] = (SH_C2[3] * xz) * dRGB;
+                        g[8] = (SH_C2[4] * (xx - yy)) * dRGB;
+                        dRGBdx = dRGBdx + (SH_C2[0] * y * s.c[4] + SH_C2[2] * 2.f * -x * s.c[6] + SH_C2[3] * z * s.c[7] + SH_C2[4] * 2.f * x * s.c[8]);
+                        dRGBdy = dRGBdy + (SH_C2[0] * x * s.c[4] + SH_C2[1] * z * s.c[5] + SH_C2[2] * 2.f * -y * s.c[6] + SH_C2[4] * 2.f * -y * s.c[8]);
+                        dRGBdz = dRGBdz + (SH_C2[1] * y * s.c[5] + SH_C2[2] * 2.f * 2.f * z * s.c[6] + SH_C2[3] * x * s.c[7]);
+                        if (a.D > 2) {
+                            g[9] = (SH_C3[0] * y * (3.f * xx - yy)) * dRGB;
+                            g[10] = (SH_C3[1] * xy * z) * dRGB;
+                            g[11] = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dRGB;
+                            g[12] = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dRGB;
+                            g[13] = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dRGB;
+                            g[14] = (SH_C3[5] * z * (xx - yy)) * dRGB;
+                            g[15] = (SH_C3[6] * x * (xx - 3.f * yy)) * dRGB;
+                            dRGBdx = dRGBdx + (SH_C3[0] * s.c[9] * 3.f * 2.f * xy + SH_C3[1] * s.c[10] * yz + SH_C3[2] * s.c[11] * -2.f * xy +
+                                               SH_C3[3] * s.c[12] * -3.f * 2.f * xz + SH_C3[4] * s.c[13] * (-3.f * xx + 4.f * zz - yy) +
+                                               SH_C3[5] * s.c[14] * 2.f * xz + SH_C3[6] * s.c[15] * 3.f * (xx - yy));
+                            dRGBdy = dRGBdy + (SH_C3[0] * s.c[9] * 3.f * (xx - yy) + SH_C3[1] * s.c[10] * xz +
+                                               SH_C3[2] * s.c[11] * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s.c[12] * -3.f * 2.f * yz +
+                                               SH_C3[4] * s.c[13] * -2.f * xy + SH_C3[5] * s.c[14] * -2.f * yz +
+                                               SH_C3[6] * s.c[15] * -3.f * 2.f * xy);
+                            dRGBdz = dRGBdz + (SH_C3[1] * s.c[10] * xy + SH_C3[2] * s.c[11] * 4.f * 2.f * yz +
+                                               SH_C3[3] * s.c[12] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s.c[13] * 4.f * 2.f * xz +
+                                               SH_C3[5] * s.c[14] * (xx - yy));
+                        }
+                    }
+                }
+                const float3 dL_ddir = make_float3(dot3(dRGBdx, dRGB), dot3(dRGBdy, dRGB), dot3(dRGBdz, dRGB));
+                // dnormvdv (cuda_rasterizer/auxiliary.h:109-119)
+                {
+                    const float3 vv = dir_orig, dv = dL_ddir;
+                    const float sum2 = vv.x * vv.x + vv.y * vv.y + vv.z * vv.z;
+                    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+                    dmean.x += ((+sum2 - vv.x * vv.x) * dv.x - vv.y * vv.x * dv.y - vv.z * vv.x * dv.z) * invsum32;
+                    dmean.y += (-vv.x * vv.y * dv.x + (sum2 - vv.y * vv.y) * dv.y - vv.z * vv.y * dv.z) * invsum32;
+                    dmean.z += (-vv.x * vv.z * dv.x - vv.y * vv.z * dv.y + (sum2 - vv.z * vv.z) * dv.z) * invsum32;
+                }
+                if (a.sh_vec_ok && ncoef_out == 16) {
+                    float f[48];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) { f[3 * k] = g[k].x; f[3 * k + 1] = g[k].y; f[3 * k + 2] = g[k].z; }
+                    float4* o4 = reinterpret_cast<float4*>(out);
+#pragma unroll
+                    for (int i = 0; i < 12; i++) o4[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (k < ncoef_out) out[k] = g[k];
+                }
+            } else {
+                if (a.sh_vec_ok && ncoef_out == 16) {
+                    float4* o4 = reinterpret_cast<float4*>(out);
+#pragma unroll
+                    for (int i = 0; i < 12; i++) o4[i] = make_float4(0, 0, 0, 0);
+                } else {
+                    for (int k = 0; k < ncoef_out; k++) out[k] = make_float3(0, 0, 0);
+                }
+            }
+        }
+
+        // ---------------- computeCov3D backward (L/cuda_rasterizer/backward.cu:280-343)
+        if (do_map && a.scales) {
+            const float3 sc = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+            const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2],
+                                         a.rotations[4 * idx + 3]);
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            M3 R;
+            quat_to_R(q, R);
+            const float3 s = make_float3(a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z);
+            const M3 Mm = mul(diag3(s.x, s.y, s.z), R);
+            M3 dSigma;
+            dSigma.m[0][0] = dcov[0]; dSigma.m[0][1] = 0.5f * dcov[1]; dSigma.m[0][2] = 0.5f * dcov[2];
+            dSigma.m[1][0] = 0.5f * dcov[1]; dSigma.m[1][1] = dcov[3]; dSigma.m[1][2] = 0.5f * dcov[4];
+            dSigma.m[2][0] = 0.5f * dcov[2]; dSigma.m[2][1] = 0.5f * dcov[4]; dSigma.m[2][2] = dcov[5];
+            M3 M2;
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++) M2.m[c][rr] = Mm.m[c][rr] * 2.0f;
+            const M3 dL_dM = mul(M2, dSigma);
+            const M3 Rt = transpose(R);
+            M3 dMt = transpose(dL_dM);
+            dscale.x = dot3(make_float3(Rt.m[0][0], Rt.m[0][1], Rt.m[0][2]), make_float3(dMt.m[0][0], dMt.m[0][1], dMt.m[0][2]));
+            dscale.y = dot3(make_float3(Rt.m[1][0], Rt.m[1][1], Rt.m[1][2]), make_float3(dMt.m[1][0], dMt.m[1][1], dMt.m[1][2]));
+            dscale.z = dot3(make_float3(Rt.m[2][0], Rt.m[2][1], Rt.m[2][2]), make_float3(dMt.m[2][0], dMt.m[2][1], dMt.m[2][2]));
+#pragma unroll
+            for (int k = 0; k < 3; k++) { dMt.m[0][k] *= s.x; dMt.m[1][k] *= s.y; dMt.m[2][k] *= s.z; }
+            drot.x = 2 * z * (dMt.m[0][1] - dMt.m[1][0]) + 2 * y * (dMt.m[2][0] - dMt.m[0][2]) + 2 * x * (dMt.m[1][2] - dMt.m[2][1]);
+            drot.y = 2 * y * (dMt.m[1][0] + dMt.m[0][1]) + 2 * z * (dMt.m[2][0] + dMt.m[0][2]) + 2 * r * (dMt.m[1][2] - dMt.m[2][1]) - 4 * x * (dMt.m[2][2] + dMt.m[1][1]);
+            drot.z = 2 * x * (dMt.m[1][0] + dMt.m[0][1]) + 2 * r * (dMt.m[2][0] - dMt.m[0][2]) + 2 * z * (dMt.m[1][2] + dMt.m[2][1]) - 4 * y * (dMt.m[2][2] + dMt.m[0][0]);
+            drot.w = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
+        }
+
+        a.dL_dmean3D[3 * (size_t)idx + 0] = dmean.x;
+        a.dL_dmean3D[3 * (size_t)idx + 1] = dmean.y;
+        a.dL_dmean3D[3 * (size_t)idx + 2] = dmean.z;
+#pragma unroll
+        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+        a.dL_dscale[3 * (size_t)idx + 0] = dscale.x;
+        a.dL_dscale[3 * (size_t)idx + 1] = dscale.y;
+        a.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
+        reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
+
+        // ---------------- pose gradient: sum over Gaussians of Jacobian x (sum over pixels)
+        // L/cuda_rasterizer/backward.cu:633-651 accumulates J_k(g) * {nx, ny, dL_ddepth} per pixel; J_k
+        // depends on the Gaussian only, so the pixel sums are taken first (acc[4], acc[5], acc[13]).
+        if (vis && !a.track_off) {
+            const float4 m_hom = xform4x4(m, a.proj);
+            const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+            const float A = acc[4], B = acc[5], Dd = acc[13];
+            const float mm[4] = {m.x, m.y, m.z, 1.0f};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                pose[3 * k + 0] = (m_w * a.perspec[0] * mm[k]) * A;
+                pose[3 * k + 1] = (m_w * a.perspec[5] * mm[k]) * B;
+                pose[3 * k + 2] = (m_hom.x * (-m_w * m_w) * mm[k]) * A + (m_hom.y * (-m_w * m_w) * mm[k]) * B + mm[k] * Dd;
+            }
+        }
+    }
+
+    if (!a.track_off) {
+        // block reduction of the 12 pose terms: wave64 butterfly, then the 4 waves through LDS
+        __shared__ float red[4][12];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            float v = pose[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0) red[wv][i] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 12)
+            a.pose_part[(size_t)blockIdx.x * 12 + threadIdx.x] =
+                ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    }
+}
+
+// Final pose reduction: fixed-order double sum of the per-block partials -> dL_dview[16].
+__global__ void __launch_bounds__(256) pose_reduce_kernel(const float* __restrict__ part, int nblocks, float* dL_dview,
+                                                          int track_off) {
+    __shared__ double sm[256];
+    const int s = threadIdx.x & 15, grp = threadIdx.x >> 4;  // 16 groups x 16 slots (12 used)
+    double v = 0.0;
+    if (!track_off && s < 12)
+        for (int b = grp; b < nblocks; b += 16) v += (double)part[(size_t)b * 12 + s];
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float out = 0.0f;
+        if (threadIdx.x < 12) {
+            double t = 0.0;
+            for (int g = 0; g < 16; g++) t += sm[g * 16 + threadIdx.x];
+            out = (float)t;
+        }
+        // slot order v0,v1,v2,v4,v5,v6,v8,v9,v10,v12,v13,v14 (L/cuda_rasterizer/backward.cu:723)
+        if (threadIdx.x < 12) dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
+        if (threadIdx.x < 4) dL_dview[threadIdx.x * 4 + 3] = 0.0f;
+    }
+}
+
+}  // namespace dgr
+
+namespace dgr {
+hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream) {
+    if (a.P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hipStream_t stream) {
+    const int blocks = (a.P + 255) / 256;
+    if (blocks > 0) {
+        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(256), 0, stream, a.pose_part, blocks, dL_dview, a.track_off);
+    return hipGetLastError();
+}
+hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means, view, present);
+    return hipGetLastError();
+}
+}  // namespace dgr

@@ -1,0 +1,337 @@
+// render_light.hip -- 16x16-tile alpha-blending kernels of the light variant for gfx950.
+//
+// Replaces renderCUDA forward (L/cuda_rasterizer/forward.cu:261-412) and renderCUDA backward
+// (L/cuda_rasterizer/backward.cu:419-699).
+//
+// Shape of the computation on CDNA4 (wave64, LDS 160 KB/CU, scalar unit per wave):
+//  * one 256-thread workgroup per tile, wave w owns the 8x8-pixel quadrant (w&1, w>>1);
+//  * the sorted tile list is staged 256 instances at a time into LDS as SoA (xy | scaled conic +
+//    opacity | rgb + depth | id), one 48-byte record gather per thread;
+//  * while staging, every thread bounds the region where its Gaussian can reach alpha >= 15/255
+//    (the ellipse q(d) <= 2 ln(255 o / 15), boxed with a safety margin) and tests it against the four
+//    quadrants; four wave ballots per staging wave publish 64-bit "may touch quadrant w" masks;
+//  * each wave then walks only the set bits of its masks with scalar bit scans (s_ff1 / s_flbit):
+//    the loop trip count and the LDS addresses are wave-uniform, the per-pixel work is pure VALU on
+//    LDS-broadcast operands.  A skipped (pixel, Gaussian) pair is one the per-pixel test
+//    `power > 0 || alpha < 15/255` would have rejected, so outputs are unchanged; `contributor`
+//    (hence n_contrib) is the position in the tile list, which skipping does not alter.
+//  * XCD-aware block->tile map: block b runs on XCD b%8, so each XCD is handed a contiguous band of
+//    tiles and neighbouring tiles share Gaussian records / accumulator rows in one L2.
+//
+// alpha is evaluated as o * exp2(p2) with the conic pre-scaled by log2(e) (one v_exp_f32, no range
+// reduction); forward and backward use the identical expression so they agree on every decision.
+#include "dgr_common.h"
+#include "kernels.h"
+
+namespace dgr {
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float ALPHA_MIN = 15.0f / 255.0f;  // forward.cu:365
+
+// bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of tiles
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+    const int xcd = b & 7, local = b >> 3;
+    const int q = n >> 3, r = n & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+struct Staged {
+    float2 xy[DGR_TILE_PIX];
+    float4 con[DGR_TILE_PIX];   // {a2, b2, c2, opacity}: p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e)*power
+    float4 rgbd[DGR_TILE_PIX];  // {r, g, b, depth}
+    uint32_t id[DGR_TILE_PIX];
+    unsigned long long mask[4][4];  // [staging wave = sub-batch of 64][consumer wave]
+};
+
+// Stage one instance and return the 4-bit "may touch quadrant" code.
+__device__ __forceinline__ unsigned stage_one(Staged& s, int slot, uint32_t gid, const float4* __restrict__ rec,
+                                              float tile_x0, float tile_y0, float3* raw_conic) {
+    const float4 q0 = rec[3 * (size_t)gid + 0];
+    const float4 q1 = rec[3 * (size_t)gid + 1];
+    const float4 q2 = rec[3 * (size_t)gid + 2];
+    s.xy[slot] = make_float2(q0.x, q0.y);
+    s.con[slot] = make_float4(-0.5f * LOG2E * q1.x, -LOG2E * q1.y, -0.5f * LOG2E * q1.z, q0.w);
+    s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
+    s.id[slot] = gid;
+    if (raw_conic) *raw_conic = make_float3(q1.x, q1.y, q1.z);
+    // alpha >= 15/255  <=>  a dx^2 + 2 b dx dy + c dy^2 <= tau = 2 ln(255 o / 15)
+    const float o = q0.w;
+    const float tau = 2.0f * __logf(o * (255.0f / 15.0f));
+    const float det = q1.x * q1.z - q1.y * q1.y;
+    float hx, hy;
+    if (!(tau > 0.0f)) {
+        return 0u;  // opacity below 15/255: can never contribute
+    } else if (det > 0.0f && q1.x > 0.0f && q1.z > 0.0f) {
+        const float k = tau / det;
+        hx = sqrtf(k * q1.z) * 1.001f + 0.05f;
+        hy = sqrtf(k * q1.x) * 1.001f + 0.05f;
+    } else {
+        return 0xFu;  // degenerate conic: do not cull
+    }
+    const float lx = q0.x - hx - tile_x0, rx = q0.x + hx - tile_x0;  // bbox relative to the tile origin
+    const float ly = q0.y - hy - tile_y0, ry = q0.y + hy - tile_y0;
+    const bool xl = (rx >= 0.0f) && (lx <= 7.0f), xr = (rx >= 8.0f) && (lx <= 15.0f);
+    const bool yt = (ry >= 0.0f) && (ly <= 7.0f), yb = (ry >= 8.0f) && (ly <= 15.0f);
+    return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+}
+
+__device__ __forceinline__ void publish_masks(Staged& s, unsigned code, int wave, int lane) {
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const unsigned long long m = __ballot((code >> w) & 1u);
+        if (lane == 0) s.mask[wave][w] = m;
+    }
+}
+
+__device__ __forceinline__ unsigned long long uniform_mask(const Staged& s, int sub, int wave) {
+    const unsigned long long m = s.mask[sub][wave];
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)m);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// ================================================================================ forward
+__global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArgs a) {
+    __shared__ Staged s;
+    const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
+    const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * DGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * DGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const size_t pix_id = (size_t)a.W * py + px;
+    const float pxf = (float)px, pyf = (float)py;
+    const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
+
+    const uint2 range = a.ranges[tile];
+    const int total = (int)(range.y - range.x);
+
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f, D_median = 0.f;
+    uint32_t last_contributor = 0;
+    bool done = !inside;
+    const float gt_px = inside ? a.gt_depth[pix_id] : 0.f;
+
+    for (int base = 0; base < total; base += DGR_TILE_PIX) {
+        // whole tile finished?  (L/cuda_rasterizer/forward.cu:329-332)
+        if (__syncthreads_and(done)) break;
+        const int cnt = min(DGR_TILE_PIX, total - base);
+        unsigned code = 0;
+        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0, nullptr);
+        publish_masks(s, code, wave, lane);
+        __syncthreads();
+
+        if (!__all(done)) {
+            for (int sub = 0; sub * 64 < cnt; sub++) {
+                unsigned long long m = uniform_mask(s, sub, wave);
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int j = sub * 64 + b;
+                    const float2 xy = s.xy[j];
+                    const float4 co = s.con[j];
+                    const float dx = xy.x - pxf, dy = xy.y - pyf;
+                    const float p2 = dx * (co.x * dx + co.y * dy) + co.z * dy * dy;
+                    const float alpha = fminf(0.99f, co.w * __builtin_amdgcn_exp2f(p2));
+                    if (!done && p2 <= 0.0f && alpha >= ALPHA_MIN) {
+                        const float test_T = T * (1.0f - alpha);
+                        if (test_T < 0.0001f) {
+                            done = true;  // this Gaussian is not blended (forward.cu:368-373)
+                        } else {
+                            const float4 cd = s.rgbd[j];
+                            const float w = alpha * T;
+                            C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
+                            weight += w;
+                            Dd += cd.w * w;
+                            if (T > 0.5f && test_T < 0.5f) {  // forward.cu:381-388
+                                D_median = cd.w;
+                                const uint32_t gid = s.id[j];
+                                const float e = cd.w - gt_px;
+                                atomicAdd(&a.gau_uncertainty[gid], e * e * w);
+                                atomicAdd(&a.gau_related_pixels[gid], 1);
+                            }
+                            T = test_T;
+                            last_contributor = (uint32_t)(base + j + 1);
+                        }
+                    }
+                }
+                if (__all(done)) break;
+            }
+        }
+    }
+
+    if (inside) {
+        const size_t N = (size_t)a.W * a.H;
+        a.n_contrib[pix_id] = last_contributor;
+        a.out_color[pix_id] = C0 + T * a.bg[0];
+        a.out_color[N + pix_id] = C1 + T * a.bg[1];
+        a.out_color[2 * N + pix_id] = C2 + T * a.bg[2];
+        a.out_alpha[pix_id] = weight;  // forward.cu:407
+        a.out_depth[pix_id] = Dd;
+        a.out_median[pix_id] = D_median;
+        a.out_depth_var[pix_id] = 0.0f;  // forward.cu:317,410
+    }
+}
+
+// ================================================================================ backward
+struct StagedBwd {
+    Staged f;
+    float4 raw[DGR_TILE_PIX];  // {conic a, b, c, unused}
+    int max_last;
+};
+
+__global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArgs a) {
+    __shared__ StagedBwd sb;
+    Staged& s = sb.f;
+    const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
+    const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int px = tx * DGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
+    const int py = ty * DGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
+    const bool inside = px < a.W && py < a.H;
+    const size_t pix_id = (size_t)a.W * py + px;
+    const size_t N = (size_t)a.W * a.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
+
+    const uint2 range = a.ranges[tile];
+    const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
+
+    if (tid == 0) sb.max_last = 0;
+    __syncthreads();
+    {
+        int v = last_contributor;  // wave max, then one LDS atomic per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+        if (lane == 0) atomicMax(&sb.max_last, v);
+    }
+    __syncthreads();
+    const int total = min((int)(range.y - range.x), sb.max_last);  // nothing past the last contributor matters
+    if (total <= 0) return;
+
+    const float T_final = inside ? (1.0f - a.alphas[pix_id]) : 0.f;
+    float T = T_final;
+    float dpix0 = 0.f, dpix1 = 0.f, dpix2 = 0.f, dpix_depth = 0.f, dpix_median = 0.f, dpix_var = 0.f, gt_px = 0.f;
+    if (inside) {
+        dpix0 = a.dL_dpix[pix_id];
+        dpix1 = a.dL_dpix[N + pix_id];
+        dpix2 = a.dL_dpix[2 * N + pix_id];
+        dpix_depth = a.dL_dpix_depth[pix_id];
+        dpix_median = a.dL_dpix_median[pix_id];
+        dpix_var = a.dL_dpix_var[pix_id];
+        gt_px = a.gt_depth[pix_id];
+    }
+    const float bg_dot_dpixel = a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_depth = 0.f, acc_var = 0.f;  // accum_rec*
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f, last_var = 0.f;
+    const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+    bool mid_once = true;
+    const bool do_map = !a.map_off, do_pose = !a.track_off;
+
+    // back-to-front: batches cover list positions [lo, hi) with hi walking down from `total`
+    for (int hi = total; hi > 0; hi -= DGR_TILE_PIX) {
+        const int lo = max(0, hi - DGR_TILE_PIX);
+        const int cnt = hi - lo;
+        __syncthreads();
+        unsigned code = 0;
+        if (tid < cnt) {
+            float3 raw;
+            code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, &raw);
+            sb.raw[tid] = make_float4(raw.x, raw.y, raw.z, 0.f);
+        }
+        publish_masks(s, code, wave, lane);
+        __syncthreads();
+
+        for (int sub = (cnt - 1) >> 6; sub >= 0; sub--) {
+            unsigned long long m = uniform_mask(s, sub, wave);
+            while (m) {
+                const int b = 63 - __builtin_clzll(m);
+                m &= ~(1ull << b);
+                const int j = sub * 64 + b;
+                const int pos = lo + j;  // 0-based position in the tile list
+                const float2 xy = s.xy[j];
+                const float4 co = s.con[j];
+                const float dx = xy.x - pxf, dy = xy.y - pyf;
+                const float p2 = dx * (co.x * dx + co.y * dy) + co.z * dy * dy;
+                const float G = __builtin_amdgcn_exp2f(p2);
+                const float alpha = fminf(0.99f, co.w * G);
+                if (pos < last_contributor && p2 <= 0.0f && alpha >= ALPHA_MIN) {
+                    const float4 cd = s.rgbd[j];
+                    const float4 rc = sb.raw[j];
+                    const uint32_t gid = s.id[j];
+                    float* row = a.acc + (size_t)gid * DGR_ACC_STRIDE;
+                    const float one_m_alpha = 1.f - alpha;
+                    const float inv = __builtin_amdgcn_rcpf(one_m_alpha);
+                    T = T * inv;
+                    const float w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
+                    const float dL_ddepth = w * dpix_depth;
+                    // colour / depth / variance recurrences (backward.cu:580-608)
+                    const float om = 1.f - last_alpha;
+                    acc0 = last_alpha * lc0 + om * acc0; lc0 = cd.x;
+                    acc1 = last_alpha * lc1 + om * acc1; lc1 = cd.y;
+                    acc2 = last_alpha * lc2 + om * acc2; lc2 = cd.z;
+                    float dL_dalpha = (cd.x - acc0) * dpix0 + (cd.y - acc1) * dpix1 + (cd.z - acc2) * dpix2;
+                    const float c_d = cd.w;
+                    const float e = c_d - gt_px;
+                    const float c_var = e * e;
+                    acc_depth = last_alpha * last_depth + om * acc_depth; last_depth = c_d;
+                    acc_var = last_alpha * last_var + om * acc_var; last_var = c_var;
+                    dL_dalpha += (c_d - acc_depth) * dpix_depth;
+                    dL_dalpha += (c_var - acc_var) * dpix_var;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
+
+                    const float dL_dG = co.w * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * rc.x - gdy * rc.y;
+                    const float dG_ddely = -gdy * rc.z - gdx * rc.y;
+                    const float gmx = dL_dG * dG_ddelx * ddelx_dx;  // == dL_dndcs_x of backward.cu:635
+                    const float gmy = dL_dG * dG_ddely * ddely_dy;
+                    if (do_map) {
+                        atomicAdd(row + 0, w * dpix0);
+                        atomicAdd(row + 1, w * dpix1);
+                        atomicAdd(row + 2, w * dpix2);
+                        atomicAdd(row + 3, dL_ddepth + dpix_var * w * 2.f * e);
+                        if (T > 0.5f && mid_once) {  // backward.cu:654-664
+                            const float* mg = a.means3D + 3 * (size_t)gid;
+                            const float* v = a.view;
+                            const float mul3 = v[2] * mg[0] + v[6] * mg[1] + v[10] * mg[2] + v[14];
+                            atomicAdd(row + 10, (v[2] - v[3] * mul3) * dpix_median);
+                            atomicAdd(row + 11, (v[6] - v[7] * mul3) * dpix_median);
+                            atomicAdd(row + 12, (v[10] - v[11] * mul3) * dpix_median);
+                            mid_once = false;
+                        }
+                        atomicAdd(row + 6, -0.5f * gdx * dx * dL_dG);
+                        atomicAdd(row + 7, -0.5f * gdx * dy * dL_dG);
+                        atomicAdd(row + 8, -0.5f * gdy * dy * dL_dG);
+                        atomicAdd(row + 9, G * dL_dalpha);
+                    }
+                    if (do_map || do_pose) {
+                        atomicAdd(row + 4, gmx);
+                        atomicAdd(row + 5, gmy);
+                    }
+                    if (do_pose) atomicAdd(row + 13, dL_ddepth);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream) {
+    const int tiles = a.grid_x * a.grid_y;
+    if (tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(render_fwd_light_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stream) {
+    const int tiles = a.grid_x * a.grid_y;
+    if (tiles <= 0 || (a.track_off && a.map_off)) return hipSuccess;
+    hipLaunchKernelGGL(render_bwd_light_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace dgr

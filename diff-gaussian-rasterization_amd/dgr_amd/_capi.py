@@ -1,0 +1,84 @@
+"""ctypes binding of lib/libdgr_hip.so (C ABI declared in include/dgr_hip.h).
+
+torch is used for device memory and the current HIP stream only; every compute call goes through
+the C ABI.  `import torch` must precede loading the library so that it binds to the HIP runtime
+torch already mapped (same SONAME, libamdhip64.so.7).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported before the HIP library is mapped)
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libdgr_hip.so")
+
+DGR_OK = 0
+DGR_ERR_BAD_ARGUMENT = -1
+DGR_ERR_PREFILTERED = -2
+DGR_ERR_BINNING_OVERFLOW = -3
+DGR_ERR_HIP = -4
+DGR_ERR_ALLOC = -5
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+# argument lists follow include/dgr_hip.h one to one
+_SIGS = {
+    "dgr_last_error": (C.c_char_p, []),
+    "dgr_version": (C.c_char_p, []),
+    "dgr_geometry_bytes": (_sz, [_i]),
+    "dgr_image_bytes": (_sz, [_i, _i]),
+    "dgr_binning_bytes": (_sz, [_i, _i, _i]),
+    "dgr_light_backward_scratch_bytes": (_sz, [_i, _i, _i]),
+    "dgr_mark_visible": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "dgr_light_forward": (_i, [_vp, ALLOC_FN, ALLOC_FN, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i,
+                               _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
+    "dgr_light_forward_presized": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i,
+                                        _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dgr_light_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp,
+                                _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+                                _vp, _i, _i, _vp, _sz]),
+    "dgr_state_export": (C.c_long, [_vp, C.c_char_p, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """Maps the HIP library; raises (never falls back) when it is missing or incomplete."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C {_PKG}` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the rasterizer.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().dgr_last_error().decode()
+
+
+def ptr(t):
+    """Device pointer of a tensor; NULL for None / empty tensors (the reference's nullptr convention)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def stream_handle():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,395 @@
+"""Host-side mirror of diff-gaussian-rasterization-light/diff_gaussian_rasterization/__init__.py.
+
+Same names, argument order, return arity and error behaviour as the reference module
+(`GaussianRasterizationSettings`, `GaussianRasterizer`, `rasterize_gaussians`, `_RasterizeGaussians`),
+with `_C.*` replaced by calls into the gfx950 C ABI (include/dgr_hip.h).  Differences, all invisible
+to a caller of the autograd surface:
+  * the per-pixel [H*W,4,4] pose-gradient buffer and its torch.sum (reference __init__.py:160-161)
+    do not exist; the C ABI returns the reduced [4,4];
+  * forward runs without a mid-pipeline host sync when a binning capacity is known from an earlier
+    call of the same shape (one status read at the end instead); DGR_FORWARD_MODE=callback selects the
+    strict mirror with allocation callbacks and the reference's blocking read;
+  * the debug path's NameError (`deoth_var`, reference __init__.py:93) is not reproduced.
+"""
+import ctypes as C
+import os
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _capi
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+def _f32c(t, dev):
+    """contiguous fp32 tensor on `dev` (L/rasterize_points.cu:101-125 calls .contiguous() on every input)."""
+    if t.device != dev:
+        t = t.to(dev)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# binning capacity learned per (device, P, H, W): last num_rendered of that shape
+_capacity_cache = {}
+
+
+def _check(rc):
+    if rc >= 0:
+        return rc
+    msg = _capi.last_error()
+    if rc == _capi.DGR_ERR_PREFILTERED:
+        raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    if rc == _capi.DGR_ERR_BAD_ARGUMENT:
+        raise RuntimeError(f"dgr_hip: bad argument: {msg}")
+    raise RuntimeError(f"dgr_hip: error {rc}: {msg}")
+
+
+class _C:
+    """Functions with the signatures of the reference's pybind11 module `_C` (L/ext.cpp:15-19)."""
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                            cov3D_precomp, viewmatrix, gt_depth, projmatrix, tan_fovx, tan_fovy,
+                            image_height, image_width, sh, degree, campos, prefiltered, debug):
+        # L/rasterize_points.cu:35-129
+        if means3D.ndimension() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        lib = _capi.load()
+        dev = means3D.device
+        if dev.type != "cuda":
+            raise RuntimeError("dgr_hip runs on the GPU only (no CPU path exists, as in the reference)")
+        P, H, W = means3D.size(0), int(image_height), int(image_width)
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        means3D = _f32c(means3D, dev)
+        background, colors, opacity = _f32c(background, dev), _f32c(colors, dev), _f32c(opacity, dev)
+        scales, rotations, cov3D_precomp = _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3D_precomp, dev)
+        viewmatrix, projmatrix, campos = _f32c(viewmatrix, dev), _f32c(projmatrix, dev), _f32c(campos, dev)
+        gt_depth, sh = _f32c(gt_depth, dev), _f32c(sh, dev)
+        M = sh.size(1) if sh.numel() != 0 else 0
+
+        out_color = torch.empty((3, H, W), **f32)
+        out_depth = torch.empty((1, H, W), **f32)
+        out_median = torch.empty((1, H, W), **f32)
+        out_var = torch.empty((1, H, W), **f32)
+        out_alpha = torch.empty((1, H, W), **f32)
+        radii = torch.zeros((P,), **i32)
+        gau_unc = torch.zeros((P, 1), **f32)
+        gau_px = torch.zeros((P, 1), **i32)
+        u8 = dict(dtype=torch.uint8, device=dev)
+        st = _capi.stream_handle()
+        p = _capi.ptr
+
+        common = (P, int(degree), M, p(background), W, H, p(means3D), p(sh), p(colors), p(opacity), p(scales),
+                  float(scale_modifier), p(rotations), p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos),
+                  float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), p(out_color), p(out_depth),
+                  p(out_median), p(out_alpha), p(gt_depth), p(out_var), p(gau_unc), p(gau_px), p(radii))
+
+        if os.environ.get("DGR_FORWARD_MODE", "presized") == "callback" or P == 0:
+            bufs = {k: torch.empty((0,), **u8) for k in ("geom", "binning", "img")}
+
+            def mk(name):
+                def cb(nbytes, _user):
+                    bufs[name] = torch.empty((max(int(nbytes), 1),), **u8)
+                    return bufs[name].data_ptr()
+                return _capi.ALLOC_FN(cb)
+            cbs = [mk("geom"), mk("binning"), mk("img")]
+            rendered = _check(lib.dgr_light_forward(st, cbs[0], cbs[1], cbs[2], None, *common, int(bool(debug))))
+            geomBuffer, binningBuffer, imgBuffer = bufs["geom"], bufs["binning"], bufs["img"]
+        else:
+            geomBuffer = torch.empty((lib.dgr_geometry_bytes(P),), **u8)
+            imgBuffer = torch.empty((lib.dgr_image_bytes(W, H),), **u8)
+            status = torch.empty((4,), **i32)
+            key = (dev.index, P, H, W)
+            cap = _capacity_cache.get(key, 0)
+            cap = int(cap * 1.25) + 4096 if cap else 4 * P + 4096
+            while True:
+                binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)
+                _check(lib.dgr_light_forward_presized(st, p(geomBuffer), p(binningBuffer), cap, p(imgBuffer),
+                                                      p(status), *common))
+                s = status.tolist()  # the one host read of this forward (also what returns num_rendered)
+                if s[2]:
+                    raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+                rendered = s[0]
+                _capacity_cache[key] = rendered
+                if not s[1]:
+                    break
+                cap = int(rendered * 1.1) + 4096  # overflow: every tile list was left empty; run again
+            if debug:
+                torch.cuda.synchronize(dev)
+        return (rendered, out_color, out_depth, out_median, out_var, out_alpha, radii, geomBuffer, binningBuffer,
+                imgBuffer, gau_unc, gau_px)
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                     cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                     dL_dout_depth, dL_dout_median_depth, dL_dout_depth_var, gt_depth, sh, degree,
+                                     campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug,
+                                     perspec_matrix, track_off, map_off):
+        # L/rasterize_points.cu:131-236
+        lib = _capi.load()
+        dev = means3D.device
+        P = means3D.size(0)
+        H, W = dL_dout_color.size(1), dL_dout_color.size(2)
+        f32 = dict(dtype=torch.float32, device=dev)
+        means3D = _f32c(means3D, dev)
+        background, colors = _f32c(background, dev), _f32c(colors, dev)
+        scales, rotations, cov3D_precomp = _f32c(scales, dev), _f32c(rotations, dev), _f32c(cov3D_precomp, dev)
+        viewmatrix, projmatrix, campos = _f32c(viewmatrix, dev), _f32c(projmatrix, dev), _f32c(campos, dev)
+        gt_depth, sh, alphas = _f32c(gt_depth, dev), _f32c(sh, dev), _f32c(alphas, dev)
+        perspec_matrix = _f32c(perspec_matrix, dev)
+        gC, gD = _f32c(dL_dout_color, dev), _f32c(dL_dout_depth, dev)
+        gM, gV = _f32c(dL_dout_median_depth, dev), _f32c(dL_dout_depth_var, dev)
+        M = sh.size(1) if sh.numel() != 0 else 0
+        # every row is written by the kernels (zeros for invisible Gaussians): no zero-fill pass
+        mk = torch.empty if P else torch.zeros
+        dL_dmeans3D, dL_dmeans2D = mk((P, 3), **f32), mk((P, 3), **f32)
+        dL_dcolors, dL_dopacity = mk((P, 3), **f32), mk((P, 1), **f32)
+        dL_dcov3D, dL_dsh = mk((P, 6), **f32), mk((P, M, 3), **f32)
+        dL_dscales, dL_drotations = mk((P, 3), **f32), mk((P, 4), **f32)
+        dL_dview = torch.empty((4, 4), **f32)
+        scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes(P, W, H), 1),), dtype=torch.uint8, device=dev)
+        p = _capi.ptr
+        _check(lib.dgr_light_backward(
+            _capi.stream_handle(), P, int(degree), M, int(R), p(background), W, H, p(means3D), p(sh), p(colors),
+            p(alphas), p(scales), float(scale_modifier), p(rotations), p(cov3D_precomp), p(viewmatrix),
+            p(projmatrix), p(campos), float(tan_fovx), float(tan_fovy), p(radii), p(geomBuffer), p(binningBuffer),
+            p(imageBuffer), p(gC), p(gD), p(gM), p(gV), p(dL_dmeans2D), None, p(dL_dopacity), p(dL_dcolors), None,
+            p(dL_dmeans3D), p(dL_dcov3D), p(dL_dsh), p(dL_dscales), p(dL_drotations), int(bool(debug)), None,
+            p(perspec_matrix), p(dL_dview), None, p(gt_depth), int(bool(track_off)), int(bool(map_off)),
+            p(scratch), scratch.numel()))
+        return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
+                dL_dview)
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        # L/rasterize_points.cu:238-256
+        lib = _capi.load()
+        dev = means3D.device
+        P = means3D.size(0)
+        present = torch.zeros((P,), dtype=torch.bool, device=dev)
+        if P != 0:
+            means3D, viewmatrix, projmatrix = _f32c(means3D, dev), _f32c(viewmatrix, dev), _f32c(projmatrix, dev)
+            _check(lib.dgr_mark_visible(_capi.stream_handle(), P, _capi.ptr(means3D), _capi.ptr(viewmatrix),
+                                        _capi.ptr(projmatrix), present.data_ptr()))
+        return present
+
+
+def rasterize_gaussians(
+    means3D,
+    means2D,
+    sh,
+    colors_precomp,
+    opacities,
+    scales,
+    rotations,
+    cov3Ds_precomp,
+    viewmatrix,
+    gt_depth,
+    raster_settings,
+):
+    return _RasterizeGaussians.apply(
+        means3D,
+        means2D,
+        sh,
+        colors_precomp,
+        opacities,
+        scales,
+        rotations,
+        cov3Ds_precomp,
+        viewmatrix,
+        gt_depth,
+        raster_settings,
+    )
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                viewmatrix, gt_depth, raster_settings):
+        # argument packing of L/diff_gaussian_rasterization/__init__.py:66-87
+        args = (
+            raster_settings.bg,
+            means3D,
+            colors_precomp,
+            opacities,
+            scales,
+            rotations,
+            raster_settings.scale_modifier,
+            cov3Ds_precomp,
+            viewmatrix,
+            gt_depth,
+            raster_settings.projmatrix,
+            raster_settings.tanfovx,
+            raster_settings.tanfovy,
+            raster_settings.image_height,
+            raster_settings.image_width,
+            sh,
+            raster_settings.sh_degree,
+            raster_settings.campos,
+            raster_settings.prefiltered,
+            raster_settings.debug,
+        )
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                out = _C.rasterize_gaussians(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            out = _C.rasterize_gaussians(*args)
+        (num_rendered, color, depth, depth_median, depth_var, opacity_map, radii, geomBuffer, binningBuffer,
+         imgBuffer, gau_uncertainty, gau_related_pixels) = out
+
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, viewmatrix, radii, sh,
+                              geomBuffer, binningBuffer, imgBuffer, opacity_map, gt_depth)
+        return color, radii, depth, depth_median, depth_var, opacity_map, gau_uncertainty, gau_related_pixels
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_depth_median, grad_depth_var, grad_alpha,
+                 grad_gau_uncertainty, grad_gau_realted_pixels):
+        num_rendered = ctx.num_rendered
+        raster_settings = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, viewmatrix, radii, sh, geomBuffer,
+         binningBuffer, imgBuffer, opacity_map, gt_depth) = ctx.saved_tensors
+
+        # argument packing of L/diff_gaussian_rasterization/__init__.py:116-146
+        args = (raster_settings.bg,
+                means3D,
+                radii,
+                colors_precomp,
+                scales,
+                rotations,
+                raster_settings.scale_modifier,
+                cov3Ds_precomp,
+                viewmatrix,
+                raster_settings.projmatrix,
+                raster_settings.tanfovx,
+                raster_settings.tanfovy,
+                grad_color,
+                grad_depth,
+                grad_depth_median,
+                grad_depth_var,
+                gt_depth,
+                sh,
+                raster_settings.sh_degree,
+                raster_settings.campos,
+                geomBuffer,
+                num_rendered,
+                binningBuffer,
+                imgBuffer,
+                opacity_map,
+                raster_settings.debug,
+                raster_settings.perspec_matrix,
+                raster_settings.track_off,
+                raster_settings.map_off)
+
+        if raster_settings.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                out = _C.rasterize_gaussians_backward(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            out = _C.rasterize_gaussians_backward(*args)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_viewmatrix) = out
+        # reference: torch.sum(grad_viewmatrix, dim=0) over a [H*W,4,4] buffer (__init__.py:160-161);
+        # here grad_viewmatrix already is the reduced [4,4].
+
+        grads = (
+            grad_means3D,
+            grad_means2D,
+            grad_sh,
+            grad_colors_precomp,
+            grad_opacities,
+            grad_scales,
+            grad_rotations,
+            grad_cov3Ds_precomp,
+            grad_viewmatrix,
+            None,
+            None,
+        )
+        return grads
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    perspec_matrix: torch.Tensor
+    track_off: bool
+    map_off: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        # Mark visible points (based on frustum culling for camera) with a boolean
+        with torch.no_grad():
+            raster_settings = self.raster_settings
+            visible = _C.mark_visible(
+                positions,
+                raster_settings.viewmatrix,
+                raster_settings.projmatrix)
+        return visible
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, viewmatrix=None, gt_depth=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        if shs is None:
+            shs = torch.Tensor([])
+        if colors_precomp is None:
+            colors_precomp = torch.Tensor([])
+        if scales is None:
+            scales = torch.Tensor([])
+        if rotations is None:
+            rotations = torch.Tensor([])
+        if cov3D_precomp is None:
+            cov3D_precomp = torch.Tensor([])
+
+        return rasterize_gaussians(
+            means3D,
+            means2D,
+            shs,
+            colors_precomp,
+            opacities,
+            scales,
+            rotations,
+            cov3D_precomp,
+            viewmatrix,
+            gt_depth,
+            raster_settings,
+        )

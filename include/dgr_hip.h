@@ -1,0 +1,122 @@
+/* dgr_hip.h -- C ABI of the MI355X (gfx950) differentiable Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the reference's hot path.  Each entry point replaces one
+ * member of `CudaRasterizer::Rasterizer` (the raw-pointer layer the reference's torch binding
+ * calls) and keeps its argument order and meaning; what changes is stated per function.
+ * Reference paths: L = diff-gaussian-rasterization-light, F = diff-gaussian-rasterization-full.
+ *
+ * Conventions
+ *  - every `float*` / `int*` / `char*` argument is a DEVICE pointer unless marked "host";
+ *    optional inputs are NULL exactly where the reference passes nullptr (empty tensors);
+ *  - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream the reference uses);
+ *  - 4x4 matrices are 16 floats read column-major: x' = m[0]x + m[4]y + m[8]z + m[12]
+ *    (cuda_rasterizer/auxiliary.h:58-77);
+ *  - the three state buffers (geometry / binning / image) are opaque to the caller, as in the
+ *    reference (L/cuda_rasterizer/rasterizer_impl.h:29-64); their layout here is different and
+ *    documented in DESIGN.md;
+ *  - return value: >= 0 success (forward: num_rendered), < 0 one of DGR_ERR_*.
+ */
+#ifndef DGR_HIP_H
+#define DGR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGR_OK 0
+#define DGR_ERR_BAD_ARGUMENT (-1)       /* e.g. non-RGB without precomputed colours (L/cr/rasterizer_impl.cu:248-251) */
+#define DGR_ERR_PREFILTERED (-2)        /* a point was culled although `prefiltered` is set (cr/auxiliary.h:154-161: __trap there) */
+#define DGR_ERR_BINNING_OVERFLOW (-3)   /* presized binning buffer too small; *num_rendered holds the required count */
+#define DGR_ERR_HIP (-4)                /* a HIP runtime call failed; see dgr_last_error() */
+#define DGR_ERR_ALLOC (-5)              /* an allocation callback returned NULL */
+
+/* Replaces std::function<char*(size_t)> (L/cr/rasterizer.h:41-43, L/rasterize_points.cu:27-33):
+ * called with the number of bytes needed, returns a device pointer (>= 256-byte aligned). */
+typedef char* (*dgr_alloc_fn)(size_t bytes, void* user);
+
+/* Human-readable text of the last DGR_ERR_HIP on this thread (host string, never NULL). */
+const char* dgr_last_error(void);
+
+/* Version / target string of the built library, e.g. "dgr_hip 0.1 gfx950". */
+const char* dgr_version(void);
+
+/* ---- state buffer sizes (the reference's `required<T>(n)`, L/cr/rasterizer_impl.h:66-72) ---- */
+size_t dgr_geometry_bytes(int P);
+size_t dgr_image_bytes(int width, int height);
+size_t dgr_binning_bytes(int num_rendered_capacity, int width, int height);
+/* scratch the backward needs (per-Gaussian accumulator rows + reduction partials) */
+size_t dgr_light_backward_scratch_bytes(int P, int width, int height);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (L/cr/rasterizer.h:33-38,
+ * L/cr/rasterizer_impl.cu:54-66,141-153).  present[i] = (view * p_i).z > 0.2.  `present` is P bytes (bool). */
+int dgr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present);
+
+/* Replaces CudaRasterizer::Rasterizer::forward of the light variant (L/cr/rasterizer.h:40-70,
+ * L/cr/rasterizer_impl.cu:197-350).  Same arguments in the same order, with `stream` prepended and
+ * the three std::function allocators replaced by C callbacks sharing one `alloc_user`.
+ * Like the reference it blocks the host once (to size the binning buffer) and returns num_rendered.
+ * Outputs need NOT be zero-initialised (the reference's binding zero-fills them first,
+ * L/rasterize_points.cu:69-76; here every element is written).  `out_depth_var` is written as 0
+ * (L/cr/forward.cu:317,410).  `radii` may be NULL (L/cr/rasterizer_impl.cu:235-238). */
+int dgr_light_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn binningBuffer, dgr_alloc_fn imageBuffer,
+                      void* alloc_user, int P, int D, int M, const float* background, int width, int height,
+                      const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                      float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_median_depth,
+                      float* out_alpha, const float* gt_depth, float* out_depth_var, float* gau_uncertainty,
+                      int* gau_related_pixels, int* radii, int debug);
+
+/* Same computation with caller-provided state buffers and NO host synchronisation (hipGraph-capturable):
+ * `binning_buffer` holds at most `binning_capacity` instances.  `status` is a device int[4] written by the
+ * kernels: {num_rendered, overflow flag, prefiltered-violation flag, reserved}.  When the capacity is too
+ * small the blend kernels see empty tile lists and the caller must re-run with a larger buffer. */
+int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binning_buffer, int binning_capacity,
+                               char* image_buffer, int* status, int P, int D, int M, const float* background,
+                               int width, int height, const float* means3D, const float* shs,
+                               const float* colors_precomp, const float* opacities, const float* scales,
+                               float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                               const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                               float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth,
+                               float* out_median_depth, float* out_alpha, const float* gt_depth,
+                               float* out_depth_var, float* gau_uncertainty, int* gau_related_pixels, int* radii);
+
+/* Replaces CudaRasterizer::Rasterizer::backward of the light variant (L/cr/rasterizer.h:72-104,
+ * L/cr/rasterizer_impl.cu:354-495).  Same arguments in the same order with `stream` prepended and a
+ * scratch buffer appended.  Differences, all on buffers the reference's Python never sees:
+ *  - `dL_dview` receives the 16 reduced entries (entries 3,7,11,15 = 0), i.e. what
+ *    L/diff_gaussian_rasterization/__init__.py:160-161 obtains by summing the reference's [H*W,4,4] buffer;
+ *  - `dgndcs_dviewmatrix` / `dg_camd_dviewmatrix` (per-Gaussian pose Jacobians, L/cr/backward.cu:701-751)
+ *    are not materialised and may be NULL;
+ *  - `dL_dconic` ([P,2,2]) and `dL_ddepth` ([P,1]) may be NULL; when given they receive the same sums
+ *    the reference accumulates there;
+ *  - gradient outputs need not be zero-initialised: rows of invisible Gaussians are written as 0.
+ * `R` is the value forward returned; `radii` may be NULL (internal copy is used). */
+int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
+                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                       float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                       const float* dL_dpix, const float* dL_dpix_depth, const float* dL_dpix_median_depth,
+                       const float* dL_dpix_depth_var, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity,
+                       float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                       float* dL_dscale, float* dL_drot, int debug, float* dgndcs_dviewmatrix,
+                       const float* perspec_matrix, float* dL_dview, float* dg_camd_dviewmatrix,
+                       const float* gt_depth, int track_off, int map_off, char* scratch, size_t scratch_bytes);
+
+/* ---- stage-wise access for tests and profiling (views into the opaque state buffers) ---- */
+/* Copies one named array of a state buffer to `dst` (device or host pointer).  Names: "depths", "radii",
+ * "means2D", "cov3D", "conic_opacity", "rgb", "clamped", "tiles_touched" (geometry); "point_list", "keys" (binning);
+ * "ranges", "n_contrib" (image).  Layout conversion to the reference's element types is done on the fly.
+ * Returns the element count, or < 0. */
+long dgr_state_export(void* stream, const char* name, int P, int width, int height, int num_rendered,
+                      const char* geom_buffer, const char* binning_buffer, const char* image_buffer, void* dst_device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGR_HIP_H */

@@ -10,35 +10,41 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
-# DGR_ORACLE_CMATH=1 selects the build whose exp/sqrt/ceil bind to the C double functions
-# (reproduces SURVEY.md Appendix C digit for digit); default is the float-overload build.
-_SO = "libdgr_oracle_cmath.so" if os.environ.get("DGR_ORACLE_CMATH") == "1" else "libdgr_oracle.so"
+_LIBS = {}
+# Two builds of the same source (see Makefile):
+#   float math (default)  exp/sqrt/ceil bind to the float overloads, as under nvcc -- the checker;
+#   C math                they bind to the C double functions, as in the survey's CPU run of the
+#                         reference -- reproduces SURVEY.md Appendix C digit for digit.
+# use_cmath(True) / DGR_ORACLE_CMATH=1 selects the second one for subsequently created states.
+_CMATH = os.environ.get("DGR_ORACLE_CMATH") == "1"
 
-_f32p = C.POINTER(C.c_float)
-_i32p = C.POINTER(C.c_int32)
+
+def use_cmath(flag):
+    global _CMATH
+    _CMATH = bool(flag)
 
 
 def build(force=False):
-    so = os.path.join(_HERE, _SO)
     src = os.path.join(_HERE, "dgr_oracle.cpp")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    sos = [os.path.join(_HERE, n) for n in ("libdgr_oracle.so", "libdgr_oracle_cmath.so")]
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src) for so in sos):
         subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "all"])
-    return so
+    return sos
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        _LIB = C.CDLL(build())
-        _LIB.dgro_state_new.restype = C.c_void_p
-        _LIB.dgro_state_free.argtypes = [C.c_void_p]
-        _LIB.dgro_state_get.restype = C.c_long
-        _LIB.dgro_state_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
-        _LIB.dgro_state_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
-        _LIB.dgro_state_set_dims.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
-        _LIB.dgro_state_num_rendered.argtypes = [C.c_void_p]
-    return _LIB
+def lib(cmath=None):
+    cmath = _CMATH if cmath is None else bool(cmath)
+    if cmath not in _LIBS:
+        l = C.CDLL(build()[1 if cmath else 0])
+        l.dgro_state_new.restype = C.c_void_p
+        l.dgro_state_free.argtypes = [C.c_void_p]
+        l.dgro_state_get.restype = C.c_long
+        l.dgro_state_get.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        l.dgro_state_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
+        l.dgro_state_set_dims.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        l.dgro_state_num_rendered.argtypes = [C.c_void_p]
+        _LIBS[cmath] = l
+    return _LIBS[cmath]
 
 
 def _p(a):
@@ -66,9 +72,10 @@ _DTYPES = {
 class OracleState:
     """Owns the Geometry/Binning/Image state of one forward call (opaque byte buffers in the reference)."""
 
-    def __init__(self):
+    def __init__(self, W=0, H=0):
         self._l = lib()
         self._h = C.c_void_p(self._l.dgro_state_new())
+        self._W, self._H = W, H
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -93,6 +100,7 @@ class OracleState:
             raise KeyError(name)
 
     def set_dims(self, P, W, H):
+        self._W, self._H = W, H
         self._l.dgro_state_set_dims(self._h, P, W, H)
 
     @property
@@ -122,14 +130,15 @@ def preprocess(st, W, H, means3D, shs, colors_precomp, opacities, scales, scale_
     (P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
      campos) = _common(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
                        projmatrix, campos)
-    return lib().dgro_preprocess(st._h, P, sh_degree, M, W, H, _p(means3D), _p(shs), _p(colors_precomp),
+    st._W, st._H = W, H
+    return st._l.dgro_preprocess(st._h, P, sh_degree, M, W, H, _p(means3D), _p(shs), _p(colors_precomp),
                                  _p(opacities), _p(scales), C.c_float(scale_modifier), _p(rotations),
                                  _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos), C.c_float(tanfovx),
                                  C.c_float(tanfovy), int(prefiltered))
 
 
 def binning(st):
-    return lib().dgro_binning(st._h)
+    return st._l.dgro_binning(st._h)
 
 
 def light_render_forward(st, bg, colors_precomp, gt_depth):
@@ -139,7 +148,7 @@ def light_render_forward(st, bg, colors_precomp, gt_depth):
                depth_median=np.zeros((1, H, W), np.float32), depth_var=np.zeros((1, H, W), np.float32),
                opacity_map=np.zeros((1, H, W), np.float32), gau_uncertainty=np.zeros((P, 1), np.float32),
                gau_related_pixels=np.zeros((P, 1), np.int32))
-    lib().dgro_light_render_forward(st._h, _p(bg), _p(colors_precomp), _p(gt_depth), _p(out["color"]), _p(out["depth"]),
+    st._l.dgro_light_render_forward(st._h, _p(bg), _p(colors_precomp), _p(gt_depth), _p(out["color"]), _p(out["depth"]),
                                     _p(out["depth_median"]), _p(out["opacity_map"]), _p(out["depth_var"]),
                                     _p(out["gau_uncertainty"]), _p(out["gau_related_pixels"]))
     return out
@@ -147,7 +156,7 @@ def light_render_forward(st, bg, colors_precomp, gt_depth):
 
 def _dims(st):
     ptr, elem = C.c_void_p(), C.c_int()
-    P = lib().dgro_state_get(st._h, b"radii", C.byref(ptr), C.byref(elem))
+    P = st._l.dgro_state_get(st._h, b"radii", C.byref(ptr), C.byref(elem))
     return st._W, st._H, P
 
 
@@ -159,15 +168,14 @@ def light_forward(bg, means3D, colors_precomp, opacities, scales, rotations, sca
      campos) = _common(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
                        projmatrix, campos)
     bg, gt_depth = _f(bg), _f(gt_depth)
-    st = OracleState()
-    st._W, st._H = W, H
+    st = OracleState(W, H)
     out = dict(color=np.zeros((3, H, W), np.float32), depth=np.zeros((1, H, W), np.float32),
                depth_median=np.zeros((1, H, W), np.float32), depth_var=np.zeros((1, H, W), np.float32),
                opacity_map=np.zeros((1, H, W), np.float32), radii=np.zeros(P, np.int32),
                gau_uncertainty=np.zeros((P, 1), np.float32), gau_related_pixels=np.zeros((P, 1), np.int32))
     R = 0
     if P:
-        R = lib().dgro_light_forward(
+        R = st._l.dgro_light_forward(
             st._h, P, sh_degree, M, _p(bg), W, H, _p(means3D), _p(shs), _p(colors_precomp), _p(opacities),
             _p(scales), C.c_float(scale_modifier), _p(rotations), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix),
             _p(campos), C.c_float(tanfovx), C.c_float(tanfovy), int(prefiltered), _p(out["color"]), _p(out["depth"]),
@@ -196,7 +204,7 @@ def light_backward(st, bg, means3D, colors_precomp, scales, rotations, scale_mod
              dL_dview=np.zeros((4, 4), np.float32))
     pix = np.zeros((H * W, 4, 4), np.float32) if per_pixel_pose else None
     if P:
-        lib().dgro_light_backward(
+        st._l.dgro_light_backward(
             st._h, P, sh_degree, M, _p(_f(bg)), _p(means3D), _p(shs), _p(colors_precomp), _p(_f(alphas)), _p(scales),
             C.c_float(scale_modifier), _p(rotations), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos),
             C.c_float(tanfovx), C.c_float(tanfovy), _p(_f(dL_dcolor)), _p(_f(dL_ddepth)), _p(_f(dL_dmedian)),

@@ -1,0 +1,92 @@
+"""Parity of the gfx950 light path against the CPU oracle, through the C ABI.
+
+Bars (north_star): bit-exact for the integer path (radii, tile counts, keys, point_list, ranges) and for
+every per-Gaussian float the integer path is derived from; 1e-5 abs (relative to max(1,|ref|)) for image
+outputs with a bounded threshold-flip outlier fraction; gradients to the tolerances of tests/util.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_grad_close, assert_image_close, make_scene
+import hip_helpers as hh
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # P, W, H, deg, seed
+    (2000, 64, 48, 0, 1),
+    (2000, 70, 45, 3, 2),      # ragged: neither dimension a multiple of 16
+    (10000, 256, 256, 0, 0),   # BASELINE config 1
+    (10000, 256, 256, 3, 0),
+    (100000, 640, 480, 3, 0),  # BASELINE config 2 shape (light variant)
+]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_preprocess_and_binning_bit_exact(oracle, case):
+    P, W, H, deg, seed = case
+    s = make_scene(P, W, H, seed)
+    _, d = hh.hip_forward(s, deg)
+    st, ref = hh.oracle_forward(oracle, s, deg)
+    assert np.array_equal(d["radii"], ref["radii"])
+    vis = ref["radii"] > 0
+    assert np.array_equal(hh.hip_state("tiles_touched", s, d), st.get("tiles_touched"))
+    assert d["num_rendered"] == ref["num_rendered"]
+    for name, w in (("depths", 1), ("means2D", 2), ("conic_opacity", 4), ("rgb", 3), ("cov3D", 6)):
+        a = hh.hip_state(name, s, d).reshape(P, w)
+        b = st.get(name).reshape(P, w)
+        rows = vis if name != "cov3D" else (hh.hip_state("depths", s, d) != 0) | vis
+        if name == "cov3D":
+            rows = vis  # the reference computes cov3D for every near-plane survivor; only visible rows are consumed
+        assert np.array_equal(bits(a[rows]), bits(b[rows])), name
+    assert np.array_equal(hh.hip_state("clamped", s, d).reshape(P, 3)[vis], st.get("clamped").reshape(P, 3)[vis])
+    # integer path: the sorted instance list and the range table
+    assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    assert np.array_equal(hh.hip_state("keys", s, d), st.get("keys"))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_images(oracle, case):
+    P, W, H, deg, seed = case
+    s = make_scene(P, W, H, seed)
+    _, d = hh.hip_forward(s, deg)
+    st, ref = hh.oracle_forward(oracle, s, deg)
+    for k in ("color", "depth", "depth_median", "opacity_map"):
+        assert d[k].shape == ref[k].shape and d[k].dtype == np.float32
+        assert_image_close(d[k], ref[k], k)
+    assert np.all(d["depth_var"] == 0)
+    nc = hh.hip_state("n_contrib", s, d)
+    assert np.mean(nc != st.get("n_contrib")) <= 1e-4
+    assert_grad_close(d["gau_uncertainty"], ref["gau_uncertainty"], "gau_uncertainty", rel_to_max=1e-3)
+    assert np.mean(d["gau_related_pixels"] != ref["gau_related_pixels"]) <= 1e-3
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mode", [(False, False), (True, False), (False, True)])
+def test_backward_gradients(oracle, case, mode):
+    P, W, H, deg, seed = case
+    track_off, map_off = mode
+    s = make_scene(P, W, H, seed)
+    # gradient images scaled up so that sums over pixels are O(1)
+    grads = tuple(g * (W * H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+    out, d = hh.hip_forward(s, deg)
+    g = hh.hip_backward(s, deg, out, track_off=track_off, map_off=map_off, grads=grads)
+    st, ref = hh.oracle_forward(oracle, s, deg)
+    gr = hh.oracle_backward(oracle, st, s, deg, ref["opacity_map"], track_off=track_off, map_off=map_off, grads=grads)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        assert g[k].shape == gr[k].shape, k
+        if map_off:
+            assert not g[k].any(), k  # tracking mode: no Gaussian gradients (L/cr/backward.cu:593,609,654,666)
+        else:
+            assert_grad_close(g[k], gr[k], k)
+    assert g["dL_dview"].shape == (4, 4)
+    if track_off:
+        assert not g["dL_dview"].any()
+    else:
+        assert not g["dL_dview"].reshape(-1)[[3, 7, 11, 15]].any()
+        assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=1e-3, elem_rtol=5e-3, elem_frac=0.1)

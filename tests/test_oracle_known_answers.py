@@ -1,0 +1,92 @@
+"""Pins the CPU oracle to the known-answer table of SURVEY.md Appendix C.
+
+Those values were recorded by the survey from a CPU execution of the reference's own sources on the
+synth-v1 inputs (the reference ships no tests or golden vectors of its own).  The survey's build bound
+the reference's unqualified exp/sqrt/ceil to the C double functions; the oracle's C-math build restates
+exactly that and must reproduce every digit.  The float-math build (what nvcc does, and what the GPU
+tests compare against) must agree with it to rounding noise.
+"""
+import numpy as np
+import pytest
+
+from dgr_amd.synth import make_scene, sha16
+
+# (P, W, H, deg) -> Appendix C columns (light variant)
+KNOWN = {
+    (10000, 256, 256, 0): dict(
+        means_sha="dd02a0f8f00c0442", visible=9384, sum_radii=80637, max_radius=16, radii_sha="059d16ea0b759cbd",
+        R=33704, list_mean=131.7, list_max=175, sum_n_contrib=7517087, color=87338.847, depth=150035.715,
+        alpha=53164.300, median=184287.010, c000=0.56643301,
+        dview=[+4.726215e-01, +3.502292e-01, +1.156665e-01, 0, +1.211684e-01, -2.053160e-01, -1.180594e-01, 0,
+               -2.573290e-01, +5.135866e-01, -2.080060e-01, 0, -2.883756e-01, +1.813904e-01, -1.363746e-01, 0],
+        gmax=dict(dL_dmeans3D=9.7e-2, dL_dopacity=2.0e-3, dL_dscales=1.0e-1, dL_drotations=3.8e-3, dL_dsh=5.3e-5)),
+    (100000, 640, 480, 3): dict(
+        means_sha="be3b5ffff70d420b", visible=87665, sum_radii=737518, max_radius=15, radii_sha="a20a1623bad630ac",
+        R=332318, list_mean=276.9, list_max=336, sum_n_contrib=79527935, color=452621.003, depth=678213.701,
+        alpha=298156.216, median=647604.466, c000=0.62521714,
+        dview=[-3.450621e-01, +2.552776e-01, +1.151826e-01, 0, -1.766948e-01, -1.966203e-02, +8.297658e-02, 0,
+               +2.150890e-02, -6.519964e-01, +3.327241e-01, 0, -5.430901e-02, -4.144245e-01, +2.108066e-01, 0],
+        gmax=dict(dL_dmeans3D=7.1e-2, dL_dopacity=4.0e-4, dL_dscales=5.9e-2, dL_drotations=7.3e-4, dL_dsh=3.3e-5)),
+    (500000, 1920, 1080, 3): dict(
+        means_sha="f1c9f89692e11a8a", visible=425824, sum_radii=3533817, max_radius=15, radii_sha="e5c9b48ef4f1074e",
+        R=1654310, list_mean=202.7, list_max=261, sum_n_contrib=383941016, color=2964281.851, depth=4848955.363,
+        alpha=1911324.401, median=5131457.176, c000=0.52706647,
+        dview=[-3.277759e-01, -1.357393e-01, +9.185782e-02, 0, -1.309201e-01, +8.697420e-02, +2.854166e-03, 0,
+               +4.315028e-01, -1.640987e+00, +1.460000e-01, 0, +3.842236e-01, -1.504349e+00, +1.134152e-01, 0],
+        gmax=dict(dL_dmeans3D=3.2e-2, dL_dopacity=7.3e-5, dL_dscales=2.7e-2, dL_drotations=1.8e-4, dL_dsh=5.3e-6)),
+}
+
+
+def run_light(O, s, deg, **kw):
+    st, out = O.light_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj,
+                              s.tanfovx, s.tanfovy, s.H, s.W, s.shs, deg, s.campos)
+    g = O.light_backward(st, s.bg, s.means, None, s.scales, s.rots, 1.0, None, s.view, s.proj, s.tanfovx, s.tanfovy,
+                         s.gC, s.gD, s.gM, s.gV, s.gt, s.shs, deg, s.campos, out["opacity_map"], s.persp, **kw)
+    return st, out, g
+
+
+@pytest.mark.parametrize("cfg", list(KNOWN))
+def test_appendix_c_known_answers(oracle, cfg):
+    P, W, H, deg = cfg
+    k = KNOWN[cfg]
+    s = make_scene(P, W, H, 0)
+    assert sha16(s.means) == k["means_sha"]  # generator itself
+    oracle.use_cmath(True)
+    try:
+        st, out, g = run_light(oracle, s, deg)
+    finally:
+        oracle.use_cmath(False)
+    r = out["radii"]
+    assert int((r > 0).sum()) == k["visible"]
+    assert int(r.sum()) == k["sum_radii"] and int(r.max()) == k["max_radius"]
+    assert sha16(r) == k["radii_sha"]
+    assert out["num_rendered"] == k["R"]
+    rg = st.get("ranges").reshape(-1, 2)
+    ln = rg[:, 1].astype(np.int64) - rg[:, 0]
+    assert round(float(ln.mean()), 1) == k["list_mean"] and int(ln.max()) == k["list_max"]
+    assert int(st.get("n_contrib").astype(np.int64).sum()) == k["sum_n_contrib"]
+    for name, key in (("color", "color"), ("depth", "depth"), ("opacity_map", "alpha"), ("depth_median", "median")):
+        assert f"{out[name].astype(np.float64).sum():.3f}" == f"{k[key]:.3f}", name
+    assert f"{out['color'][0, 0, 0]:.8f}" == f"{k['c000']:.8f}"
+    assert np.all(out["depth_var"] == 0)
+    # pose gradient: the table prints 7 significant digits (half a unit of the last one = 5e-7 relative)
+    np.testing.assert_allclose(g["dL_dview"].reshape(-1), np.array(k["dview"]), rtol=6e-7, atol=0)
+    for name, v in k["gmax"].items():
+        assert abs(np.abs(g[name]).max() - v) <= 0.06 * v, name  # table holds 2 significant digits
+
+
+def test_float_math_build_agrees_with_cmath_build(oracle):
+    """exp/sqrt binding moves no integer and only rounding-level floats on config 1."""
+    s = make_scene(10000, 256, 256, 0)
+    oracle.use_cmath(True)
+    try:
+        st_c, out_c, g_c = run_light(oracle, s, 0)
+    finally:
+        oracle.use_cmath(False)
+    st_f, out_f, g_f = run_light(oracle, s, 0)
+    assert np.array_equal(out_c["radii"], out_f["radii"])
+    assert np.array_equal(st_c.get("point_list"), st_f.get("point_list"))
+    assert np.array_equal(st_c.get("n_contrib"), st_f.get("n_contrib"))
+    for k in ("color", "depth", "opacity_map", "depth_median"):
+        assert np.abs(out_c[k] - out_f[k]).max() <= 1e-5, k
+    np.testing.assert_allclose(g_f["dL_dview"], g_c["dL_dview"], rtol=1e-4, atol=1e-6)

@@ -1,0 +1,39 @@
+"""Shared helpers for the parity tests."""
+import numpy as np
+
+from dgr_amd.synth import make_scene  # noqa: F401
+
+
+def frac_outside(a, ref, atol, rtol):
+    """Fraction of elements with |a-ref| > atol*max(1,|ref|)... generalised: atol + rtol*|ref|."""
+    a = np.asarray(a, np.float64)
+    ref = np.asarray(ref, np.float64)
+    return float(np.mean(np.abs(a - ref) > (atol + rtol * np.abs(ref))))
+
+
+def assert_image_close(a, ref, name, tol=1e-5, max_outliers=1e-4):
+    """north_star tolerance: |d| <= 1e-5 * max(1, |ref|) per value, for all but a bounded fraction of
+    values.  The outlier budget exists because one-ulp differences in exp() flip the reference's hard
+    thresholds (alpha < 15/255, T < 1e-4) for a handful of pixel/Gaussian pairs per frame; the reference
+    itself moves by this much between FMA-on and FMA-off builds (SURVEY.md s7 "Hard parts")."""
+    a = np.asarray(a, np.float64)
+    ref = np.asarray(ref, np.float64)
+    bad = np.abs(a - ref) > tol * np.maximum(1.0, np.abs(ref))
+    frac = float(bad.mean())
+    assert frac <= max_outliers, f"{name}: {frac:.2e} of values off by > {tol} (max |d| = {np.abs(a - ref).max():.3e})"
+
+
+def assert_grad_close(a, ref, name, rel_to_max=2e-4, elem_rtol=2e-3, elem_frac=2e-3):
+    """Gradients are sums over many pixels of float atomics (order-nondeterministic in the reference too)
+    and inherit the forward's threshold flips: bound the worst element relative to the tensor's scale,
+    and the fraction of elements that miss a per-element relative tolerance."""
+    a = np.asarray(a, np.float64)
+    ref = np.asarray(ref, np.float64)
+    scale = np.abs(ref).max()
+    if scale == 0:
+        assert np.abs(a).max() == 0, f"{name}: reference is all zero, got max {np.abs(a).max():.3e}"
+        return
+    err = np.abs(a - ref).max() / scale
+    assert err <= rel_to_max, f"{name}: max |d| / max |ref| = {err:.3e} > {rel_to_max}"
+    frac = float(np.mean(np.abs(a - ref) > (1e-7 * scale + elem_rtol * np.abs(ref))))
+    assert frac <= elem_frac, f"{name}: {frac:.2e} of elements off by > {elem_rtol} relative"
