@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- Mviews/s forward+backward @1080p, 500k Gaussians (BASELINE.json `metric`).
+
+One "step" = one view: GaussianRasterizer.forward + backward through the reference-shaped autograd
+surface (light variant, SH degree 3, all four pixel-gradient images non-zero, track_off = map_off =
+False) on the synth-v1 scene of BASELINE config 3, inputs resident in HBM before the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, rank r renders view r of the same Gaussians (weak scaling) and the
+per-Gaussian gradients are all-reduced (RCCL, one fused buffer) inside the timed region, as a mapping
+step over N views needs; pose gradients stay per view.  value = views of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel, `cpu_baseline` the CPU oracle
+timed on this host (oracle/ is used here only as the reported baseline, never inside the timed path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "diff-gaussian-rasterization_amd")
+for p in (ROOT, PKG, os.path.join(PKG, "light")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (P, W, H, sh_degree)
+    "config3": (500_000, 1920, 1080, 3),
+    "config2": (100_000, 640, 480, 3),
+    "config1": (10_000, 256, 256, 0),
+}
+
+
+def algorithmic_bytes(stage, P, V, R, N, M):
+    """Minimum HBM bytes of one launch of `stage` (V = visible, R = instances, N = pixels).
+    Every stage reads its inputs once and writes its outputs once; tile batches are staged in LDS."""
+    sh = 12 * M
+    table = {
+        # means 12 + scales 12 + rot 16 + opacity 4 in; radii 4 + rect 8 out; SH in, record 48 + depth 4 +
+        # cov3D 24 + clamp 1 out per visible Gaussian; one 4-B histogram RMW per instance
+        "preprocess_fwd": 44 * P + 12 * P + (sh + 77) * V + 4 * R,
+        "scan_tiles": 0,
+        "emit_instances": 8 * P + 4 * V + 8 * R,          # rect + depth in, one 8-B key out per instance
+        "sort_tiles": 8 * R + 12 * R,                      # keys in; sorted keys + point_list out
+        "render_fwd_light": 4 * R + 48 * R + 36 * N,       # id + record per instance; gt in, 7 images + n_contrib out
+        "zero_scratch": 64 * P,
+        "render_bwd_light": 4 * R + 48 * R + 56 * R + 36 * N,  # + 14 accumulator floats RMW per instance; 9 images in
+        # accumulator row 64 + means 12 + cov3D 24 + SH + scale/rot 28 in per visible; dense outputs
+        # (dmeans3D 12, dmeans2D 12, dsh, dscales 12, drot 16, dopacity 4, dcov3D 24, dcolors 12) per Gaussian
+        "preprocess_bwd": 4 * P + (128 + sh) * V + (92 + sh) * P,
+    }
+    return float(table[stage])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        assert world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dgr_amd import _capi
+    from dgr_amd.multiview import GradientArena, make_settings
+    from dgr_amd.synth import make_scene
+    from diff_gaussian_rasterization import GaussianRasterizer
+
+    P, W, H, deg = WORKLOADS[args.workload]
+    s = make_scene(P, W, H, seed=0, view_index=rank)  # rank r renders view r of the same Gaussians
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    means3D = t(s.means).requires_grad_(True)
+    shs = t(s.shs).requires_grad_(True)
+    opac = t(s.opac).requires_grad_(True)
+    scales = t(s.scales).requires_grad_(True)
+    rots = t(s.rots).requires_grad_(True)
+    means2D = torch.zeros((P, 3), device=dev, requires_grad=True)
+    view = t(s.view).requires_grad_(True)
+    gt = t(s.gt)
+    gC, gD, gM, gV = t(s.gC), t(s.gD[None]), t(s.gM[None]), t(s.gV[None])
+    rast = GaussianRasterizer(make_settings(s, deg, dev))
+    params = [means3D, means2D, shs, opac, scales, rots]
+    arena = GradientArena(params) if world > 1 else None
+
+    def step():
+        for p_ in params + [view]:
+            p_.grad = None
+        color, radii, depth, median, var, alpha, unc, px = rast(
+            means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots,
+            viewmatrix=view, gt_depth=gt)
+        torch.autograd.backward([color, depth, median, var], [gC, gD, gM, gV])
+        if arena is not None:
+            arena.all_reduce(dist)  # one fused RCCL all-reduce of the per-Gaussian gradients
+        return radii
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        radii = step()
+    # calibration pass (untimed): every stage bracketed, to find the dominant kernel
+    _capi.profile_select("all")
+    for _ in range(3):
+        radii = step()
+    torch.cuda.synchronize(dev)
+    stage_ms = {}
+    for st_name in _capi.profile_stages():
+        tot, n = _capi.profile_read(st_name)
+        if n:
+            stage_ms[st_name] = tot / n
+    dominant = max(stage_ms, key=stage_ms.get)
+    _capi.profile_select(dominant)  # during the timed region only the dominant kernel is bracketed (2 events/step)
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        radii = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dom_tot, dom_n = _capi.profile_read(dominant)
+    _capi.profile_select("")
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        V = int((radii > 0).sum().item())
+        R = int(_capi_last_num_rendered(P, H, W, dev))
+        N = W * H
+        views_per_s = world * args.steps / elapsed
+        dom_ms = dom_tot / max(dom_n, 1)
+        abytes = algorithmic_bytes(dominant, P, V, R, N, 16)
+        achieved = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_file):
+            try:
+                traffic = json.load(open(pmc_file)).get(args.workload, {}).get(dominant)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mviews/sec fwd+bwd @1080p, 500k Gaussians",
+            "value": views_per_s / 1e6,
+            "unit": "Mviews/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, light variant, "
+                                   f"fwd+bwd incl. viewmatrix gradient, one view per GPU", "visible": V,
+                       "num_rendered": R, "views_per_s": views_per_s,
+                       "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": abytes,
+                         "avg_ms": dom_ms, "launches": dom_n},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(s, deg, args.cpu_runs)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _capi_last_num_rendered(P, H, W, dev):
+    from dgr_amd import light
+    return light._capacity_cache.get((dev.index, P, H, W), 0)
+
+
+def cpu_baseline(s, deg, runs):
+    """The CPU oracle (OpenMP restatement of the reference path) timed on this host: full forward+backward of
+    the same view, `runs` repetitions after one warm-up.  A reported baseline, not the thing measured above."""
+    from oracle import oracle as O
+    O.build()
+
+    def once():
+        st, out = O.light_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj,
+                                  s.tanfovx, s.tanfovy, s.H, s.W, s.shs, deg, s.campos)
+        O.light_backward(st, s.bg, s.means, None, s.scales, s.rots, 1.0, None, s.view, s.proj, s.tanfovx, s.tanfovy,
+                         s.gC, s.gD, s.gM, s.gV, s.gt, s.shs, deg, s.campos, out["opacity_map"], s.persp)
+
+    once()
+    ts = []
+    for _ in range(max(runs, 1)):
+        t0 = time.perf_counter()
+        once()
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    cpu = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": 1.0 / med / 1e6, "unit": "Mviews/s", "cores": cores, "kind": "port",
+            "sample": f"{len(ts)} full fwd+bwd views of the same workload after 1 warm-up, median {med:.3f} s "
+                      f"(min {min(ts):.3f} s), OpenMP on {cpu}"}
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -32,6 +35,36 @@ int hip_fail(hipError_t e, const char* what) {
     } while (0)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- optional per-stage timing with HIP events on the launching stream (dgr_profile_* in dgr_hip.h).
+// Disabled by default; when a stage is selected, two events bracket that stage's launch only.
+struct StageProf {
+    const char* name;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+StageProf g_prof[] = {{"preprocess_fwd"}, {"scan_tiles"}, {"emit_instances"}, {"sort_tiles"}, {"render_fwd_light"},
+                      {"zero_scratch"}, {"render_bwd_light"}, {"preprocess_bwd"}};
+enum { ST_PRE_FWD, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD, ST_ZERO, ST_RENDER_BWD, ST_PRE_BWD, ST_COUNT };
+std::mutex g_prof_mu;
+
+struct ScopedStage {
+    StageProf* p = nullptr;
+    hipStream_t st;
+    hipEvent_t a{}, b{};
+    ScopedStage(int id, hipStream_t s) : st(s) {
+        if (!g_prof[id].on) return;
+        p = &g_prof[id];
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { p = nullptr; return; }
+        (void)hipEventRecord(a, st);
+    }
+    ~ScopedStage() {
+        if (!p) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        p->ev.emplace_back(a, b);
+    }
+};
 
 struct FwdCommon {
     int P, D, M, W, H;
@@ -75,8 +108,8 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
     a.prefiltered = c.prefiltered;
     a.sh_vec_ok = aligned16(c.shs);
     a.geom = geom; a.radii_out = c.radii; a.tile_count = img.tile_count; a.status = img.status;
-    HIP_TRY(dgr::launch_preprocess_fwd(a, st));
-    HIP_TRY(dgr::launch_scan_tiles(img, tiles, capacity, st));
+    { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd(a, st)); }
+    { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, capacity, st)); }
     return DGR_OK;
 }
 
@@ -84,8 +117,8 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
                  hipStream_t st) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
     if (have_instances) {
-        HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st));
-        HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st));
+        { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
+        { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
     }
     dgr::RenderFwdLightArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
@@ -93,7 +126,7 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_median = c.out_median_depth; r.out_alpha = c.out_alpha;
     r.out_depth_var = c.out_depth_var; r.n_contrib = img.n_contrib; r.gau_uncertainty = c.gau_uncertainty;
     r.gau_related_pixels = c.gau_related_pixels;
-    HIP_TRY(dgr::launch_render_fwd_light(r, st));
+    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_light(r, st)); }
     return DGR_OK;
 }
 
@@ -258,7 +291,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st));
+    { ScopedStage t(ST_ZERO, st); HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
 
     dgr::RenderBwdLightArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
@@ -266,7 +299,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     r.gt_depth = gt_depth; r.alphas = alphas; r.n_contrib = img.n_contrib; r.dL_dpix = dL_dpix;
     r.dL_dpix_depth = dL_dpix_depth; r.dL_dpix_median = dL_dpix_median_depth; r.dL_dpix_var = dL_dpix_depth_var;
     r.means3D = means3D; r.view = viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
-    HIP_TRY(dgr::launch_render_bwd_light(r, st));
+    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_light(r, st)); }
 
     dgr::PreprocessBwdArgs b{};
     b.P = P; b.D = D; b.M = M; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs; b.scales = scales;
@@ -279,9 +312,44 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor;
     b.dL_ddepth = dL_ddepth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
     b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part;
-    HIP_TRY(dgr::launch_preprocess_bwd(b, dL_dview, st));
+    { ScopedStage t(ST_PRE_BWD, st); HIP_TRY(dgr::launch_preprocess_bwd(b, dL_dview, st)); }
     if (debug) HIP_TRY(hipStreamSynchronize(st));
     return DGR_OK;
+}
+
+int dgr_profile_select(const char* stage) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    const std::string n(stage ? stage : "");
+    bool found = n.empty() || n == "all";
+    for (auto& p : g_prof) {
+        p.on = (n == "all") || (n == p.name);
+        found = found || p.on;
+    }
+    return found ? DGR_OK : DGR_ERR_BAD_ARGUMENT;
+}
+int dgr_profile_stage_count(void) { return ST_COUNT; }
+const char* dgr_profile_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? g_prof[i].name : ""; }
+int dgr_profile_read(const char* stage, double* total_ms, int* launches) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& p : g_prof) {
+        if (std::string(stage) != p.name) continue;
+        double tot = 0;
+        int n = 0;
+        for (auto& e : p.ev) {
+            float ms = 0;
+            if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) {
+                tot += ms;
+                n++;
+            }
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+        p.ev.clear();
+        *total_ms = tot;
+        *launches = n;
+        return DGR_OK;
+    }
+    return DGR_ERR_BAD_ARGUMENT;
 }
 
 long dgr_state_export(void* stream, const char* name, int P, int width, int height, int num_rendered,

@@ -43,6 +43,10 @@ _SIGS = {
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
                                 _vp, _i, _i, _vp, _sz]),
     "dgr_state_export": (C.c_long, [_vp, C.c_char_p, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dgr_profile_select": (_i, [C.c_char_p]),
+    "dgr_profile_stage_count": (_i, []),
+    "dgr_profile_stage_name": (C.c_char_p, [_i]),
+    "dgr_profile_read": (_i, [C.c_char_p, C.POINTER(C.c_double), C.POINTER(_i)]),
 }
 
 _lib = None
@@ -82,3 +86,23 @@ def ptr(t):
 
 def stream_handle():
     return torch.cuda.current_stream().cuda_stream
+
+
+def profile_select(stage=""):
+    rc = load().dgr_profile_select(stage.encode())
+    if rc:
+        raise ValueError(f"unknown stage {stage!r}")
+
+
+def profile_stages():
+    lib = load()
+    return [lib.dgr_profile_stage_name(i).decode() for i in range(lib.dgr_profile_stage_count())]
+
+
+def profile_read(stage):
+    """(total milliseconds, launches) recorded for `stage` since the last read."""
+    tot, n = C.c_double(0), C.c_int(0)
+    rc = load().dgr_profile_read(stage.encode(), C.byref(tot), C.byref(n))
+    if rc:
+        raise ValueError(f"unknown stage {stage!r}")
+    return tot.value, n.value

@@ -1,0 +1,55 @@
+"""One-view-per-GPU sharding helpers: views are independent, Gaussians are replicated,
+and the only exchange step of a mapping iteration is a sum of the per-Gaussian gradients over GPUs.
+
+`GradientArena.all_reduce` performs that sum with ONE collective: the backward writes all per-Gaussian
+gradients into one flat arena (dgr_amd.light._C.rasterize_gaussians_backward) and autograd hands the
+arena's views to `.grad` without copying, so the contiguous span holding
+[dL_dmeans3D | dL_dmeans2D | dL_dsh | dL_dopacity | dL_dscales | dL_drot] (236 B + 12 B per Gaussian at
+SH degree 3) is reduced in place.  Pose gradients (`viewmatrix.grad`) are per view and never reduced.
+In tracking mode (map_off) there are no Gaussian gradients and no collective at all.
+"""
+import torch
+
+from . import light
+
+
+def make_settings(s, sh_degree, device, track_off=False, map_off=False, debug=False, prefiltered=False,
+                  scale_modifier=1.0):
+    """GaussianRasterizationSettings (light field order) for a dgr_amd.synth.Scene."""
+    t = lambda a: torch.as_tensor(a, dtype=torch.float32, device=device)  # noqa: E731
+    return light.GaussianRasterizationSettings(
+        image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=t(s.bg),
+        scale_modifier=scale_modifier, viewmatrix=t(s.view), projmatrix=t(s.proj), sh_degree=sh_degree,
+        campos=t(s.campos), prefiltered=prefiltered, debug=debug, perspec_matrix=t(s.persp),
+        track_off=track_off, map_off=map_off)
+
+
+class GradientArena:
+    """Sums the gradients of the Gaussian parameters over all ranks after a backward."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p is not None]
+
+    def fused_span(self):
+        """The flat span aliasing every parameter's .grad, or None if autograd copied instead of aliasing."""
+        if light._last_arena is None:
+            return None
+        arena, n = light._last_arena
+        lo, hi = arena.data_ptr(), arena.data_ptr() + 4 * n
+        for p in self.params:
+            g = p.grad
+            if g is None or not g.is_contiguous() or not (lo <= g.data_ptr() and g.data_ptr() + 4 * g.numel() <= hi):
+                return None
+        return arena[:n]
+
+    def all_reduce(self, dist, group=None):
+        span = self.fused_span()
+        if span is not None:
+            dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
+            return 1
+        n = 0
+        for p in self.params:  # fallback: gradients were copied by autograd; reduce them one by one
+            if p.grad is not None:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group)
+                n += 1
+        return n

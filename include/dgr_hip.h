@@ -116,6 +116,16 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
 long dgr_state_export(void* stream, const char* name, int P, int width, int height, int num_rendered,
                       const char* geom_buffer, const char* binning_buffer, const char* image_buffer, void* dst_device);
 
+/* ---- per-stage timing (bench.py's roofline object) ----
+ * dgr_profile_select("") disables timing (default), "all" brackets every stage, a stage name brackets that
+ * stage only with two HIP events recorded on the launching stream.  Stage names: dgr_profile_stage_name(i),
+ * i < dgr_profile_stage_count().  dgr_profile_read waits for the recorded events, returns their summed
+ * duration and the number of launches since the previous read, and clears them. */
+int dgr_profile_select(const char* stage);
+int dgr_profile_stage_count(void);
+const char* dgr_profile_stage_name(int i);
+int dgr_profile_read(const char* stage, double* total_ms, int* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,11 +82,15 @@ def binning_capacity(d, W, H):
 
 
 def hip_backward(s, deg, out, colors_precomp=None, cov3D_precomp=None, track_off=False, map_off=False,
-                 scale_modifier=1.0, grads=None):
+                 scale_modifier=1.0, grads=None, alphas=None):
+    """`alphas` overrides the forward's own opacity map (stage isolation: the light backward derives
+    T_final = 1 - alpha, which amplifies one-ulp forward differences on nearly opaque pixels)."""
     use_sh = colors_precomp is None
     use_sr = cov3D_precomp is None
     (R, color, depth, median, var, alpha, radii, geom, binning, img, _, _) = out
     gC, gD, gM, gV = grads if grads is not None else (s.gC, s.gD, s.gM, s.gV)
+    if alphas is not None:
+        alpha = T(alphas)
     g = L._C.rasterize_gaussians_backward(
         T(s.bg), T(s.means), radii, E() if use_sh else T(colors_precomp), T(s.scales) if use_sr else E(),
         T(s.rots) if use_sr else E(), scale_modifier, E() if use_sr else T(cov3D_precomp), T(s.view), T(s.proj),

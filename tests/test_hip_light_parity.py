@@ -66,27 +66,49 @@ def test_forward_images(oracle, case):
     assert np.mean(d["gau_related_pixels"] != ref["gau_related_pixels"]) <= 1e-3
 
 
+GRAD_NAMES = ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+
+
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("mode", [(False, False), (True, False), (False, True)])
 def test_backward_gradients(oracle, case, mode):
+    """Backward parity, stage-isolated and end to end.
+
+    The light backward recovers the final transmittance as T_final = 1 - alpha_image
+    (L/cuda_rasterizer/backward.cu:477): on nearly opaque pixels (T_final ~ 1e-4) a one-ulp difference in
+    the forward's alpha sum is a ~1e-3 relative change of T and of every gradient of that pixel.  That is a
+    property of the reference algorithm (it reacts the same way to its own exp() rounding), so:
+      * with the ORACLE's alpha image handed to the HIP backward, gradients must agree to 1e-5 of each
+        tensor's scale -- this is the parity bar for the backward kernels;
+      * end to end (HIP forward feeding HIP backward) the bound is the amplified one.
+    """
     P, W, H, deg, seed = case
     track_off, map_off = mode
     s = make_scene(P, W, H, seed)
-    # gradient images scaled up so that sums over pixels are O(1)
-    grads = tuple(g * (W * H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+    grads = tuple(g * (W * H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))  # pixel sums of O(1)
     out, d = hh.hip_forward(s, deg)
-    g = hh.hip_backward(s, deg, out, track_off=track_off, map_off=map_off, grads=grads)
     st, ref = hh.oracle_forward(oracle, s, deg)
     gr = hh.oracle_backward(oracle, st, s, deg, ref["opacity_map"], track_off=track_off, map_off=map_off, grads=grads)
-    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
-        assert g[k].shape == gr[k].shape, k
-        if map_off:
-            assert not g[k].any(), k  # tracking mode: no Gaussian gradients (L/cr/backward.cu:593,609,654,666)
+    same_lists = np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
+    for label, alphas in (("isolated", ref["opacity_map"]), ("end-to-end", None)):
+        g = hh.hip_backward(s, deg, out, track_off=track_off, map_off=map_off, grads=grads, alphas=alphas)
+        tight = label == "isolated" and same_lists
+        for k in GRAD_NAMES:
+            assert g[k].shape == gr[k].shape, k
+            if map_off:
+                assert not g[k].any(), k  # tracking mode: no Gaussian gradients (L/cr/backward.cu:593,609,654,666)
+            elif tight:
+                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-4)
+            else:
+                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=3e-3, elem_rtol=2e-2, elem_frac=2e-2)
+        assert g["dL_dview"].shape == (4, 4)
+        if track_off:
+            assert not g["dL_dview"].any()
         else:
-            assert_grad_close(g[k], gr[k], k)
-    assert g["dL_dview"].shape == (4, 4)
-    if track_off:
-        assert not g["dL_dview"].any()
-    else:
-        assert not g["dL_dview"].reshape(-1)[[3, 7, 11, 15]].any()
-        assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=1e-3, elem_rtol=5e-3, elem_frac=0.1)
+            assert not g["dL_dview"].reshape(-1)[[3, 7, 11, 15]].any()
+            if tight:
+                assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=1e-5, elem_rtol=1e-3,
+                                  elem_frac=0.0)
+            else:
+                assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=3e-3, elem_rtol=2e-2,
+                                  elem_frac=0.1)
