@@ -317,6 +317,11 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     return DGR_OK;
 }
 
+int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4) {
+    HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out4, comp16, comp4, (hipStream_t)stream));
+    return DGR_OK;
+}
+
 int dgr_profile_select(const char* stage) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     const std::string n(stage ? stage : "");

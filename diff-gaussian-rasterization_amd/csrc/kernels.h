@@ -105,5 +105,6 @@ hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStrea
 
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream);
 hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stream);
+hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, hipStream_t stream);
 
 }  // namespace dgr

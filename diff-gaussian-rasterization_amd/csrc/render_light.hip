@@ -22,6 +22,7 @@
 // reduction); forward and backward use the identical expression so they agree on every decision.
 #include "dgr_common.h"
 #include "kernels.h"
+#include "wave_reduce.h"
 
 namespace dgr {
 namespace {
@@ -175,12 +176,27 @@ __global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArg
 }
 
 // ================================================================================ backward
+// Per-Gaussian gradient sums.  Only ~6 of a wave's 64 pixels are hit by any one Gaussian and LDS float
+// atomics retire barely one lane per cycle on gfx950 (measured: 55 % of wave cycles in SQ_WAIT_INST_LDS
+// with per-lane ds_add_f32), so the sums are formed in registers: every in-mask Gaussian is visited
+// wave-uniformly (as in the forward), the valid lanes compute their 14 contributions, and ONE butterfly
+// (wave_reduce.h, 33 instructions) reduces all 14 across the wave at once, leaving each total in its own
+// lane quad.  A single ds_add_f32 with 14 active lanes on 14 distinct banks then merges the four
+// quadrant waves in LDS accumulators acc[14][257], which are flushed once per batch with line-coalesced
+// global atomics (16 consecutive lanes = one Gaussian's 64-byte accumulator row).  Global float atomics
+// drop from 14 per valid (pixel, Gaussian) pair to <= 14 per (tile, Gaussian).
+// Tracking mode (map_off) needs only the three sums the pose gradient is built from: a 4-value butterfly.
+constexpr int NACC = 14;
+constexpr int ACC_LD = DGR_TILE_PIX + 1;
+
 struct StagedBwd {
     Staged f;
     float4 raw[DGR_TILE_PIX];  // {conic a, b, c, unused}
+    float acc[NACC * ACC_LD];
     int max_last;
 };
 
+template <bool DO_MAP, bool DO_POSE>
 __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArgs a) {
     __shared__ StagedBwd sb;
     Staged& s = sb.f;
@@ -227,19 +243,31 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f, last_var = 0.f;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     bool mid_once = true;
-    const bool do_map = !a.map_off, do_pose = !a.track_off;
+    const float v2 = a.view[2], v3 = a.view[3], v6 = a.view[6], v7 = a.view[7], v10 = a.view[10], v11 = a.view[11],
+                v14 = a.view[14];
+    // which accumulator component this lane's quad delivers after the butterfly (-1: none)
+    int my_comp;
+    if (DO_MAP) {
+        const int c = wave_reduce16_comp(lane);
+        my_comp = ((lane & 3) == 0 && c < NACC) ? c : -1;
+    } else {
+        const int c = wave_reduce4_comp(lane);  // {4: gmx, 5: gmy, 13: pose depth}
+        my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
+    }
 
     // back-to-front: batches cover list positions [lo, hi) with hi walking down from `total`
     for (int hi = total; hi > 0; hi -= DGR_TILE_PIX) {
         const int lo = max(0, hi - DGR_TILE_PIX);
         const int cnt = hi - lo;
-        __syncthreads();
+        __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
         if (tid < cnt) {
             float3 raw;
             code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, &raw);
             sb.raw[tid] = make_float4(raw.x, raw.y, raw.z, 0.f);
         }
+#pragma unroll
+        for (int k = 0; k < NACC; k++) sb.acc[k * ACC_LD + tid] = 0.f;
         publish_masks(s, code, wave, lane);
         __syncthreads();
 
@@ -249,20 +277,22 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                 const int b = 63 - __builtin_clzll(m);
                 m &= ~(1ull << b);
                 const int j = sub * 64 + b;
-                const int pos = lo + j;  // 0-based position in the tile list
                 const float2 xy = s.xy[j];
                 const float4 co = s.con[j];
                 const float dx = xy.x - pxf, dy = xy.y - pyf;
                 const float p2 = dx * (co.x * dx + co.y * dy) + co.z * dy * dy;
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, co.w * G);
-                if (pos < last_contributor && p2 <= 0.0f && alpha >= ALPHA_MIN) {
+                const bool valid = (lo + j) < last_contributor && p2 <= 0.0f && alpha >= ALPHA_MIN;
+                if (!__any(valid)) continue;
+
+                float g[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) g[k] = 0.f;
+                if (valid) {
                     const float4 cd = s.rgbd[j];
                     const float4 rc = sb.raw[j];
-                    const uint32_t gid = s.id[j];
-                    float* row = a.acc + (size_t)gid * DGR_ACC_STRIDE;
-                    const float one_m_alpha = 1.f - alpha;
-                    const float inv = __builtin_amdgcn_rcpf(one_m_alpha);
+                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     T = T * inv;
                     const float w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
                     const float dL_ddepth = w * dpix_depth;
@@ -289,34 +319,69 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                     const float dG_ddely = -gdy * rc.z - gdx * rc.y;
                     const float gmx = dL_dG * dG_ddelx * ddelx_dx;  // == dL_dndcs_x of backward.cu:635
                     const float gmy = dL_dG * dG_ddely * ddely_dy;
-                    if (do_map) {
-                        atomicAdd(row + 0, w * dpix0);
-                        atomicAdd(row + 1, w * dpix1);
-                        atomicAdd(row + 2, w * dpix2);
-                        atomicAdd(row + 3, dL_ddepth + dpix_var * w * 2.f * e);
+                    if (DO_MAP) {
+                        g[0] = w * dpix0;
+                        g[1] = w * dpix1;
+                        g[2] = w * dpix2;
+                        g[3] = dL_ddepth + dpix_var * w * 2.f * e;
+                        g[4] = gmx;
+                        g[5] = gmy;
+                        g[6] = -0.5f * gdx * dx * dL_dG;
+                        g[7] = -0.5f * gdx * dy * dL_dG;
+                        g[8] = -0.5f * gdy * dy * dL_dG;
+                        g[9] = G * dL_dalpha;
                         if (T > 0.5f && mid_once) {  // backward.cu:654-664
-                            const float* mg = a.means3D + 3 * (size_t)gid;
-                            const float* v = a.view;
-                            const float mul3 = v[2] * mg[0] + v[6] * mg[1] + v[10] * mg[2] + v[14];
-                            atomicAdd(row + 10, (v[2] - v[3] * mul3) * dpix_median);
-                            atomicAdd(row + 11, (v[6] - v[7] * mul3) * dpix_median);
-                            atomicAdd(row + 12, (v[10] - v[11] * mul3) * dpix_median);
+                            const float* mg = a.means3D + 3 * (size_t)s.id[j];
+                            const float mul3 = v2 * mg[0] + v6 * mg[1] + v10 * mg[2] + v14;
+                            g[10] = (v2 - v3 * mul3) * dpix_median;
+                            g[11] = (v6 - v7 * mul3) * dpix_median;
+                            g[12] = (v10 - v11 * mul3) * dpix_median;
                             mid_once = false;
                         }
-                        atomicAdd(row + 6, -0.5f * gdx * dx * dL_dG);
-                        atomicAdd(row + 7, -0.5f * gdx * dy * dL_dG);
-                        atomicAdd(row + 8, -0.5f * gdy * dy * dL_dG);
-                        atomicAdd(row + 9, G * dL_dalpha);
+                        if (DO_POSE) g[13] = dL_ddepth;
+                    } else {
+                        g[0] = gmx;
+                        g[1] = gmy;
+                        g[2] = dL_ddepth;
                     }
-                    if (do_map || do_pose) {
-                        atomicAdd(row + 4, gmx);
-                        atomicAdd(row + 5, gmy);
-                    }
-                    if (do_pose) atomicAdd(row + 13, dL_ddepth);
+                }
+                float tot;
+                if (DO_MAP) {
+                    tot = wave_reduce16(g, lane);
+                } else {
+                    float g4[4] = {g[0], g[1], g[2], 0.f};
+                    tot = wave_reduce4(g4);
+                }
+                if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * ACC_LD + j], tot);
+            }
+        }
+
+        // ---- flush: 16 consecutive lanes cover components 0..15 of one Gaussian's accumulator row
+        __syncthreads();
+        {
+            const int comp = tid & 15;
+            if (comp < NACC) {
+                for (int r = tid >> 4; r < cnt; r += 16) {
+                    const float v = sb.acc[comp * ACC_LD + r];
+                    if (v != 0.f) atomicAdd(a.acc + (size_t)s.id[r] * DGR_ACC_STRIDE + comp, v);
                 }
             }
         }
     }
+}
+
+// self-test of the butterflies: in[c * 64 + lane] -> out16[lane], out4[lane] (see dgr_debug_wave_reduce)
+__global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, float* out16, float* out4, int* comp16,
+                                                             int* comp4) {
+    const int lane = threadIdx.x;
+    float g[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) g[k] = in[k * 64 + lane];
+    float g4[4] = {g[0], g[1], g[2], g[3]};
+    out16[lane] = wave_reduce16(g, lane);
+    out4[lane] = wave_reduce4(g4);
+    comp16[lane] = wave_reduce16_comp(lane);
+    comp4[lane] = wave_reduce4_comp(lane);
 }
 
 }  // namespace
@@ -330,7 +395,16 @@ hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stre
 hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0 || (a.track_off && a.map_off)) return hipSuccess;
-    hipLaunchKernelGGL(render_bwd_light_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    if (!a.map_off && !a.track_off)
+        hipLaunchKernelGGL((render_bwd_light_kernel<true, true>), dim3(tiles), dim3(256), 0, stream, a);
+    else if (!a.map_off)
+        hipLaunchKernelGGL((render_bwd_light_kernel<true, false>), dim3(tiles), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((render_bwd_light_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, hipStream_t stream) {
+    hipLaunchKernelGGL(wave_reduce_test_kernel, dim3(1), dim3(64), 0, stream, in, out16, out4, comp16, comp4);
     return hipGetLastError();
 }
 

@@ -116,6 +116,11 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
 long dgr_state_export(void* stream, const char* name, int P, int width, int height, int num_rendered,
                       const char* geom_buffer, const char* binning_buffer, const char* image_buffer, void* dst_device);
 
+/* Self-test of the wave64 multi-value butterfly reductions the backward blend relies on.  `in` holds 16
+ * values per lane as in[c * 64 + lane]; out16[lane] / out4[lane] receive what each lane holds after the
+ * 16-value / 4-value reduction, comp16[lane] / comp4[lane] the index of the value that lane's total belongs to. */
+int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4);
+
 /* ---- per-stage timing (bench.py's roofline object) ----
  * dgr_profile_select("") disables timing (default), "all" brackets every stage, a stage name brackets that
  * stage only with two HIP events recorded on the launching stream.  Stage names: dgr_profile_stage_name(i),
