@@ -3,18 +3,23 @@
 // Replaces renderCUDA forward (L/cuda_rasterizer/forward.cu:261-412) and renderCUDA backward
 // (L/cuda_rasterizer/backward.cu:419-699).
 //
-// Shape of the computation on CDNA4 (wave64, LDS 160 KB/CU, scalar unit per wave):
+// Shape of the computation on CDNA4 (wave64, LDS 160 KB/CU, ONE scalar unit per CU):
 //  * one 256-thread workgroup per tile, wave w owns the 8x8-pixel quadrant (w&1, w>>1);
-//  * the sorted tile list is staged 256 instances at a time into LDS as SoA (xy | scaled conic +
-//    opacity | rgb + depth | id), one 48-byte record gather per thread;
-//  * while staging, every thread bounds the region where its Gaussian can reach alpha >= 15/255
-//    (the ellipse q(d) <= 2 ln(255 o / 15), boxed with a safety margin) and tests it against the four
-//    quadrants; four wave ballots per staging wave publish 64-bit "may touch quadrant w" masks;
-//  * each wave then walks only the set bits of its masks with scalar bit scans (s_ff1 / s_flbit):
-//    the loop trip count and the LDS addresses are wave-uniform, the per-pixel work is pure VALU on
-//    LDS-broadcast operands.  A skipped (pixel, Gaussian) pair is one the per-pixel test
-//    `power > 0 || alpha < 15/255` would have rejected, so outputs are unchanged; `contributor`
-//    (hence n_contrib) is the position in the tile list, which skipping does not alter.
+//  * the sorted tile list is staged 256 instances at a time into LDS: a 32-byte traversal record
+//    {x, y, a2, b2 | c2, opacity, slot, -} plus {r, g, b, depth} and the Gaussian id, one 48-byte gather
+//    per thread;
+//  * while staging, every thread bounds the region where its Gaussian can reach alpha >= 15/255 (the
+//    ellipse q(d) <= 2 ln(255 o / 15), boxed with a safety margin) and tests it against the four
+//    quadrants.  Wave ballots + mbcnt turn those tests into four COMPACTED lists of 16-bit record
+//    offsets, one per consumer wave, in tile-list order;
+//  * each wave walks its own list four entries at a time: one 8-byte LDS read yields four offsets, eight
+//    broadcast ds_read_b128 fetch the records, then pure VALU per pixel.  The loop has no scalar bit
+//    scans and "pixel finished" is a per-lane threshold register rather than a lane mask: the first
+//    version of this loop spent ~20 SALU instructions per Gaussian and was bound by the CU's single
+//    scalar unit (SQ_INSTS_SALU ~ 0.87 per CU cycle), not by the four SIMDs.
+//    A skipped (pixel, Gaussian) pair is one the per-pixel test `power > 0 || alpha < 15/255` would have
+//    rejected, so outputs are unchanged; `contributor` (hence n_contrib) is the position in the tile list,
+//    which skipping does not alter.
 //  * XCD-aware block->tile map: block b runs on XCD b%8, so each XCD is handed a contiguous band of
 //    tiles and neighbouring tiles share Gaussian records / accumulator rows in one L2.
 //
@@ -29,6 +34,8 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float ALPHA_MIN = 15.0f / 255.0f;  // forward.cu:365
+constexpr int SENTINEL = DGR_TILE_PIX;       // record slot that can never contribute (opacity 0)
+constexpr int LIST_LD = DGR_TILE_PIX + 8;    // list row: 256 entries + sentinel padding, 8-byte aligned rows
 
 // bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of tiles
 __device__ __forceinline__ int xcd_tile(int b, int n) {
@@ -39,24 +46,25 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
 }
 
 struct Staged {
-    float2 xy[DGR_TILE_PIX];
-    float4 con[DGR_TILE_PIX];   // {a2, b2, c2, opacity}: p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e)*power
-    float4 rgbd[DGR_TILE_PIX];  // {r, g, b, depth}
+    float4 rec[2 * (DGR_TILE_PIX + 1)];  // [2*slot] = {x, y, a2, b2}, [2*slot+1] = {c2, opacity, slot (int bits), 0}
+                                         //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power
+    float4 rgbd[DGR_TILE_PIX];           // {r, g, b, depth}
     uint32_t id[DGR_TILE_PIX];
-    unsigned long long mask[4][4];  // [staging wave = sub-batch of 64][consumer wave]
+    unsigned short list[4][LIST_LD];     // per consumer wave: byte offsets (slot * 32) into rec, tile-list order
+    int cnt4[4][4];                      // [staging wave][consumer wave] entries contributed
 };
 
 // Stage one instance and return the 4-bit "may touch quadrant" code.
 __device__ __forceinline__ unsigned stage_one(Staged& s, int slot, uint32_t gid, const float4* __restrict__ rec,
-                                              float tile_x0, float tile_y0, float3* raw_conic) {
+                                              float tile_x0, float tile_y0, float4* raw_conic) {
     const float4 q0 = rec[3 * (size_t)gid + 0];
     const float4 q1 = rec[3 * (size_t)gid + 1];
     const float4 q2 = rec[3 * (size_t)gid + 2];
-    s.xy[slot] = make_float2(q0.x, q0.y);
-    s.con[slot] = make_float4(-0.5f * LOG2E * q1.x, -LOG2E * q1.y, -0.5f * LOG2E * q1.z, q0.w);
+    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -LOG2E * q1.y);
+    s.rec[2 * slot + 1] = make_float4(-0.5f * LOG2E * q1.z, q0.w, __int_as_float(slot), 0.f);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
-    if (raw_conic) *raw_conic = make_float3(q1.x, q1.y, q1.z);
+    if (raw_conic) *raw_conic = make_float4(q1.x, q1.y, q1.z, 0.f);
     // alpha >= 15/255  <=>  a dx^2 + 2 b dx dy + c dy^2 <= tau = 2 ln(255 o / 15)
     const float o = q0.w;
     const float tau = 2.0f * __logf(o * (255.0f / 15.0f));
@@ -78,24 +86,55 @@ __device__ __forceinline__ unsigned stage_one(Staged& s, int slot, uint32_t gid,
     return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
 }
 
-__device__ __forceinline__ void publish_masks(Staged& s, unsigned code, int wave, int lane) {
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// Builds the four per-consumer lists from the staging threads' quadrant codes.  Contains two barriers;
+// returns the (uniform) length of the calling wave's list, padded to a multiple of 4 with sentinels.
+__device__ __forceinline__ int build_lists(Staged& s, unsigned code, int tid, int wave, int lane) {
+    unsigned long long bal[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
-        const unsigned long long m = __ballot((code >> w) & 1u);
-        if (lane == 0) s.mask[wave][w] = m;
+        bal[w] = __ballot((code >> w) & 1u);
+        if (lane == 0) s.cnt4[wave][w] = __popcll(bal[w]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if ((code >> w) & 1u) {
+            int base = 0;
+            for (int sw = 0; sw < wave; sw++) base += s.cnt4[sw][w];
+            s.list[w][base + lanes_below(bal[w])] = (unsigned short)(tid * 32);
+        }
+    }
+    const int n = __builtin_amdgcn_readfirstlane(s.cnt4[0][wave] + s.cnt4[1][wave] + s.cnt4[2][wave] + s.cnt4[3][wave]);
+    __syncthreads();
+    if (lane < 4) s.list[wave][n + lane] = (unsigned short)(SENTINEL * 32);  // own list, own wave: program order suffices
+    return n;
+}
+
+__device__ __forceinline__ void load4(const Staged& s, int wave, int k, float4 (&q0)[4], float4 (&q1)[4]) {
+    const uint2 pk = *reinterpret_cast<const uint2*>(&s.list[wave][k]);
+    const unsigned off[4] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
+    const char* base = reinterpret_cast<const char*>(s.rec);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        q0[u] = *reinterpret_cast<const float4*>(base + off[u]);
+        q1[u] = *reinterpret_cast<const float4*>(base + off[u] + 16);
     }
 }
 
-__device__ __forceinline__ unsigned long long uniform_mask(const Staged& s, int sub, int wave) {
-    const unsigned long long m = s.mask[sub][wave];
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)m);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(m >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // ================================================================================ forward
+struct StagedFwd {
+    Staged f;
+    float unc[DGR_TILE_PIX];   // per staged instance: sum of (d - gt)^2 alpha T over its median pixels (forward.cu:386)
+    uint32_t cnt[DGR_TILE_PIX];
+};
+
 __global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArgs a) {
-    __shared__ Staged s;
+    __shared__ StagedFwd sf;
+    Staged& s = sf.f;
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -111,55 +150,68 @@ __global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArg
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f, D_median = 0.f;
     uint32_t last_contributor = 0;
-    bool done = !inside;
+    // "done" as a threshold: alpha never exceeds 0.99, so a finished pixel compares against +inf
+    float thr = inside ? ALPHA_MIN : __builtin_inff();
     const float gt_px = inside ? a.gt_depth[pix_id] : 0.f;
+    if (tid == 0) {
+        s.rec[2 * SENTINEL] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s.rec[2 * SENTINEL + 1] = make_float4(0.f, 0.f, __int_as_float(SENTINEL), 0.f);
+    }
+    bool have_flush = false;
 
     for (int base = 0; base < total; base += DGR_TILE_PIX) {
         // whole tile finished?  (L/cuda_rasterizer/forward.cu:329-332)
-        if (__syncthreads_and(done)) break;
+        if (__syncthreads_and(thr > 1.0f)) break;
+        // median statistics of the previous batch: slot tid is flushed by the thread that restages it
+        if (have_flush && sf.cnt[tid] != 0u) {
+            atomicAdd(&a.gau_uncertainty[s.id[tid]], sf.unc[tid]);
+            atomicAdd(&a.gau_related_pixels[s.id[tid]], (int)sf.cnt[tid]);
+        }
+        sf.unc[tid] = 0.f;
+        sf.cnt[tid] = 0u;
+        have_flush = true;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
         if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0, nullptr);
-        publish_masks(s, code, wave, lane);
-        __syncthreads();
+        const int n = build_lists(s, code, tid, wave, lane);
 
-        if (!__all(done)) {
-            for (int sub = 0; sub * 64 < cnt; sub++) {
-                unsigned long long m = uniform_mask(s, sub, wave);
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int j = sub * 64 + b;
-                    const float2 xy = s.xy[j];
-                    const float4 co = s.con[j];
-                    const float dx = xy.x - pxf, dy = xy.y - pyf;
-                    const float p2 = dx * (co.x * dx + co.y * dy) + co.z * dy * dy;
-                    const float alpha = fminf(0.99f, co.w * __builtin_amdgcn_exp2f(p2));
-                    if (!done && p2 <= 0.0f && alpha >= ALPHA_MIN) {
-                        const float test_T = T * (1.0f - alpha);
-                        if (test_T < 0.0001f) {
-                            done = true;  // this Gaussian is not blended (forward.cu:368-373)
-                        } else {
-                            const float4 cd = s.rgbd[j];
-                            const float w = alpha * T;
-                            C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
-                            weight += w;
-                            Dd += cd.w * w;
-                            if (T > 0.5f && test_T < 0.5f) {  // forward.cu:381-388
-                                D_median = cd.w;
-                                const uint32_t gid = s.id[j];
-                                const float e = cd.w - gt_px;
-                                atomicAdd(&a.gau_uncertainty[gid], e * e * w);
-                                atomicAdd(&a.gau_related_pixels[gid], 1);
-                            }
-                            T = test_T;
-                            last_contributor = (uint32_t)(base + j + 1);
+        for (int k = 0; k < n; k += 4) {
+            float4 q0[4], q1[4];
+            load4(s, wave, k, q0, q1);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
+                const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
+                const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
+                if (p2 <= 0.0f && alpha >= thr) {
+                    const float test_T = T * (1.0f - alpha);
+                    if (test_T < 0.0001f) {
+                        thr = __builtin_inff();  // done; this Gaussian is not blended (forward.cu:368-373)
+                    } else {
+                        const int j = __float_as_int(q1[u].z);
+                        const float4 cd = s.rgbd[j];
+                        const float w = alpha * T;
+                        C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
+                        weight += w;
+                        Dd += cd.w * w;
+                        if (T > 0.5f && test_T < 0.5f) {  // forward.cu:381-388
+                            D_median = cd.w;
+                            const float e = cd.w - gt_px;
+                            atomicAdd(&sf.unc[j], e * e * w);
+                            atomicAdd(&sf.cnt[j], 1u);
                         }
+                        T = test_T;
+                        last_contributor = (uint32_t)(base + j + 1);
                     }
                 }
-                if (__all(done)) break;
             }
+            if (__all(thr > 1.0f)) break;
         }
+    }
+    __syncthreads();
+    if (have_flush && sf.cnt[tid] != 0u) {
+        atomicAdd(&a.gau_uncertainty[s.id[tid]], sf.unc[tid]);
+        atomicAdd(&a.gau_related_pixels[s.id[tid]], (int)sf.cnt[tid]);
     }
 
     if (inside) {
@@ -178,7 +230,7 @@ __global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArg
 // ================================================================================ backward
 // Per-Gaussian gradient sums.  Only ~6 of a wave's 64 pixels are hit by any one Gaussian and LDS float
 // atomics retire barely one lane per cycle on gfx950 (measured: 55 % of wave cycles in SQ_WAIT_INST_LDS
-// with per-lane ds_add_f32), so the sums are formed in registers: every in-mask Gaussian is visited
+// with per-lane ds_add_f32), so the sums are formed in registers: every listed Gaussian is visited
 // wave-uniformly (as in the forward), the valid lanes compute their 14 contributions, and ONE butterfly
 // (wave_reduce.h, 33 instructions) reduces all 14 across the wave at once, leaving each total in its own
 // lane quad.  A single ds_add_f32 with 14 active lanes on 14 distinct banks then merges the four
@@ -214,7 +266,11 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
     const uint2 range = a.ranges[tile];
     const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
 
-    if (tid == 0) sb.max_last = 0;
+    if (tid == 0) {
+        sb.max_last = 0;
+        s.rec[2 * SENTINEL] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s.rec[2 * SENTINEL + 1] = make_float4(0.f, 0.f, __int_as_float(SENTINEL), 0.f);
+    }
     __syncthreads();
     {
         int v = last_contributor;  // wave max, then one LDS atomic per wave
@@ -261,37 +317,32 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
         const int cnt = hi - lo;
         __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
-        if (tid < cnt) {
-            float3 raw;
-            code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, &raw);
-            sb.raw[tid] = make_float4(raw.x, raw.y, raw.z, 0.f);
-        }
+        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, &sb.raw[tid]);
 #pragma unroll
         for (int k = 0; k < NACC; k++) sb.acc[k * ACC_LD + tid] = 0.f;
-        publish_masks(s, code, wave, lane);
-        __syncthreads();
+        const int n = build_lists(s, code, tid, wave, lane);
+        const int rel_last = last_contributor - lo;  // slots below this are at or before the last contributor
 
-        for (int sub = (cnt - 1) >> 6; sub >= 0; sub--) {
-            unsigned long long m = uniform_mask(s, sub, wave);
-            while (m) {
-                const int b = 63 - __builtin_clzll(m);
-                m &= ~(1ull << b);
-                const int j = sub * 64 + b;
-                const float2 xy = s.xy[j];
-                const float4 co = s.con[j];
-                const float dx = xy.x - pxf, dy = xy.y - pyf;
-                const float p2 = dx * (co.x * dx + co.y * dy) + co.z * dy * dy;
+        for (int k = ((n + 3) & ~3) - 4; k >= 0; k -= 4) {
+            float4 q0[4], q1[4];
+            load4(s, wave, k, q0, q1);
+#pragma unroll
+            for (int u = 3; u >= 0; u--) {
+                const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
+                const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
                 const float G = __builtin_amdgcn_exp2f(p2);
-                const float alpha = fminf(0.99f, co.w * G);
-                const bool valid = (lo + j) < last_contributor && p2 <= 0.0f && alpha >= ALPHA_MIN;
+                const float alpha = fminf(0.99f, q1[u].y * G);
+                const int j = __float_as_int(q1[u].z);
+                const bool valid = j < rel_last && p2 <= 0.0f && alpha >= ALPHA_MIN;
                 if (!__any(valid)) continue;
 
                 float g[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) g[k] = 0.f;
+                for (int c = 0; c < 16; c++) g[c] = 0.f;
                 if (valid) {
                     const float4 cd = s.rgbd[j];
                     const float4 rc = sb.raw[j];
+                    const float opac = q1[u].y;
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     T = T * inv;
                     const float w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
@@ -313,7 +364,7 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                     last_alpha = alpha;
                     dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
 
-                    const float dL_dG = co.w * dL_dalpha;
+                    const float dL_dG = opac * dL_dalpha;
                     const float gdx = G * dx, gdy = G * dy;
                     const float dG_ddelx = -gdx * rc.x - gdy * rc.y;
                     const float dG_ddely = -gdy * rc.z - gdx * rc.y;
@@ -352,6 +403,7 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                     float g4[4] = {g[0], g[1], g[2], 0.f};
                     tot = wave_reduce4(g4);
                 }
+                // j is wave-uniform here (every lane read the same record)
                 if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * ACC_LD + j], tot);
             }
         }
