@@ -23,6 +23,7 @@
 // once, i.e. the centre of the reference's own run-to-run spread.
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -479,10 +480,26 @@ void renderForward(State& st, const float* features, const float* bg, const floa
 // ---------------------------------------------------------------- per-Gaussian backward
 // L/cr/backward.cu:20-139
 void shBackward(int idx, int deg, int M, const float* means, V3 campos, const float* shs, const uint8_t* clamped,
-                const float* dL_dcolor, float* dL_dmeans, float* dL_dshs) {
+                const float* dL_dcolor, float* dL_dmeans, float* dL_dshs, float* dgc_dCampos = nullptr) {
     V3 pos = {means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]};
     V3 dir_orig = pos - campos;
     V3 dir = dir_orig / length(dir_orig);
+    // full variant only: d(dir)/d(campos) (F/cr/backward.cu:27-43)
+    float dxdCamx = 0, dydCamx = 0, dzdCamx = 0, dxdCamy = 0, dydCamy = 0, dzdCamy = 0, dxdCamz = 0, dydCamz = 0, dzdCamz = 0;
+    if (dgc_dCampos) {
+        float len_dir_orig3 = length(dir_orig) * length(dir_orig) * length(dir_orig);
+        float one_len_dir_orig3 = 1.0f / len_dir_orig3;
+        float one_len_dir_orig = 1.0f / length(dir_orig);
+        dxdCamx = dir_orig.x * dir_orig.x * one_len_dir_orig3 - one_len_dir_orig;
+        dydCamx = dir_orig.x * dir_orig.y * one_len_dir_orig3;
+        dzdCamx = dir_orig.x * dir_orig.z * one_len_dir_orig3;
+        dxdCamy = dir_orig.x * dir_orig.y * one_len_dir_orig3;
+        dydCamy = dir_orig.y * dir_orig.y * one_len_dir_orig3 - one_len_dir_orig;
+        dzdCamy = dir_orig.y * dir_orig.z * one_len_dir_orig3;
+        dxdCamz = dir_orig.x * dir_orig.z * one_len_dir_orig3;
+        dydCamz = dir_orig.y * dir_orig.z * one_len_dir_orig3;
+        dzdCamz = dir_orig.z * dir_orig.z * one_len_dir_orig3 - one_len_dir_orig;
+    }
     const V3* sh = reinterpret_cast<const V3*>(shs) + (size_t)idx * M;
     V3 dL_dRGB = {dL_dcolor[3 * idx], dL_dcolor[3 * idx + 1], dL_dcolor[3 * idx + 2]};
     dL_dRGB.x *= clamped[3 * idx + 0] ? 0 : 1;
@@ -533,6 +550,12 @@ void shBackward(int idx, int deg, int M, const float* means, V3 campos, const fl
             }
         }
     }
+    if (dgc_dCampos) {  // F/cr/backward.cu:159-166 (not clamp-masked)
+        V3* o = reinterpret_cast<V3*>(dgc_dCampos) + (size_t)idx * 3;
+        o[0] = dRGBdx * dxdCamx + dRGBdy * dydCamx + dRGBdz * dzdCamx;
+        o[1] = dRGBdx * dxdCamy + dRGBdy * dydCamy + dRGBdz * dzdCamy;
+        o[2] = dRGBdx * dxdCamz + dRGBdy * dydCamz + dRGBdz * dzdCamz;
+    }
     V3 dL_ddir = {dot(dRGBdx, dL_dRGB), dot(dRGBdy, dL_dRGB), dot(dRGBdz, dL_dRGB)};
     V3 dL_dmean = dnormvdv(dir_orig, dL_ddir);
     dL_dmeans[3 * idx + 0] += dL_dmean.x;
@@ -541,9 +564,11 @@ void shBackward(int idx, int deg, int M, const float* means, V3 campos, const fl
 }
 
 // L/cr/backward.cu:144-276 (light: accumulates into dL_dmeans)
+// full: dL_dgau_depths != nullptr -> dL_dmeans is ASSIGNED and the depth term added (F/cr/backward.cu:383-386);
+// its dginvcovs_dT output (F:243-312) feeds only ComputePG's part 2-2, which is never summed (dead) and is skipped.
 void cov2DBackwardLight(const State& st, int P, const float* means, const int32_t* radii, const float* cov3Ds,
                         float hx, float hy, float tanx, float tany, const float* view, const float* dL_dconics,
-                        float* dL_dmeans, float* dL_dcov) {
+                        float* dL_dmeans, float* dL_dcov, const float* dL_dgau_depths = nullptr) {
 #pragma omp parallel for schedule(static)
     for (int idx = 0; idx < P; idx++) {
         if (!(radii[idx] > 0)) continue;
@@ -599,9 +624,17 @@ void cov2DBackwardLight(const State& st, int P, const float* means, const int32_
         float dL_dty = y_grad_mul * -hy * tz2 * dL_dJ12;
         float dL_dtz = -hx * tz2 * dL_dJ00 - hy * tz2 * dL_dJ11 + (2 * hx * t.x) * tz3 * dL_dJ02 + (2 * hy * t.y) * tz3 * dL_dJ12;
         V3 dL_dmean = transformVec4x3Transpose({dL_dtx, dL_dty, dL_dtz}, view);
-        dL_dmeans[3 * idx + 0] += dL_dmean.x;
-        dL_dmeans[3 * idx + 1] += dL_dmean.y;
-        dL_dmeans[3 * idx + 2] += dL_dmean.z;
+        if (dL_dgau_depths) {
+            const float dgd = dL_dgau_depths[idx];
+            float mul3 = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14];
+            dL_dmeans[3 * idx + 0] = dL_dmean.x + dgd * (view[2] - view[3] * mul3);
+            dL_dmeans[3 * idx + 1] = dL_dmean.y + dgd * (view[6] - view[7] * mul3);
+            dL_dmeans[3 * idx + 2] = dL_dmean.z + dgd * (view[10] - view[11] * mul3);
+        } else {
+            dL_dmeans[3 * idx + 0] += dL_dmean.x;
+            dL_dmeans[3 * idx + 1] += dL_dmean.y;
+            dL_dmeans[3 * idx + 2] += dL_dmean.z;
+        }
     }
     (void)st;
 }
@@ -639,7 +672,8 @@ void preprocessBackwardLight(int P, int D, int M, const float* means, const int3
                              const uint8_t* clamped, const float* scales, const float* rots, float mod,
                              const float* view, const float* proj, const float* campos, const float* dL_dmean2D,
                              float* dL_dmeans, const float* dL_dcolor, const float* dL_ddepth, const float* dL_dcov3D,
-                             float* dL_dsh, float* dL_dscale, float* dL_drot) {
+                             float* dL_dsh, float* dL_dscale, float* dL_drot, float* dgc_dCampos = nullptr) {
+    // dL_ddepth == nullptr selects the full flavour (F/cr/backward.cu:459-537): no depth->mean term here
     V3 cam = {0, 0, 0};
     if (campos) cam = {campos[0], campos[1], campos[2]};
 #pragma omp parallel for schedule(static)
@@ -658,15 +692,17 @@ void preprocessBackwardLight(int P, int D, int M, const float* means, const int3
         dL_dmeans[3 * idx + 0] += dL_dmean.x;
         dL_dmeans[3 * idx + 1] += dL_dmean.y;
         dL_dmeans[3 * idx + 2] += dL_dmean.z;
-        float mul3 = view[2] * m.x + view[6] * m.y + view[10] * m.z + view[14];
-        V3 d2;
-        d2.x = (view[2] - view[3] * mul3) * dL_ddepth[idx];
-        d2.y = (view[6] - view[7] * mul3) * dL_ddepth[idx];
-        d2.z = (view[10] - view[11] * mul3) * dL_ddepth[idx];
-        dL_dmeans[3 * idx + 0] += d2.x;
-        dL_dmeans[3 * idx + 1] += d2.y;
-        dL_dmeans[3 * idx + 2] += d2.z;
-        if (shs) shBackward(idx, D, M, means, cam, shs, clamped, dL_dcolor, dL_dmeans, dL_dsh);
+        if (dL_ddepth) {
+            float mul3 = view[2] * m.x + view[6] * m.y + view[10] * m.z + view[14];
+            V3 d2;
+            d2.x = (view[2] - view[3] * mul3) * dL_ddepth[idx];
+            d2.y = (view[6] - view[7] * mul3) * dL_ddepth[idx];
+            d2.z = (view[10] - view[11] * mul3) * dL_ddepth[idx];
+            dL_dmeans[3 * idx + 0] += d2.x;
+            dL_dmeans[3 * idx + 1] += d2.y;
+            dL_dmeans[3 * idx + 2] += d2.z;
+        }
+        if (shs) shBackward(idx, D, M, means, cam, shs, clamped, dL_dcolor, dL_dmeans, dL_dsh, dgc_dCampos);
         if (scales)
             cov3DBackward(idx, {scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]}, mod, rots + 4 * (size_t)idx,
                           dL_dcov3D, dL_dscale, dL_drot);
@@ -840,6 +876,233 @@ void renderBackwardLight(const State& st, const float* bg, const float* colors, 
     for (int i = 0; i < 16; i++) dL_dview_sum[i] = vsum[i];
 }
 
+
+// ---------------------------------------------------------------- backward blend + pose gradient, full
+// F/cr/backward.cu:540-836 (renderCUDA) and :838-1338 (ComputePG).  The reference writes 23 words per valid
+// (pixel, Gaussian) pair into NG-sized lists and re-walks every tile to consume them; here each pixel keeps
+// its own pairs in a local vector and ComputePG's per-pixel body runs right after the blend loop -- same
+// values, same order (back to front), same arithmetic:
+//   * only part 1 (colour -> campos -> view) and part 2-1 (ndc -> view) are summed (:1264-1275); part 2-2
+//     (conic -> T -> view, :1076-1243) is computed there but never used, so it is not restated;
+//   * the depth terms dd_dvK are ASSIGNED, not accumulated (:1278-1289): only the last matched pair --
+//     the front-most valid Gaussian of the pixel -- contributes dL_depth * dd_dvK;
+//   * dL_duncertainty never enters the pose gradient; entries 3,7,11,15 are never written.
+// acc[g*10 + {0..2 colour, 3 gau depth, 4..5 mean2D, 6..8 conic, 9 opacity}]
+int g_stale_collected_id[256];  // emulate_dropout only: ComputePG's __shared__ collected_id across blocks
+struct PairRec {
+    uint32_t gid;
+    float dpix_dgc;
+    float dndcs[2][3];
+    float ddepth_dndcs[2];
+};
+void renderBackwardFull(const State& st, const float* bg, const float* colors, const float* dL_dpixels,
+                        const float* dL_depths, const float* dL_duncertainties, const float* gt_depth,
+                        std::vector<double>& acc, const float* means, const float* view, const float* dgc_dCampos_or_null,
+                        bool pose_pass, double* dL_dview_sum, bool emulate_dropout = false) {
+    const int W = st.W, H = st.H;
+    const size_t N = (size_t)W * H;
+    const int tiles = st.gx * st.gy;
+    const float ddelx_dx = 0.5 * W, ddely_dy = 0.5 * H;
+    const float* depths = st.depths.data();
+    double vsum[16] = {0};
+    if (emulate_dropout) std::fill(g_stale_collected_id, g_stale_collected_id + 256, 0);
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : vsum[:16]) if (!emulate_dropout)
+    for (int tile = 0; tile < tiles; tile++) {
+        const uint32_t r0 = st.ranges[2 * tile], r1 = st.ranges[2 * tile + 1];
+        const int tx = tile % st.gx, ty = tile / st.gx;
+        std::vector<PairRec> pairs;
+        std::vector<std::vector<PairRec>> tile_pairs(pose_pass ? 256 : 0);
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
+                const size_t pix_id = (size_t)W * py + px;
+                const float pfx = (float)px, pfy = (float)py;
+                const float T_final = st.final_T[pix_id];
+                float T = T_final;
+                uint32_t contributor = r1 - r0;
+                const int last_contributor = st.n_contrib[pix_id];
+                float dpixel_dalpha[3] = {0, 0, 0}, ddepth_dalpha = 0;
+                float accum_rec[3] = {0, 0, 0}, dL_dpixel[3];
+                for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpixels[i * N + pix_id];
+                const float dL_depth = dL_depths[pix_id];
+                const float dL_duncertainty = dL_duncertainties[pix_id];
+                const float gt_px_depth = gt_depth[pix_id];
+                float accum_depth_rec = 0, accum_uncertainty_rec = 0;
+                float last_alpha = 0, last_color[3] = {0, 0, 0}, last_depth = 0, last_uncertainty = 0;
+                pairs.clear();
+                for (uint32_t k = r1; k-- > r0;) {
+                    contributor--;
+                    if ((int)contributor >= last_contributor) continue;
+                    const uint32_t gid = st.point_list[k];
+                    const float dx = st.means2D[2 * (size_t)gid] - pfx, dy = st.means2D[2 * (size_t)gid + 1] - pfy;
+                    const float* co = &st.conic_opacity[4 * (size_t)gid];
+                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float G = m_exp(power);
+                    const float alpha = std::min(0.99f, co[3] * G);
+                    if (alpha < 15.0f / 255.0f) continue;
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dalpha = 0.0f;
+                    double* a = pose_pass ? nullptr : &acc[(size_t)gid * 10];
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float c = colors[(size_t)gid * 3 + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = c;
+                        const float dL_dchannel = dL_dpixel[ch];
+                        dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
+                        dpixel_dalpha[ch] = T * (c - accum_rec[ch]);
+                        if (a) {
+                            const float v = dchannel_dcolor * dL_dchannel;
+#pragma omp atomic
+                            a[ch] += (double)v;
+                        }
+                    }
+                    const float c_d = depths[gid];
+                    const float c_u = (depths[gid] - gt_px_depth) * (depths[gid] - gt_px_depth);
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    accum_uncertainty_rec = last_alpha * last_uncertainty + (1.f - last_alpha) * accum_uncertainty_rec;
+                    last_depth = c_d;
+                    last_uncertainty = c_u;
+                    dL_dalpha += (c_d - accum_depth_rec) * dL_depth;
+                    dL_dalpha += (c_u - accum_uncertainty_rec) * dL_duncertainty;
+                    if (a) {
+                        const float v = dchannel_dcolor * dL_depth + 2. * (depths[gid] - gt_px_depth) * dchannel_dcolor * dL_duncertainty;
+#pragma omp atomic
+                        a[3] += (double)v;
+                    }
+                    ddepth_dalpha = T * (c_d - accum_depth_rec);
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    float bg_dot_dpixel = 0;
+                    for (int i = 0; i < 3; i++) bg_dot_dpixel += bg[i] * dL_dpixel[i];
+                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    const float dL_dG = co[3] * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                    const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                    if (pose_pass) {
+                        PairRec r;
+                        r.gid = gid;
+                        r.dpix_dgc = dchannel_dcolor;
+                        for (int ch = 0; ch < 3; ch++) {
+                            r.dndcs[0][ch] = (dpixel_dalpha[ch] * co[3] * dG_ddelx * ddelx_dx);
+                            r.dndcs[1][ch] = (dpixel_dalpha[ch] * co[3] * dG_ddely * ddely_dy);
+                        }
+                        r.ddepth_dndcs[0] = ddepth_dalpha * co[3] * dG_ddelx * ddelx_dx;
+                        r.ddepth_dndcs[1] = ddepth_dalpha * co[3] * dG_ddely * ddely_dy;
+                        pairs.push_back(r);
+                    } else {
+                        const float v4 = dL_dG * dG_ddelx * ddelx_dx, v5 = dL_dG * dG_ddely * ddely_dy;
+                        const float v6 = -0.5f * gdx * dx * dL_dG, v7 = -0.5f * gdx * dy * dL_dG;
+                        const float v8 = -0.5f * gdy * dy * dL_dG, v9 = G * dL_dalpha;
+#pragma omp atomic
+                        a[4] += (double)v4;
+#pragma omp atomic
+                        a[5] += (double)v5;
+#pragma omp atomic
+                        a[6] += (double)v6;
+#pragma omp atomic
+                        a[7] += (double)v7;
+#pragma omp atomic
+                        a[8] += (double)v8;
+#pragma omp atomic
+                        a[9] += (double)v9;
+                    }
+                }
+                if (pose_pass) tile_pairs[ly * BLOCK_X + lx] = pairs;
+            }
+        if (!pose_pass) continue;
+        // ---- ComputePG for this tile (F/cr/backward.cu:864-1337).
+        // Well-defined semantics (default): every pixel consumes all of its recorded pairs in order.
+        // emulate_dropout: the reference's threads with no valid contributor (or outside the image) return BEFORE
+        // the block-wide loads (:875-878, 935-938) and never fill collected_id[thread_rank]; the survivors then
+        // compare against whatever that __shared__ slot held.  Under the survey's CPU execution (__shared__ ->
+        // static, blocks run one after another) the slot keeps the value an earlier block left there; that run is
+        // what this flag reproduces.  On a GPU the outcome is undefined.
+        static thread_local std::vector<int> dummy;
+        const int L = (int)(r1 - r0);
+        const int rounds = (L + 255) / 256;
+        std::vector<size_t> vseq(256, 0);
+        std::vector<char> shut(256, 0);
+        std::vector<std::array<V3, 12>> dpv(256);
+        std::vector<std::array<float, 12>> ddv(256);
+        for (int t = 0; t < 256; t++)
+            for (int sidx = 0; sidx < 12; sidx++) { dpv[t][sidx] = {0, 0, 0}; ddv[t][sidx] = 0; }
+        const V3* dgc = reinterpret_cast<const V3*>(dgc_dCampos_or_null);
+        auto consume = [&](int t, const PairRec& r) {
+            const uint32_t g = r.gid;
+            V3 zero = {0, 0, 0};
+            V3 dp_dCx = dgc ? r.dpix_dgc * dgc[(size_t)g * 3 + 0] : zero;
+            V3 dp_dCy = dgc ? r.dpix_dgc * dgc[(size_t)g * 3 + 1] : zero;
+            V3 dp_dCz = dgc ? r.dpix_dgc * dgc[(size_t)g * 3 + 2] : zero;
+            V3 part1[12];
+            part1[0] = dp_dCx * (-view[12]); part1[1] = dp_dCx * (-view[13]); part1[2] = dp_dCx * (-view[14]);
+            part1[3] = dp_dCy * (-view[12]); part1[4] = dp_dCy * (-view[13]); part1[5] = dp_dCy * (-view[14]);
+            part1[6] = dp_dCz * (-view[12]); part1[7] = dp_dCz * (-view[13]); part1[8] = dp_dCz * (-view[14]);
+            part1[9] = dp_dCx * (-view[0]) + dp_dCy * (-view[4]) + dp_dCz * (-view[8]);
+            part1[10] = dp_dCx * (-view[1]) + dp_dCy * (-view[5]) + dp_dCz * (-view[9]);
+            part1[11] = dp_dCx * (-view[2]) + dp_dCy * (-view[6]) + dp_dCz * (-view[10]);
+            const float* J = &st.dgndcs_dview[24 * (size_t)g];
+            const V3 nx = {r.dndcs[0][0], r.dndcs[0][1], r.dndcs[0][2]};
+            const V3 ny = {r.dndcs[1][0], r.dndcs[1][1], r.dndcs[1][2]};
+            const float* mg = means + 3 * (size_t)g;
+            const float wc[4] = {mg[0], mg[1], mg[2], 1.0f};
+            for (int sidx = 0; sidx < 12; sidx++) {
+                const V3 p21 = J[2 * sidx] * nx + J[2 * sidx + 1] * ny;
+                const float d21 = J[2 * sidx] * r.ddepth_dndcs[0] + J[2 * sidx + 1] * r.ddepth_dndcs[1];
+                dpv[t][sidx] = dpv[t][sidx] + (part1[sidx] + p21);
+                const float d1 = (sidx % 3 == 2) ? r.dpix_dgc * wc[sidx / 3] : 0.f;
+                ddv[t][sidx] = d1 + d21;  // assigned (F/cr/backward.cu:1278-1289)
+            }
+        };
+        if (!emulate_dropout) {
+            for (int t = 0; t < 256; t++)
+                for (const PairRec& r : tile_pairs[t]) consume(t, r);
+        } else {
+            int toDo = L;
+            for (int i = 0; i < rounds; i++, toDo -= 256) {
+                for (int t = 0; t < 256; t++) {  // loads by the threads that are still alive
+                    if (tile_pairs[t].empty()) continue;  // returned early: !inside or length == 0
+                    const int progress = i * 256 + t;
+                    if ((uint32_t)(r0 + progress) < r1) g_stale_collected_id[t] = (int)st.point_list[r1 - progress - 1];
+                }
+                for (int t = 0; t < 256; t++) {
+                    if (tile_pairs[t].empty()) continue;
+                    for (int j = 0; j < std::min(256, toDo); j++) {
+                        const int global_id = g_stale_collected_id[j];
+                        if (shut[t] || vseq[t] >= tile_pairs[t].size()) break;
+                        if ((uint32_t)global_id == tile_pairs[t][vseq[t]].gid) {
+                            consume(t, tile_pairs[t][vseq[t]]);
+                            if (vseq[t] == tile_pairs[t].size() - 1) { shut[t] = 1; continue; }
+                            vseq[t]++;
+                        }
+                    }
+                }
+            }
+        }
+        static const int slot2entry[12] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 12, 13, 14};
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const int t = ly * BLOCK_X + lx;
+                if (tile_pairs[t].empty()) continue;
+                const uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                const size_t pix_id = (size_t)W * py + px;
+                float dL_dpixel[3];
+                for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpixels[i * N + pix_id];
+                const float dL_depth = dL_depths[pix_id];
+                for (int sidx = 0; sidx < 12; sidx++) {
+                    const float v = dL_dpixel[0] * dpv[t][sidx].x + dL_dpixel[1] * dpv[t][sidx].y + dL_dpixel[2] * dpv[t][sidx].z +
+                                    dL_depth * ddv[t][sidx];
+                    vsum[slot2entry[sidx]] += (double)v;
+                }
+            }
+    }
+    if (dL_dview_sum)
+        for (int i = 0; i < 16; i++) dL_dview_sum[i] = vsum[i];
+}
+
 }  // namespace
 
 // =================================================================== C entry points
@@ -988,6 +1251,74 @@ void dgro_light_backward(void* sp, int P, int D, int M, const float* background,
                                 viewmatrix, projmatrix, campos, dL_dmean2D, dL_dmean3D, dL_dcolor, dL_ddepth,
                                 dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
     }
+}
+
+
+// Mirror of CudaRasterizer::Rasterizer::forward, full (F/cr/rasterizer.h:40-67, F/cr/rasterizer_impl.cu:349-500).
+// Returns num_rendered (or -1); *num_related receives the total of n_valid_contrib (the second host read there).
+int dgro_full_forward(void* sp, int P, int D, int M, const float* background, int width, int height,
+                      const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                      const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                      const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                      float tan_fovy, int prefiltered, float* out_color, float* out_depth, const float* gt_depth,
+                      float* out_uncertainty, int32_t* radii, int* num_related) {
+    State& st = *static_cast<State*>(sp);
+    if (dgro_preprocess(sp, P, D, M, width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+                        rotations, cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered))
+        return -1;
+    if (radii) std::memcpy(radii, st.radii.data(), sizeof(int32_t) * P);
+    binning(st);
+    const float* feat = colors_precomp ? colors_precomp : st.rgb.data();
+    renderForward<false>(st, feat, background, gt_depth, out_color, out_depth, nullptr, out_uncertainty, nullptr, nullptr,
+                         nullptr);
+    long ng = 0;
+    for (uint32_t v : st.n_valid_contrib) ng += v;
+    if (num_related) *num_related = (int)ng;
+    return st.R;
+}
+
+// Mirror of CudaRasterizer::Rasterizer::backward, full (F/cr/rasterizer.h:69-102, F/cr/rasterizer_impl.cu:504-666):
+// blend backward, computeCov2DCUDA + preprocessCUDA, ComputePG.  Gradient buffers arrive zeroed
+// (F/rasterize_points.cu:161-171); dL_dview16 is the [4,4] the binding returns.
+void dgro_full_backward(void* sp, int P, int D, int M, const float* background, const float* means3D, const float* shs,
+                        const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                        const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                        float tan_fovx, float tan_fovy, const float* dL_dpix, const float* dL_depths, float* dL_dmean2D,
+                        float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                        float* dL_dsh, float* dL_dscale, float* dL_drot, const float* perspec_matrix, float* dL_dview16,
+                        float* dL_dgau_depth, const float* gt_depth, const float* dL_duncertainties, int emulate_dropout) {
+    State& st = *static_cast<State*>(sp);
+    const int W = st.W, H = st.H;
+    const float focal_y = H / (2.0f * tan_fovy);
+    const float focal_x = W / (2.0f * tan_fovx);
+    const int32_t* radii = st.radii.data();
+    const float* color_ptr = colors_precomp ? colors_precomp : st.rgb.data();
+    std::vector<double> acc((size_t)P * 10, 0.0);
+    renderBackwardFull(st, background, color_ptr, dL_dpix, dL_depths, dL_duncertainties, gt_depth, acc, means3D, viewmatrix,
+                       nullptr, false, nullptr);
+    for (int g = 0; g < P; g++) {
+        const double* a = &acc[(size_t)g * 10];
+        for (int c = 0; c < 3; c++) dL_dcolor[3 * (size_t)g + c] += (float)a[c];
+        dL_dgau_depth[g] += (float)a[3];
+        dL_dmean2D[3 * (size_t)g + 0] += (float)a[4];
+        dL_dmean2D[3 * (size_t)g + 1] += (float)a[5];
+        dL_dconic[4 * (size_t)g + 0] += (float)a[6];
+        dL_dconic[4 * (size_t)g + 1] += (float)a[7];
+        dL_dconic[4 * (size_t)g + 3] += (float)a[8];
+        dL_dopacity[g] += (float)a[9];
+    }
+    const float* cov3D_ptr = cov3D_precomp ? cov3D_precomp : st.cov3D.data();
+    cov2DBackwardLight(st, P, means3D, radii, cov3D_ptr, focal_x, focal_y, tan_fovx, tan_fovy, viewmatrix, dL_dconic,
+                       dL_dmean3D, dL_dcov3D, dL_dgau_depth);
+    std::vector<float> dgc((size_t)P * 9, 0.f);
+    preprocessBackwardLight(P, D, M, means3D, radii, shs, st.clamped.data(), scales, rotations, scale_modifier, viewmatrix,
+                            projmatrix, campos, dL_dmean2D, dL_dmean3D, dL_dcolor, nullptr, dL_dcov3D, dL_dsh, dL_dscale,
+                            dL_drot, dgc.data());
+    poseGradientPre(st, P, means3D, radii, projmatrix, perspec_matrix);  // dgndcs_dview, F/cr/backward.cu:516-534
+    double vsum[16];
+    renderBackwardFull(st, background, color_ptr, dL_dpix, dL_depths, dL_duncertainties, gt_depth, acc, means3D, viewmatrix,
+                       dgc.data(), true, vsum, emulate_dropout != 0);
+    for (int i = 0; i < 16; i++) dL_dview16[i] = (float)vsum[i];
 }
 
 }  // extern "C"

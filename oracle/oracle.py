@@ -215,3 +215,52 @@ def light_backward(st, bg, means3D, colors_precomp, scales, rotations, scale_mod
     if per_pixel_pose:
         g["dL_dview_pix"] = pix
     return g
+
+
+# ------------------------------------------------------------------------------------------ full variant
+def full_forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3D_precomp,
+                 viewmatrix, gt_depth, projmatrix, tanfovx, tanfovy, H, W, shs, sh_degree, campos, prefiltered=False):
+    """Argument order of the full `_C.rasterize_gaussians` (F/rasterize_points.h:18-38).  Returns (state, dict)."""
+    (P, M, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+     campos) = _common(means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, viewmatrix,
+                       projmatrix, campos)
+    bg, gt_depth = _f(bg), _f(gt_depth)
+    st = OracleState(W, H)
+    out = dict(color=np.zeros((3, H, W), np.float32), depth=np.zeros((1, H, W), np.float32),
+               uncertainty=np.zeros((1, H, W), np.float32), radii=np.zeros(P, np.int32))
+    R, ng = 0, C.c_int(0)
+    if P:
+        R = st._l.dgro_full_forward(
+            st._h, P, sh_degree, M, _p(bg), W, H, _p(means3D), _p(shs), _p(colors_precomp), _p(opacities),
+            _p(scales), C.c_float(scale_modifier), _p(rotations), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix),
+            _p(campos), C.c_float(tanfovx), C.c_float(tanfovy), int(prefiltered), _p(out["color"]), _p(out["depth"]),
+            _p(gt_depth), _p(out["uncertainty"]), _p(out["radii"]), C.byref(ng))
+        if R < 0:
+            raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    out["num_rendered"] = R
+    out["num_related"] = ng.value
+    return st, out
+
+
+def full_backward(st, bg, means3D, colors_precomp, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                  gt_depth, projmatrix, tanfovx, tanfovy, dL_dcolor, dL_ddepth, dL_duncertainty, shs, sh_degree, campos,
+                  perspec_matrix, emulate_dropout=False):
+    """Argument meaning of the full `_C.rasterize_gaussians_backward` (F/rasterize_points.h:40-67)."""
+    (P, M, means3D, shs, colors_precomp, _, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+     campos) = _common(means3D, shs, colors_precomp, None, scales, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                       campos)
+    g = dict(dL_dmeans2D=np.zeros((P, 3), np.float32), dL_dcolors=np.zeros((P, 3), np.float32),
+             dL_dgau_depths=np.zeros((P, 1), np.float32), dL_dconic=np.zeros((P, 2, 2), np.float32),
+             dL_dopacity=np.zeros((P, 1), np.float32), dL_dmeans3D=np.zeros((P, 3), np.float32),
+             dL_dcov3D=np.zeros((P, 6), np.float32), dL_dsh=np.zeros((P, M, 3), np.float32),
+             dL_dscales=np.zeros((P, 3), np.float32), dL_drotations=np.zeros((P, 4), np.float32),
+             dL_dview=np.zeros((4, 4), np.float32))
+    if P:
+        st._l.dgro_full_backward(
+            st._h, P, sh_degree, M, _p(_f(bg)), _p(means3D), _p(shs), _p(colors_precomp), _p(scales),
+            C.c_float(scale_modifier), _p(rotations), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos),
+            C.c_float(tanfovx), C.c_float(tanfovy), _p(_f(dL_dcolor)), _p(_f(dL_ddepth)), _p(g["dL_dmeans2D"]),
+            _p(g["dL_dconic"]), _p(g["dL_dopacity"]), _p(g["dL_dcolors"]), _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]),
+            _p(g["dL_dsh"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]), _p(_f(perspec_matrix)), _p(g["dL_dview"]),
+            _p(g["dL_dgau_depths"]), _p(_f(gt_depth)), _p(_f(dL_duncertainty)), int(emulate_dropout))
+    return g

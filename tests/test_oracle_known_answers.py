@@ -90,3 +90,61 @@ def test_float_math_build_agrees_with_cmath_build(oracle):
     for k in ("color", "depth", "opacity_map", "depth_median"):
         assert np.abs(out_c[k] - out_f[k]).max() <= 1e-5, k
     np.testing.assert_allclose(g_f["dL_dview"], g_c["dL_dview"], rtol=1e-4, atol=1e-6)
+
+
+# ---- full variant (NG column and the "Full dL_dview" block, gU := gV)
+KNOWN_FULL = {
+    (10000, 256, 256, 0): dict(NG=472252, dview=[+2.444670e-02, +1.515201e-01, -4.218012e-02, 0, -3.048362e-02, -4.470351e-02,
+                                                -6.645557e-03, 0, +1.255521e-01, +1.000811e-01, +9.958681e-03, 0,
+                                                +4.999591e-02, +6.168350e-02, +7.114520e-03, 0]),
+    (100000, 640, 480, 3): dict(NG=4602988, dview=[-1.162237e-02, +3.704931e-02, -3.354471e-02, 0, -2.120929e-02, +3.775639e-02,
+                                                  +7.021485e-04, 0, +2.316311e-01, +1.868812e-02, -4.177905e-02, 0,
+                                                  +1.500740e-01, +2.374977e-03, -4.642588e-02, 0]),
+}
+
+
+def run_full(O, s, deg, **kw):
+    st, out = O.full_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj, s.tanfovx,
+                             s.tanfovy, s.H, s.W, s.shs, deg, s.campos)
+    g = O.full_backward(st, s.bg, s.means, None, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj, s.tanfovx, s.tanfovy,
+                        s.gC, s.gD, s.gV, s.shs, deg, s.campos, s.persp, **kw)
+    return st, out, g
+
+
+@pytest.mark.parametrize("cfg", list(KNOWN_FULL))
+def test_appendix_c_full_variant(oracle, cfg):
+    """The survey's full-variant numbers come from a run in which ComputePG's early-returning threads (pixels
+    without a valid contributor, F/cr/backward.cu:875-878,935-938) left their __shared__ slot stale -- undefined
+    behaviour that its CPU execution resolved deterministically.  `emulate_dropout` restates exactly that, and
+    only with it do the survey's digits come out on the sparse config 1; the survey's own matrix was summed by
+    concurrent float atomics, so its last 1-2 digits are noise (Appendix C)."""
+    P, W, H, deg = cfg
+    k = KNOWN_FULL[cfg]
+    s = make_scene(P, W, H, 0)
+    oracle.use_cmath(True)
+    try:
+        st, out, g = run_full(oracle, s, deg, emulate_dropout=True)
+        _, _, g_defined = run_full(oracle, s, deg)
+    finally:
+        oracle.use_cmath(False)
+    assert out["num_rendered"] == KNOWN[cfg]["R"] and out["num_related"] == k["NG"]
+    assert sha16(out["radii"]) == KNOWN[cfg]["radii_sha"]
+    ref = np.array(k["dview"])
+    scale = np.abs(ref).max()
+    assert np.abs(g["dL_dview"].reshape(-1) - ref).max() <= 2e-5 * scale
+    # the well-defined semantics (every recorded pair consumed) differ from that run only through the artifact
+    d = np.abs(g_defined["dL_dview"].reshape(-1) - ref).max() / scale
+    assert d <= (0.2 if cfg[0] == 10000 else 2e-5)
+    assert not g_defined["dL_dview"].reshape(-1)[[3, 7, 11, 15]].any()
+
+
+def test_full_forward_outputs_differ_from_light_only_as_documented(oracle):
+    """full blends the terminating Gaussian before stopping (F/cr/forward.cu:370-381), light drops it (L:368-373)."""
+    s = make_scene(10000, 256, 256, 0)
+    _, lo = oracle.light_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj, s.tanfovx,
+                                 s.tanfovy, s.H, s.W, s.shs, 0, s.campos)
+    _, fo = oracle.full_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj, s.tanfovx,
+                                s.tanfovy, s.H, s.W, s.shs, 0, s.campos)
+    assert np.array_equal(lo["radii"], fo["radii"]) and lo["num_rendered"] == fo["num_rendered"]
+    assert np.all(fo["uncertainty"] >= lo["opacity_map"] - 1e-6)   # silhouette can only gain the dropped Gaussian
+    assert np.mean(fo["uncertainty"] != lo["opacity_map"]) < 0.05
