@@ -84,9 +84,9 @@ int zero_outputs(const FwdCommon& c, hipStream_t st) {
     const size_t N = (size_t)c.W * c.H;
     HIP_TRY(hipMemsetAsync(c.out_color, 0, 3 * N * 4, st));
     HIP_TRY(hipMemsetAsync(c.out_depth, 0, N * 4, st));
-    HIP_TRY(hipMemsetAsync(c.out_median_depth, 0, N * 4, st));
-    HIP_TRY(hipMemsetAsync(c.out_alpha, 0, N * 4, st));
-    HIP_TRY(hipMemsetAsync(c.out_depth_var, 0, N * 4, st));
+    if (c.out_median_depth) HIP_TRY(hipMemsetAsync(c.out_median_depth, 0, N * 4, st));
+    if (c.out_alpha) HIP_TRY(hipMemsetAsync(c.out_alpha, 0, N * 4, st));
+    if (c.out_depth_var) HIP_TRY(hipMemsetAsync(c.out_depth_var, 0, N * 4, st));
     return DGR_OK;
 }
 
@@ -95,8 +95,8 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
     // status, tile_count and tile_fill are adjacent: one memset
     HIP_TRY(hipMemsetAsync(img.status, 0, (char*)img.ranges - (char*)img.status, st));
-    HIP_TRY(hipMemsetAsync(c.gau_uncertainty, 0, (size_t)c.P * 4, st));
-    HIP_TRY(hipMemsetAsync(c.gau_related_pixels, 0, (size_t)c.P * 4, st));
+    if (c.gau_uncertainty) HIP_TRY(hipMemsetAsync(c.gau_uncertainty, 0, (size_t)c.P * 4, st));
+    if (c.gau_related_pixels) HIP_TRY(hipMemsetAsync(c.gau_related_pixels, 0, (size_t)c.P * 4, st));
     dgr::PreprocessFwdArgs a{};
     a.P = c.P; a.D = c.D; a.M = c.M; a.W = c.W; a.H = c.H; a.grid_x = gx; a.grid_y = gy;
     a.means3D = c.means3D; a.scales = c.scales; a.scale_modifier = c.scale_modifier; a.rotations = c.rotations;
@@ -127,6 +127,24 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
     r.out_depth_var = c.out_depth_var; r.n_contrib = img.n_contrib; r.gau_uncertainty = c.gau_uncertainty;
     r.gau_related_pixels = c.gau_related_pixels;
     { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_light(r, st)); }
+    return DGR_OK;
+}
+
+// ---- full variant: same front end, different blend
+int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryView geom, dgr::ImageView img,
+                      dgr::BinningView bin, bool have_instances, hipStream_t st) {
+    const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
+    if (have_instances) {
+        { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
+        { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
+    }
+    dgr::RenderFwdFullArgs r{};
+    r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
+    r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background;
+    r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_uncertainty = out_uncertainty;
+    r.n_contrib = img.n_contrib; r.n_valid = img.n_valid; r.first_contrib = img.first_contrib; r.final_T = img.final_T;
+    r.status = img.status;
+    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_full(r, st)); }
     return DGR_OK;
 }
 
@@ -317,6 +335,129 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     return DGR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ full variant
+int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning_buffer, int binning_capacity,
+                              char* image_buffer, int* status, int P, int D, int M, const float* background, int width,
+                              int height, const float* means3D, const float* shs, const float* colors_precomp,
+                              const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                              const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                              const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                              float* out_depth, const float* gt_depth, float* out_uncertainty, int* radii) {
+    hipStream_t st = (hipStream_t)stream;
+    FwdCommon c{P, D, M, width, height, background, means3D, shs, colors_precomp, opacities, scales, rotations,
+                cov3D_precomp, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+                out_color, out_depth, nullptr, out_uncertainty, gt_depth, nullptr, nullptr, nullptr, radii};
+    int rc = check_common(c);
+    if (rc) return rc;
+    if (P == 0) {
+        if (status) HIP_TRY(hipMemsetAsync(status, 0, 16, st));
+        return zero_outputs(c, st);
+    }
+    dgr::GeometryView geom = dgr::carve_geometry(geometry_buffer, P);
+    dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
+    dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
+    if ((rc = forward_front(c, geom, img, binning_capacity, st))) return rc;
+    if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, binning_capacity > 0, st))) return rc;
+    if (status) HIP_TRY(hipMemcpyAsync(status, img.status, 16, hipMemcpyDeviceToDevice, st));
+    return DGR_OK;
+}
+
+int dgr_full_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn binningBuffer, dgr_alloc_fn imageBuffer,
+                     void* alloc_user, int P, int D, int M, const float* background, int width, int height,
+                     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                     float tan_fovy, int prefiltered, float* out_color, float* out_depth, const float* gt_depth,
+                     float* out_uncertainty, int* radii, int* num_related_primitives) {
+    hipStream_t st = (hipStream_t)stream;
+    FwdCommon c{P, D, M, width, height, background, means3D, shs, colors_precomp, opacities, scales, rotations,
+                cov3D_precomp, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
+                out_color, out_depth, nullptr, out_uncertainty, gt_depth, nullptr, nullptr, nullptr, radii};
+    if (num_related_primitives) *num_related_primitives = 0;
+    int rc = check_common(c);
+    if (rc) return rc;
+    if (P == 0) return zero_outputs(c, st);
+    char* gptr = geometryBuffer(dgr_geometry_bytes(P), alloc_user);
+    char* iptr = imageBuffer(dgr_image_bytes(width, height), alloc_user);
+    if (!gptr || !iptr) { g_last_error = "allocation callback returned NULL"; return DGR_ERR_ALLOC; }
+    dgr::GeometryView geom = dgr::carve_geometry(gptr, P);
+    dgr::ImageView img = dgr::carve_image(iptr, width, height);
+    if ((rc = forward_front(c, geom, img, INT_MAX, st))) return rc;
+    int status[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(status, img.status, sizeof(status), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));  // first blocking read of the reference (F/cuda_rasterizer/rasterizer_impl.cu:435)
+    if (status[2]) { g_last_error = "Point is filtered although prefiltered is set. This shouldn't happen!"; return DGR_ERR_PREFILTERED; }
+    const int R = status[0];
+    char* bptr = nullptr;
+    if (R > 0) {
+        bptr = binningBuffer(dgr_binning_bytes(R, width, height), alloc_user);
+        if (!bptr) { g_last_error = "allocation callback returned NULL"; return DGR_ERR_ALLOC; }
+    } else {
+        binningBuffer(0, alloc_user);
+    }
+    dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
+    if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, R > 0, st))) return rc;
+    if (num_related_primitives) {  // second blocking read of the reference (:498)
+        HIP_TRY(hipMemcpyAsync(status, img.status, sizeof(status), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *num_related_primitives = status[3];
+    }
+    return R;
+}
+
+int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,
+                      const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                      const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                      char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                      const float* dL_depths, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                      float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                      float* dpixel_dgc, int* gau_id_list, int* pix_id_list, float* dgc_dCam_position, float* dpixel_dndcs,
+                      const float* perspec_matrix, float* dgndcs_dviewmatrix, float* dpixel_dinvcovs,
+                      float* dgc_invcovs_dT, float* dL_dview, float* dL_dgau_depth, float* ddepth_dndcs,
+                      float* ddepth_dinvcovs, const float* gt_depth, const float* dL_duncertainties, char* scratch,
+                      size_t scratch_bytes) {
+    (void)R; (void)colors_precomp; (void)dpixel_dgc; (void)gau_id_list; (void)pix_id_list; (void)dgc_dCam_position;
+    (void)dpixel_dndcs; (void)dgndcs_dviewmatrix; (void)dpixel_dinvcovs; (void)dgc_invcovs_dT; (void)ddepth_dndcs;
+    (void)ddepth_dinvcovs;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
+    if (P == 0) {
+        HIP_TRY(hipMemsetAsync(dL_dview, 0, 16 * 4, st));
+        return DGR_OK;
+    }
+    if (scratch_bytes < dgr_light_backward_scratch_bytes(P, width, height) || !scratch) {
+        g_last_error = "backward scratch too small";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    dgr::GeometryView geom = dgr::carve_geometry(geom_buffer, P);
+    dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
+    dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
+    const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
+    { ScopedStage t(ST_ZERO, st); HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
+
+    dgr::RenderBwdFullArgs r{};
+    r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
+    r.ranges = img.ranges; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
+    r.gt_depth = gt_depth; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.first_contrib = img.first_contrib;
+    r.dL_dpix = dL_dpix; r.dL_depths = dL_depths; r.dL_duncertainties = dL_duncertainties; r.acc = sc.acc;
+    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_full(r, st)); }
+
+    dgr::PreprocessBwdArgs b{};
+    b.P = P; b.D = D; b.M = M; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs; b.scales = scales;
+    b.rotations = rotations; b.scale_modifier = scale_modifier; b.cov3D_precomp = cov3D_precomp; b.view = viewmatrix;
+    b.proj = projmatrix; b.campos = campos; b.perspec = perspec_matrix; b.tan_fovx = tan_fovx; b.tan_fovy = tan_fovy;
+    b.focal_y = height / (2.0f * tan_fovy);
+    b.focal_x = width / (2.0f * tan_fovx);
+    b.sh_vec_ok = aligned16(shs) && aligned16(dL_dsh);
+    b.track_off = 0; b.map_off = 0; b.full_variant = 1; b.geom = geom; b.acc = sc.acc;
+    b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor;
+    b.dL_ddepth = dL_dgau_depth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
+    b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part;
+    { ScopedStage t(ST_PRE_BWD, st); HIP_TRY(dgr::launch_preprocess_bwd(b, dL_dview, st)); }
+    return DGR_OK;
+}
+
 int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4) {
     HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out4, comp16, comp4, (hipStream_t)stream));
     return DGR_OK;
@@ -390,6 +531,8 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
     }
     if (n == "ranges") return copy(img.ranges, 8 * tiles) ? -1 : (long)(2 * tiles);
     if (n == "n_contrib") return copy(img.n_contrib, 4 * N) ? -1 : (long)N;
+    if (n == "n_valid") return copy(img.n_valid, 4 * N) ? -1 : (long)N;
+    if (n == "final_T") return copy(img.final_T, 4 * N) ? -1 : (long)N;
     g_last_error = "unknown state array: " + n;
     return -1;
 }

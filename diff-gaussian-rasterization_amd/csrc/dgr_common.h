@@ -53,7 +53,8 @@ struct ImageView {
     uint2* ranges;        // [tiles] {start, end} into point_list
     uint32_t* n_contrib;  // [N]
     float* final_T;       // [N]   (full variant)
-    uint32_t* n_valid;    // [N]   (full variant)
+    uint32_t* n_valid;    // [N]   (full variant) valid contributors of the pixel
+    uint32_t* first_contrib;  // [N] (full variant) 1-based list position of the pixel's first valid contributor, 0 = none
     size_t bytes;
 };
 __host__ __device__ inline int tiles_x(int W) { return (W + DGR_BLOCK_X - 1) / DGR_BLOCK_X; }
@@ -69,6 +70,7 @@ __host__ __device__ inline ImageView carve_image(char* base, int W, int H) {
     v.n_contrib = (uint32_t*)(base + o);  o = align_up(o + N * 4, 256);
     v.final_T = (float*)(base + o);       o = align_up(o + N * 4, 256);
     v.n_valid = (uint32_t*)(base + o);    o = align_up(o + N * 4, 256);
+    v.first_contrib = (uint32_t*)(base + o); o = align_up(o + N * 4, 256);
     v.bytes = o;
     return v;
 }
@@ -94,6 +96,10 @@ __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
 //  [0..2] dL/dcolour  [3] dL/ddepth (blend + variance terms)  [4..5] dL/dmean2D
 //  [6..8] dL/dconic (xx, xy, yy)  [9] dL/dopacity  [10..12] median-depth term of dL/dmean3D
 //  [13] sum of the blend-only depth term (pose gradient)  [14..15] unused
+// full variant: [0..9] as above ([3] = dL/dgau_depth incl. the uncertainty term), then the sums its pose gradient
+// (ComputePG, F/cuda_rasterizer/backward.cu:838-1338) is linear in:
+//  [10..11] colour-only dL/d(ndc x, y)   [12] dL_depth * alpha T of the pixels whose FRONT-MOST valid Gaussian this is
+//  [13..14] dL_depth * d(depth)/d(ndc x, y) of those same pixels   [15] unused
 #define DGR_ACC_STRIDE 16
 struct BackwardScratch {
     float* acc;         // [P * 16]

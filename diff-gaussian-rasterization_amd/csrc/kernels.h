@@ -42,6 +42,8 @@ struct PreprocessBwdArgs {
     float tan_fovx, tan_fovy, focal_x, focal_y;
     bool sh_vec_ok;
     int track_off, map_off;
+    int full_variant;   // 1: semantics of F/cuda_rasterizer/backward.cu (computeCov2DCUDA assigns + depth term, pose from
+                        //    dgc_dCampos / colour-only ndc sums / front-most depth sums); 0: light
     GeometryView geom;
     const float* acc;   // [P,16] sums written by the blend backward
     float* dL_dmean2D;  // [P,3]
@@ -93,6 +95,38 @@ struct RenderBwdLightArgs {
     int track_off, map_off;
 };
 
+struct RenderFwdFullArgs {
+    int W, H, grid_x, grid_y;
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float4* rec;
+    const float* bg;
+    float* out_color;
+    float* out_depth;
+    float* out_uncertainty;
+    uint32_t* n_contrib;
+    uint32_t* n_valid;
+    uint32_t* first_contrib;
+    float* final_T;
+    int* status;  // status[3] += sum of n_valid (num_related_primitives)
+};
+
+struct RenderBwdFullArgs {
+    int W, H, grid_x, grid_y;
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float4* rec;
+    const float* bg;
+    const float* gt_depth;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const uint32_t* first_contrib;
+    const float* dL_dpix;
+    const float* dL_depths;
+    const float* dL_duncertainties;
+    float* acc;  // [P,16]
+};
+
 // ---- launchers (each enqueues on `stream` and returns the hipError_t of the launch) ----
 hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream);
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hipStream_t stream);
@@ -105,6 +139,8 @@ hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStrea
 
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream);
 hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stream);
+hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, hipStream_t stream);
+hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, hipStream_t stream);
 hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, hipStream_t stream);
 
 }  // namespace dgr

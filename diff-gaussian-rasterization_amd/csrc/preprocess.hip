@@ -307,7 +307,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
             *o = make_float4(acc[6], acc[7], 0.0f, acc[8]);
         }
 
-        float3 dmean = make_float3(acc[10], acc[11], acc[12]);
+        const bool full = a.full_variant != 0;
+        // light: the blend kernel's median-depth term; full: computeCov2DCUDA ASSIGNS (F/cuda_rasterizer/backward.cu:383)
+        float3 dmean = full ? make_float3(0.f, 0.f, 0.f) : make_float3(acc[10], acc[11], acc[12]);
+        float3 s_cam = make_float3(0.f, 0.f, 0.f);  // full: sum_ch dL_dcolor[ch] * d(rgb[ch])/d(campos.{x,y,z})
         float dcov[6] = {0, 0, 0, 0, 0, 0};
         float3 dscale = make_float3(0, 0, 0);
         float4 drot = make_float4(0, 0, 0, 0);
@@ -369,6 +372,12 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
             dmean.x += v[0] * dL_dtx + v[1] * dL_dty + v[2] * dL_dtz;
             dmean.y += v[4] * dL_dtx + v[5] * dL_dty + v[6] * dL_dtz;
             dmean.z += v[8] * dL_dtx + v[9] * dL_dty + v[10] * dL_dtz;
+            if (full) {  // depth -> mean term inside computeCov2DCUDA (F/cuda_rasterizer/backward.cu:385-386)
+                const float mul3f = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
+                dmean.x = dmean.x + acc[3] * (v[2] - v[3] * mul3f);
+                dmean.y = dmean.y + acc[3] * (v[6] - v[7] * mul3f);
+                dmean.z = dmean.z + acc[3] * (v[10] - v[11] * mul3f);
+            }
 
             // ---------------- preprocessCUDA (L/cuda_rasterizer/backward.cu:348-416)
             const float* pj = a.proj;
@@ -382,12 +391,14 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
             d1.y = (pj[4] * m_w - pj[7] * mul1) * g2x + (pj[5] * m_w - pj[7] * mul2) * g2y;
             d1.z = (pj[8] * m_w - pj[11] * mul1) * g2x + (pj[9] * m_w - pj[11] * mul2) * g2y;
             dmean.x += d1.x; dmean.y += d1.y; dmean.z += d1.z;
-            const float mul3 = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
-            float3 d2;
-            d2.x = (v[2] - v[3] * mul3) * acc[3];
-            d2.y = (v[6] - v[7] * mul3) * acc[3];
-            d2.z = (v[10] - v[11] * mul3) * acc[3];
-            dmean.x += d2.x; dmean.y += d2.y; dmean.z += d2.z;
+            if (!full) {  // light: depth -> mean term inside preprocessCUDA (L/cuda_rasterizer/backward.cu:396-407)
+                const float mul3 = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
+                float3 d2;
+                d2.x = (v[2] - v[3] * mul3) * acc[3];
+                d2.y = (v[6] - v[7] * mul3) * acc[3];
+                d2.z = (v[10] - v[11] * mul3) * acc[3];
+                dmean.x += d2.x; dmean.y += d2.y; dmean.z += d2.z;
+            }
         }
 
         // ---------------- SH backward (L/cuda_rasterizer/backward.cu:20-139); writes the dense dL_dsh row
@@ -448,6 +459,18 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
                                                SH_C3[5] * s.c[14] * (xx - yy));
                         }
                     }
+                }
+                if (full) {
+                    // dgc_dCampos (F/cuda_rasterizer/backward.cu:27-43,159-166; not clamp-masked) contracted with the
+                    // raw colour gradient: all ComputePG's part 1 needs of this Gaussian (:990-1022, 1313-1324)
+                    const float len3 = len * len * len;
+                    const float i3 = 1.0f / len3, i1 = 1.0f / len;
+                    const float3 o = dir_orig;
+                    const float3 raw = make_float3(acc[0], acc[1], acc[2]);
+                    const float3 cx = dRGBdx * (o.x * o.x * i3 - i1) + dRGBdy * (o.x * o.y * i3) + dRGBdz * (o.x * o.z * i3);
+                    const float3 cy = dRGBdx * (o.x * o.y * i3) + dRGBdy * (o.y * o.y * i3 - i1) + dRGBdz * (o.y * o.z * i3);
+                    const float3 cz = dRGBdx * (o.x * o.z * i3) + dRGBdy * (o.y * o.z * i3) + dRGBdz * (o.z * o.z * i3 - i1);
+                    s_cam = make_float3(dot3(raw, cx), dot3(raw, cy), dot3(raw, cz));
                 }
                 const float3 dL_ddir = make_float3(dot3(dRGBdx, dRGB), dot3(dRGBdy, dRGB), dot3(dRGBdz, dRGB));
                 // dnormvdv (cuda_rasterizer/auxiliary.h:109-119)
@@ -531,13 +554,38 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         if (vis && !a.track_off) {
             const float4 m_hom = xform4x4(m, a.proj);
             const float m_w = 1.0f / (m_hom.w + 0.0000001f);
-            const float A = acc[4], B = acc[5], Dd = acc[13];
             const float mm[4] = {m.x, m.y, m.z, 1.0f};
+            if (!full) {
+                const float A = acc[4], B = acc[5], Dd = acc[13];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                pose[3 * k + 0] = (m_w * a.perspec[0] * mm[k]) * A;
-                pose[3 * k + 1] = (m_w * a.perspec[5] * mm[k]) * B;
-                pose[3 * k + 2] = (m_hom.x * (-m_w * m_w) * mm[k]) * A + (m_hom.y * (-m_w * m_w) * mm[k]) * B + mm[k] * Dd;
+                for (int k = 0; k < 4; k++) {
+                    pose[3 * k + 0] = (m_w * a.perspec[0] * mm[k]) * A;
+                    pose[3 * k + 1] = (m_w * a.perspec[5] * mm[k]) * B;
+                    pose[3 * k + 2] = (m_hom.x * (-m_w * m_w) * mm[k]) * A + (m_hom.y * (-m_w * m_w) * mm[k]) * B + mm[k] * Dd;
+                }
+            } else {
+                // ComputePG (F/cuda_rasterizer/backward.cu:990-1072, 1247-1289, 1313-1324) summed per Gaussian:
+                // part 1 (colour -> campos -> view) + part 2-1 (ndc -> view, colour terms) + the depth terms of the
+                // pixels whose front-most valid Gaussian this is.
+                const float A = acc[10], B = acc[11], Dw = acc[12], Dx = acc[13], Dy = acc[14];
+                const float* v = a.view;
+                const float sc[3] = {s_cam.x, s_cam.y, s_cam.z};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float jx0 = m_w * a.perspec[0] * mm[k], jy1 = m_w * a.perspec[5] * mm[k];
+                    const float jx2 = m_hom.x * (-m_w * m_w) * mm[k], jy2 = m_hom.y * (-m_w * m_w) * mm[k];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        float p1;
+                        if (k < 3) p1 = sc[k] * (-v[12 + j]);
+                        else p1 = sc[0] * (-v[j]) + sc[1] * (-v[4 + j]) + sc[2] * (-v[8 + j]);
+                        float p21, dpt;
+                        if (j == 0) { p21 = jx0 * A; dpt = jx0 * Dx; }
+                        else if (j == 1) { p21 = jy1 * B; dpt = jy1 * Dy; }
+                        else { p21 = jx2 * A + jy2 * B; dpt = mm[k] * Dw + (jx2 * Dx + jy2 * Dy); }
+                        pose[3 * k + j] = (p1 + p21) + dpt;
+                    }
+                }
             }
         }
     }

@@ -1,0 +1,121 @@
+// render_common.h -- staging and traversal helpers shared by the light and full blend kernels (gfx950).
+// See the header comment of render_light.hip for the design (per-wave compacted record lists, quadrant culling).
+#pragma once
+#include "dgr_common.h"
+#include "kernels.h"
+#include "wave_reduce.h"
+
+namespace dgr {
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float ALPHA_MIN = 15.0f / 255.0f;  // forward.cu:365
+constexpr int SENTINEL = DGR_TILE_PIX;       // record slot that can never contribute (opacity 0)
+constexpr int LIST_LD = DGR_TILE_PIX + 8;    // list row: 256 entries + sentinel padding, 8-byte aligned rows
+
+// bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of tiles
+__device__ __forceinline__ int xcd_tile(int b, int n) {
+    const int xcd = b & 7, local = b >> 3;
+    const int q = n >> 3, r = n & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+struct Staged {
+    float4 rec[2 * (DGR_TILE_PIX + 1)];  // [2*slot] = {x, y, a2, b2}, [2*slot+1] = {c2, opacity, slot (int bits), 0}
+                                         //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power
+    float4 rgbd[DGR_TILE_PIX];           // {r, g, b, depth}
+    uint32_t id[DGR_TILE_PIX];
+    unsigned short list[4][LIST_LD];     // per consumer wave: byte offsets (slot * 32) into rec, tile-list order
+    int cnt4[4][4];                      // [staging wave][consumer wave] entries contributed
+};
+
+// Stage one instance and return the 4-bit "may touch quadrant" code.
+__device__ __forceinline__ unsigned stage_one(Staged& s, int slot, uint32_t gid, const float4* __restrict__ rec,
+                                              float tile_x0, float tile_y0, float4* raw_conic) {
+    const float4 q0 = rec[3 * (size_t)gid + 0];
+    const float4 q1 = rec[3 * (size_t)gid + 1];
+    const float4 q2 = rec[3 * (size_t)gid + 2];
+    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -LOG2E * q1.y);
+    s.rec[2 * slot + 1] = make_float4(-0.5f * LOG2E * q1.z, q0.w, __int_as_float(slot), 0.f);
+    s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
+    s.id[slot] = gid;
+    if (raw_conic) *raw_conic = make_float4(q1.x, q1.y, q1.z, 0.f);
+    // alpha >= 15/255  <=>  a dx^2 + 2 b dx dy + c dy^2 <= tau = 2 ln(255 o / 15)
+    const float o = q0.w;
+    const float tau = 2.0f * __logf(o * (255.0f / 15.0f));
+    const float det = q1.x * q1.z - q1.y * q1.y;
+    float hx, hy;
+    if (!(tau > 0.0f)) {
+        return 0u;  // opacity below 15/255: can never contribute
+    } else if (det > 0.0f && q1.x > 0.0f && q1.z > 0.0f) {
+        const float k = tau / det;
+        hx = sqrtf(k * q1.z) * 1.001f + 0.05f;
+        hy = sqrtf(k * q1.x) * 1.001f + 0.05f;
+    } else {
+        return 0xFu;  // degenerate conic: do not cull
+    }
+    const float lx = q0.x - hx - tile_x0, rx = q0.x + hx - tile_x0;  // bbox relative to the tile origin
+    const float ly = q0.y - hy - tile_y0, ry = q0.y + hy - tile_y0;
+    const bool xl = (rx >= 0.0f) && (lx <= 7.0f), xr = (rx >= 8.0f) && (lx <= 15.0f);
+    const bool yt = (ry >= 0.0f) && (ly <= 7.0f), yb = (ry >= 8.0f) && (ly <= 15.0f);
+    return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
+}
+
+__device__ __forceinline__ int lanes_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+// Builds the four per-consumer lists from the staging threads' quadrant codes.  Contains two barriers;
+// returns the (uniform) length of the calling wave's list, padded to a multiple of 4 with sentinels.
+__device__ __forceinline__ int build_lists(Staged& s, unsigned code, int tid, int wave, int lane) {
+    unsigned long long bal[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        bal[w] = __ballot((code >> w) & 1u);
+        if (lane == 0) s.cnt4[wave][w] = __popcll(bal[w]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if ((code >> w) & 1u) {
+            int base = 0;
+            for (int sw = 0; sw < wave; sw++) base += s.cnt4[sw][w];
+            s.list[w][base + lanes_below(bal[w])] = (unsigned short)(tid * 32);
+        }
+    }
+    const int n = __builtin_amdgcn_readfirstlane(s.cnt4[0][wave] + s.cnt4[1][wave] + s.cnt4[2][wave] + s.cnt4[3][wave]);
+    __syncthreads();
+    if (lane < 4) s.list[wave][n + lane] = (unsigned short)(SENTINEL * 32);  // own list, own wave: program order suffices
+    return n;
+}
+
+__device__ __forceinline__ void load4(const Staged& s, int wave, int k, float4 (&q0)[4], float4 (&q1)[4]) {
+    const uint2 pk = *reinterpret_cast<const uint2*>(&s.list[wave][k]);
+    const unsigned off[4] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
+    const char* base = reinterpret_cast<const char*>(s.rec);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        q0[u] = *reinterpret_cast<const float4*>(base + off[u]);
+        q1[u] = *reinterpret_cast<const float4*>(base + off[u] + 16);
+    }
+}
+
+
+constexpr int NACC = DGR_ACC_STRIDE;          // accumulator components carried per staged instance (<= 16)
+constexpr int ACC_LD = DGR_TILE_PIX + 1;      // component-major LDS accumulators, +1 pad for the transposed flush
+
+// flush of the per-batch LDS accumulators: 16 consecutive lanes cover one Gaussian's 64-byte accumulator row
+template <int NCOMP>
+__device__ __forceinline__ void flush_acc(const float* lds_acc, const uint32_t* ids, int cnt, float* global_acc, int tid) {
+    const int comp = tid & 15;
+    if (comp < NCOMP) {
+        for (int r = tid >> 4; r < cnt; r += 16) {
+            const float v = lds_acc[comp * ACC_LD + r];
+            if (v != 0.f) atomicAdd(global_acc + (size_t)ids[r] * DGR_ACC_STRIDE + comp, v);
+        }
+    }
+}
+
+}  // namespace
+}  // namespace dgr

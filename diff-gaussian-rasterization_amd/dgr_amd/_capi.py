@@ -42,6 +42,15 @@ _SIGS = {
                                 _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
                                 _vp, _i, _i, _vp, _sz]),
+    "dgr_full_forward": (_i, [_vp, ALLOC_FN, ALLOC_FN, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i,
+                              _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,
+                              _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)]),
+    "dgr_full_forward_presized": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _i,
+                                       _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,
+                                       _vp, _vp, _vp, _vp, _vp]),
+    "dgr_full_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "dgr_state_export": (C.c_long, [_vp, C.c_char_p, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dgr_debug_wave_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dgr_profile_select": (_i, [C.c_char_p]),

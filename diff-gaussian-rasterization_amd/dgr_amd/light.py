@@ -41,6 +41,26 @@ _capacity_cache = {}
 _last_arena = None
 
 
+def _grad_arena(P, M, f32):
+    """One flat arena holds every per-Gaussian gradient (returned as views), ordered so that the tensors a
+    mapping step all-reduces across GPUs -- means3D, means2D, sh, opacity, scales, rotations -- are one
+    contiguous span (dgr_amd.multiview.GradientArena).  Every row is written by the kernels (zeros for
+    invisible Gaussians), so the arena is not zero-filled."""
+    global _last_arena
+    shapes = [("means3D", (P, 3)), ("means2D", (P, 3)), ("sh", (P, M, 3)), ("opacity", (P, 1)),
+              ("scales", (P, 3)), ("rotations", (P, 4)), ("cov3D", (P, 6)), ("colors", (P, 3))]
+    offs, o = {}, 0
+    for name, shp in shapes:
+        n = 1
+        for d_ in shp:
+            n *= d_
+        offs[name] = (o, n, shp)
+        o += (n + 63) // 64 * 64  # 256-byte aligned segments (vector stores in the kernels)
+    arena = (torch.empty if P else torch.zeros)((max(o, 1),), **f32)
+    _last_arena = (arena, offs["cov3D"][0])  # (flat buffer, length of the all-reduced span)
+    return {name: arena[a:a + n].view(shp) for name, (a, n, shp) in offs.items()}
+
+
 def _check(rc):
     if rc >= 0:
         return rc
@@ -149,25 +169,9 @@ class _C:
         gC, gD = _f32c(dL_dout_color, dev), _f32c(dL_dout_depth, dev)
         gM, gV = _f32c(dL_dout_median_depth, dev), _f32c(dL_dout_depth_var, dev)
         M = sh.size(1) if sh.numel() != 0 else 0
-        # One flat arena holds every per-Gaussian gradient (views below), ordered so that the tensors a
-        # mapping step all-reduces across GPUs -- means3D, means2D, sh, opacity, scales, rotations -- are one
-        # contiguous span (dgr_amd.multiview.GradientArena).  Every row is written by the kernels (zeros for
-        # invisible Gaussians), so the arena is not zero-filled.
-        shapes = [("means3D", (P, 3)), ("means2D", (P, 3)), ("sh", (P, M, 3)), ("opacity", (P, 1)),
-                  ("scales", (P, 3)), ("rotations", (P, 4)), ("cov3D", (P, 6)), ("colors", (P, 3))]
-        offs, o = {}, 0
-        for name, shp in shapes:
-            n = 1
-            for d_ in shp:
-                n *= d_
-            offs[name] = (o, n, shp)
-            o += (n + 63) // 64 * 64  # 256-byte aligned segments (vector stores in the kernels)
-        arena = (torch.empty if P else torch.zeros)((max(o, 1),), **f32)
-        seg = {name: arena[a:a + n].view(shp) for name, (a, n, shp) in offs.items()}
+        seg = _grad_arena(P, M, f32)
         dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dopacity = seg["means3D"], seg["means2D"], seg["sh"], seg["opacity"]
         dL_dscales, dL_drotations, dL_dcov3D, dL_dcolors = seg["scales"], seg["rotations"], seg["cov3D"], seg["colors"]
-        global _last_arena
-        _last_arena = (arena, offs["cov3D"][0])  # (flat buffer, length of the all-reduced span)
         dL_dview = torch.empty((4, 4), **f32)
         scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes(P, W, H), 1),), dtype=torch.uint8, device=dev)
         p = _capi.ptr

@@ -108,10 +108,54 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
                        const float* perspec_matrix, float* dL_dview, float* dg_camd_dviewmatrix,
                        const float* gt_depth, int track_off, int map_off, char* scratch, size_t scratch_bytes);
 
+/* ---- -full variant -------------------------------------------------------------------------------
+ * Replaces CudaRasterizer::Rasterizer::forward of the full variant (F/cr/rasterizer.h:31-62,
+ * F/cr/rasterizer_impl.cu:349-500): returns num_rendered; the tuple's second member (num_related_primitives,
+ * the total of n_valid_contrib) is written to *num_related_primitives (host int, may be NULL to skip the second
+ * blocking read).  `out_uncertainty` is sum alpha*T (F/cr/forward.cu:367,394); gt_depth is accepted and unused in
+ * the forward, as there (quirk F6). */
+int dgr_full_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn binningBuffer, dgr_alloc_fn imageBuffer,
+                     void* alloc_user, int P, int D, int M, const float* background, int width, int height,
+                     const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                     const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                     const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                     float tan_fovy, int prefiltered, float* out_color, float* out_depth, const float* gt_depth,
+                     float* out_uncertainty, int* radii, int* num_related_primitives);
+
+/* No-sync form; status = device int[4] {num_rendered, overflow, prefiltered violation, num_related_primitives}. */
+int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning_buffer, int binning_capacity,
+                              char* image_buffer, int* status, int P, int D, int M, const float* background, int width,
+                              int height, const float* means3D, const float* shs, const float* colors_precomp,
+                              const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                              const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                              const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                              float* out_depth, const float* gt_depth, float* out_uncertainty, int* radii);
+
+/* Replaces CudaRasterizer::Rasterizer::backward of the full variant (F/cr/rasterizer.h:64-102,
+ * F/cr/rasterizer_impl.cu:504-666), same arguments in the same order (+ stream, + scratch).  The NG-sized pair
+ * lists (dpixel_dgc, gau_id_list, pix_id_list, dpixel_dndcs, dpixel_dinvcovs, ddepth_dndcs, ddepth_dinvcovs) and
+ * the per-Gaussian Jacobian tables (dgc_dCam_position, dgndcs_dviewmatrix, dgc_invcovs_dT) are implementation
+ * scratch of the reference; they are not materialised here and may be NULL.  dL_dview receives the 4x4 gradient
+ * with the well-defined semantics of ComputePG: every recorded (pixel, Gaussian) pair is consumed.  (The reference
+ * lets threads of pixels without a valid contributor return before the block-wide loads, F/cr/backward.cu:875-878,
+ * 935-938, which makes its own result undefined for the other pixels of such a tile; DESIGN.md "full variant".) */
+int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,
+                      const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                      float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                      const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                      char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                      const float* dL_depths, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                      float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                      float* dpixel_dgc, int* gau_id_list, int* pix_id_list, float* dgc_dCam_position, float* dpixel_dndcs,
+                      const float* perspec_matrix, float* dgndcs_dviewmatrix, float* dpixel_dinvcovs,
+                      float* dgc_invcovs_dT, float* dL_dview, float* dL_dgau_depth, float* ddepth_dndcs,
+                      float* ddepth_dinvcovs, const float* gt_depth, const float* dL_duncertainties, char* scratch,
+                      size_t scratch_bytes);
+
 /* ---- stage-wise access for tests and profiling (views into the opaque state buffers) ---- */
 /* Copies one named array of a state buffer to `dst` (device or host pointer).  Names: "depths", "radii",
  * "means2D", "cov3D", "conic_opacity", "rgb", "clamped", "tiles_touched" (geometry); "point_list", "keys" (binning);
- * "ranges", "n_contrib" (image).  Layout conversion to the reference's element types is done on the fly.
+ * "ranges", "n_contrib", "n_valid", "final_T" (image; the last two: full variant).  Layout conversion to the reference's element types is done on the fly.
  * Returns the element count, or < 0. */
 long dgr_state_export(void* stream, const char* name, int P, int width, int height, int num_rendered,
                       const char* geom_buffer, const char* binning_buffer, const char* image_buffer, void* dst_device);

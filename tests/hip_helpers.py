@@ -118,3 +118,49 @@ def oracle_backward(O, st, s, deg, alphas, colors_precomp=None, cov3D_precomp=No
                             s.rots if use_sr else None, scale_modifier, cov3D_precomp, s.view, s.proj, s.tanfovx,
                             s.tanfovy, gC, gD, gM, gV, s.gt, s.shs if use_sh else None, deg, s.campos, alphas, s.persp,
                             track_off=track_off, map_off=map_off)
+
+
+# ------------------------------------------------------------------------------------------ full variant
+def hip_full_forward(s, deg, colors_precomp=None, cov3D_precomp=None):
+    from dgr_amd import full as F
+    use_sh = colors_precomp is None
+    use_sr = cov3D_precomp is None
+    out = F._C.rasterize_gaussians(
+        T(s.bg), T(s.means), E() if use_sh else T(colors_precomp), T(s.opac), T(s.scales) if use_sr else E(),
+        T(s.rots) if use_sr else E(), 1.0, E() if use_sr else T(cov3D_precomp), T(s.view), T(s.gt), T(s.proj), s.tanfovx,
+        s.tanfovy, s.H, s.W, T(s.shs) if use_sh else E(), deg, T(s.campos), False)
+    names = ["num_rendered", "num_related", "color", "depth", "uncertainty", "radii", "geom", "binning", "img"]
+    d = {n: (v if n in ("geom", "binning", "img") or not isinstance(v, torch.Tensor) else v.cpu().numpy())
+         for n, v in zip(names, out)}
+    return out, d
+
+
+def hip_full_backward(s, deg, out, colors_precomp=None, cov3D_precomp=None, grads=None):
+    from dgr_amd import full as F
+    use_sh = colors_precomp is None
+    use_sr = cov3D_precomp is None
+    (R, NG, color, depth, unc, radii, geom, binning, img) = out
+    gC, gD, gU = grads if grads is not None else (s.gC, s.gD, s.gV)
+    g = F._C.rasterize_gaussians_backward(
+        T(s.bg), T(s.means), radii, E() if use_sh else T(colors_precomp), T(s.scales) if use_sr else E(),
+        T(s.rots) if use_sr else E(), 1.0, E() if use_sr else T(cov3D_precomp), T(s.view), T(s.gt), T(s.proj), s.tanfovx,
+        s.tanfovy, T(gC), T(gD[None]), T(gU[None]), T(s.shs) if use_sh else E(), deg, T(s.campos), geom, R, binning, img,
+        NG, T(s.persp))
+    names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations", "dL_dview"]
+    return {n: v.cpu().numpy() for n, v in zip(names, g)}
+
+
+def oracle_full(O, s, deg, colors_precomp=None, cov3D_precomp=None, grads=None, backward=True):
+    use_sh = colors_precomp is None
+    use_sr = cov3D_precomp is None
+    st, out = O.full_forward(s.bg, s.means, colors_precomp, s.opac, s.scales if use_sr else None,
+                             s.rots if use_sr else None, 1.0, cov3D_precomp, s.view, s.gt, s.proj, s.tanfovx, s.tanfovy,
+                             s.H, s.W, s.shs if use_sh else None, deg, s.campos)
+    if not backward:
+        return st, out, None
+    gC, gD, gU = grads if grads is not None else (s.gC, s.gD, s.gV)
+    g = O.full_backward(st, s.bg, s.means, colors_precomp, s.scales if use_sr else None, s.rots if use_sr else None, 1.0,
+                        cov3D_precomp, s.view, s.gt, s.proj, s.tanfovx, s.tanfovy, gC, gD, gU,
+                        s.shs if use_sh else None, deg, s.campos, s.persp)
+    return st, out, g
