@@ -499,11 +499,13 @@ int dgr_profile_read(const char* stage, double* total_ms, int* launches) {
 }
 
 long dgr_state_export(void* stream, const char* name, int P, int width, int height, int num_rendered,
-                      const char* geom_buffer, const char* binning_buffer, const char* image_buffer, void* dst) {
+                      int binning_capacity, const char* geom_buffer, const char* binning_buffer, const char* image_buffer,
+                      void* dst) {
     hipStream_t st = (hipStream_t)stream;
+    if (binning_capacity < num_rendered) { g_last_error = "binning_capacity < num_rendered"; return -1; }
     dgr::GeometryView g = dgr::carve_geometry(const_cast<char*>(geom_buffer), P);
     dgr::ImageView img = dgr::carve_image(const_cast<char*>(image_buffer), width, height);
-    dgr::BinningView bin = dgr::carve_binning(const_cast<char*>(binning_buffer), (size_t)num_rendered);
+    dgr::BinningView bin = dgr::carve_binning(const_cast<char*>(binning_buffer), (size_t)binning_capacity);
     const size_t tiles = (size_t)dgr::tiles_x(width) * dgr::tiles_y(height), N = (size_t)width * height;
     auto copy = [&](const void* src, size_t bytes) -> int {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st));

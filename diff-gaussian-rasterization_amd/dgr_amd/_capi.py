@@ -51,7 +51,7 @@ _SIGS = {
     "dgr_full_backward": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
-    "dgr_state_export": (C.c_long, [_vp, C.c_char_p, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dgr_state_export": (C.c_long, [_vp, C.c_char_p, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dgr_debug_wave_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dgr_profile_select": (_i, [C.c_char_p]),
     "dgr_profile_stage_count": (_i, []),

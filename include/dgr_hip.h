@@ -156,9 +156,11 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
 /* Copies one named array of a state buffer to `dst` (device or host pointer).  Names: "depths", "radii",
  * "means2D", "cov3D", "conic_opacity", "rgb", "clamped", "tiles_touched" (geometry); "point_list", "keys" (binning);
  * "ranges", "n_contrib", "n_valid", "final_T" (image; the last two: full variant).  Layout conversion to the reference's element types is done on the fly.
- * Returns the element count, or < 0. */
+ * `num_rendered` instances are exported; `binning_capacity` is the capacity the binning buffer was carved with
+ * (= num_rendered after dgr_*_forward, the caller's capacity after *_presized).  Returns the element count, or < 0. */
 long dgr_state_export(void* stream, const char* name, int P, int width, int height, int num_rendered,
-                      const char* geom_buffer, const char* binning_buffer, const char* image_buffer, void* dst_device);
+                      int binning_capacity, const char* geom_buffer, const char* binning_buffer,
+                      const char* image_buffer, void* dst_device);
 
 /* Self-test of the wave64 multi-value butterfly reductions the backward blend relies on.  `in` holds 16
  * values per lane as in[c * 64 + lane]; out16[lane] / out4[lane] receive what each lane holds after the

@@ -58,7 +58,7 @@ def hip_state(name, s, d, capacity=None):
                 np.uint64: torch.int64}[dt]
     dst = torch.zeros(max(n, 1), dtype=torch_dt, device=dev())
     cap = capacity if capacity is not None else binning_capacity(d, W, H)
-    got = lib.dgr_state_export(_capi.stream_handle(), name.encode(), P, W, H, cap, _capi.ptr(d["geom"]),
+    got = lib.dgr_state_export(_capi.stream_handle(), name.encode(), P, W, H, R, cap, _capi.ptr(d["geom"]),
                                _capi.ptr(d["binning"]), _capi.ptr(d["img"]), dst.data_ptr())
     assert got >= 0, _capi.last_error()
     torch.cuda.synchronize()
