@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--sync-mode", default="lazy", choices=["lazy", "strict"],
+                    help="lazy: forward's status word is checked one step late (no host sync in the step); "
+                         "strict: one blocking status read per forward, like the reference")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,7 +92,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from dgr_amd import _capi
+    os.environ["DGR_SYNC_MODE"] = args.sync_mode
+    from dgr_amd import _capi, light
     from dgr_amd.multiview import GradientArena, make_settings
     from dgr_amd.synth import make_scene
     from diff_gaussian_rasterization import GaussianRasterizer
@@ -145,6 +149,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         radii = step()
+    light.check_async_errors()  # status words of every timed step (lazy mode): raises if any forward was invalid
     barrier()
     elapsed = time.perf_counter() - t0
     dom_tot, dom_n = _capi.profile_read(dominant)
@@ -185,7 +190,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, light variant, "
                                    f"fwd+bwd incl. viewmatrix gradient, one view per GPU", "visible": V,
-                       "num_rendered": R, "views_per_s": views_per_s,
+                       "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": abytes,

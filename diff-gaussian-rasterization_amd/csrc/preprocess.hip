@@ -609,20 +609,28 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
 }
 
 // Final pose reduction: fixed-order double sum of the per-block partials -> dL_dview[16].
-__global__ void __launch_bounds__(256) pose_reduce_kernel(const float* __restrict__ part, int nblocks, float* dL_dview,
-                                                          int track_off) {
-    __shared__ double sm[256];
-    const int s = threadIdx.x & 15, grp = threadIdx.x >> 4;  // 16 groups x 16 slots (12 used)
-    double v = 0.0;
-    if (!track_off && s < 12)
-        for (int b = grp; b < nblocks; b += 16) v += (double)part[(size_t)b * 12 + s];
-    sm[threadIdx.x] = v;
+// 1024 threads = 64 row groups x 16 slots (12 used): each thread sums every 64th partial row, then 16 threads fold
+// the 64 groups.  (A single 256-thread block walking all rows took 30 us at P = 500k.)
+__global__ void __launch_bounds__(1024) pose_reduce_kernel(const float* __restrict__ part, int nblocks, float* dL_dview,
+                                                           int track_off) {
+    __shared__ double sm[64][16];
+    const int s = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    double v0 = 0.0, v1 = 0.0;
+    if (!track_off && s < 12) {
+        int b = grp;
+        for (; b + 64 < nblocks; b += 128) {  // two independent chains keep two loads in flight
+            v0 += (double)part[(size_t)b * 12 + s];
+            v1 += (double)part[(size_t)(b + 64) * 12 + s];
+        }
+        if (b < nblocks) v0 += (double)part[(size_t)b * 12 + s];
+    }
+    sm[grp][s] = v0 + v1;
     __syncthreads();
     if (threadIdx.x < 16) {
         float out = 0.0f;
         if (threadIdx.x < 12) {
             double t = 0.0;
-            for (int g = 0; g < 16; g++) t += sm[g * 16 + threadIdx.x];
+            for (int g = 0; g < 64; g++) t += sm[g][threadIdx.x];
             out = (float)t;
         }
         // slot order v0,v1,v2,v4,v5,v6,v8,v9,v10,v12,v13,v14 (L/cuda_rasterizer/backward.cu:723)
@@ -646,7 +654,7 @@ hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hi
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(256), 0, stream, a.pose_part, blocks, dL_dview, a.track_off);
+    hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(1024), 0, stream, a.pose_part, blocks, dL_dview, a.track_off);
     return hipGetLastError();
 }
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream) {

@@ -79,7 +79,7 @@ class _C:
                 if s[2]:
                     raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
                 rendered, related = s[0], s[3]
-                _capacity_cache[key] = rendered
+                _capacity_cache[key] = max(_capacity_cache.get(key, 0), rendered)
                 if not s[1]:
                     break
                 cap = int(rendered * 1.1) + 4096

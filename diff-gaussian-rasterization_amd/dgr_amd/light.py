@@ -35,8 +35,50 @@ def _f32c(t, dev):
     return t.contiguous()
 
 
-# binning capacity learned per (device, P, H, W): last num_rendered of that shape
+# binning capacity learned per (device, P, H, W): largest num_rendered seen for that shape
 _capacity_cache = {}
+
+# DGR_SYNC_MODE=lazy: once a shape's num_rendered is known, forward performs NO host synchronisation.  The binning
+# buffer is over-provisioned (1.5x the largest count seen); the device status word {num_rendered, overflow,
+# prefiltered violation, -} is copied asynchronously to pinned host memory behind an event, and inspected when a
+# later call starts (or by check_async_errors()), by which time the event has long fired.  An overflow or a
+# `prefiltered` violation therefore raises one or two calls late.  Default ("strict"): one status read at the end of
+# every forward, like the reference's blocking copy of num_rendered (L/cuda_rasterizer/rasterizer_impl.cu:287).
+_pending_status = []   # [(pinned host int32[4], event, key)]
+_pinned_pool = []
+
+
+def _sync_mode():
+    return os.environ.get("DGR_SYNC_MODE", "strict")
+
+
+def _post_status(status, key):
+    host = _pinned_pool.pop() if _pinned_pool else torch.empty((4,), dtype=torch.int32, pin_memory=True)
+    host.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _pending_status.append((host, ev, key))
+
+
+def _check_oldest():
+    host, ev, key = _pending_status.pop(0)
+    ev.synchronize()  # waits for that forward only
+    s = host.tolist()
+    _pinned_pool.append(host)
+    _capacity_cache[key] = max(_capacity_cache.get(key, 0), s[0])
+    if s[2]:
+        raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    if s[1]:
+        raise RuntimeError(f"dgr_hip: binning buffer overflow in an earlier lazily-checked forward (needed {s[0]} "
+                           f"instances); its outputs were invalid -- rerun that step")
+
+
+def check_async_errors():
+    """Raises if an earlier lazily-checked forward overflowed its binning buffer or hit the prefiltered trap."""
+    while _pending_status:
+        _check_oldest()
+
+
 # (flat gradient arena of the most recent backward, number of leading floats that are parameter gradients)
 _last_arena = None
 
@@ -101,9 +143,11 @@ class _C:
         out_median = torch.empty((1, H, W), **f32)
         out_var = torch.empty((1, H, W), **f32)
         out_alpha = torch.empty((1, H, W), **f32)
-        radii = torch.zeros((P,), **i32)
-        gau_unc = torch.zeros((P, 1), **f32)
-        gau_px = torch.zeros((P, 1), **i32)
+        # radii is written for every Gaussian and the two median statistics are zeroed by the C ABI (stream memsets)
+        mk = torch.empty if P else torch.zeros
+        radii = mk((P,), **i32)
+        gau_unc = mk((P, 1), **f32)
+        gau_px = mk((P, 1), **i32)
         u8 = dict(dtype=torch.uint8, device=dev)
         st = _capi.stream_handle()
         p = _capi.ptr
@@ -130,6 +174,19 @@ class _C:
             status = torch.empty((4,), **i32)
             key = (dev.index, P, H, W)
             cap = _capacity_cache.get(key, 0)
+            lazy = _sync_mode() == "lazy" and cap > 0
+            if lazy:
+                # status words of earlier calls have long completed: reading them does not stall the pipeline
+                while len(_pending_status) > 1:
+                    _check_oldest()
+                cap = int(cap * 1.5) + 4096
+                binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)
+                _check(lib.dgr_light_forward_presized(st, p(geomBuffer), p(binningBuffer), cap, p(imgBuffer),
+                                                      p(status), *common))
+                _post_status(status, key)
+                rendered = _capacity_cache[key]
+                return (rendered, out_color, out_depth, out_median, out_var, out_alpha, radii, geomBuffer,
+                        binningBuffer, imgBuffer, gau_unc, gau_px)
             cap = int(cap * 1.25) + 4096 if cap else 4 * P + 4096
             while True:
                 binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)
@@ -139,7 +196,7 @@ class _C:
                 if s[2]:
                     raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
                 rendered = s[0]
-                _capacity_cache[key] = rendered
+                _capacity_cache[key] = max(_capacity_cache.get(key, 0), rendered)
                 if not s[1]:
                     break
                 cap = int(rendered * 1.1) + 4096  # overflow: every tile list was left empty; run again
