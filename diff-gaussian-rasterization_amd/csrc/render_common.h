@@ -22,7 +22,7 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
 }
 
 struct Staged {
-    float4 rec[2 * (DGR_TILE_PIX + 1)];  // [2*slot] = {x, y, a2, b2}, [2*slot+1] = {c2, opacity, slot (int bits), 0}
+    float4 rec[2 * (DGR_TILE_PIX + 1)];  // [2*slot] = {x, y, a2, b2}, [2*slot+1] = {c2, opacity, slot (int bits), lthr}
                                          //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power
     float4 rgbd[DGR_TILE_PIX];           // {r, g, b, depth}
     uint32_t id[DGR_TILE_PIX];
@@ -31,34 +31,35 @@ struct Staged {
 };
 
 // Stage one instance and return the 4-bit "may touch quadrant" code.
+// A quadrant is kept when the bounding box of the region alpha >= 15/255, i.e. q(d) <= tau = 2 ln(255 o / 15), reaches
+// one of its pixels; the box carries a safety margin far above the rounding of the per-pixel evaluation (and of the
+// fast rcp / sqrt used here), so every dropped (pixel, Gaussian) pair is one the per-pixel test rejects.
+// (An exact ellipse-vs-quadrant test was measured: it removes almost no list entries beyond the box -- the
+// iterations without a valid lane are finished pixels and sub-pixel splats -- and costs more VALU than it saves.)
 __device__ __forceinline__ unsigned stage_one(Staged& s, int slot, uint32_t gid, const float4* __restrict__ rec,
                                               float tile_x0, float tile_y0, float4* raw_conic) {
     const float4 q0 = rec[3 * (size_t)gid + 0];
     const float4 q1 = rec[3 * (size_t)gid + 1];
     const float4 q2 = rec[3 * (size_t)gid + 2];
+    const float o = q0.w;
+    // log-domain threshold: alpha >= 15/255 <=> p2 >= log2(15/(255 o)); the loop compares against a slightly lower
+    // value and re-tests alpha itself on the rare path, so decisions are those of the linear-domain test.
+    const float l2 = __log2f(o * (255.0f / 15.0f));  // = tau / (2 ln 2)
+    const float lthr = (o > 0.f) ? (-l2 - 1.0e-4f) : 3.0e38f;
     s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -LOG2E * q1.y);
-    s.rec[2 * slot + 1] = make_float4(-0.5f * LOG2E * q1.z, q0.w, __int_as_float(slot), 0.f);
+    s.rec[2 * slot + 1] = make_float4(-0.5f * LOG2E * q1.z, o, __int_as_float(slot), lthr);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
     if (raw_conic) *raw_conic = make_float4(q1.x, q1.y, q1.z, 0.f);
-    // alpha >= 15/255  <=>  a dx^2 + 2 b dx dy + c dy^2 <= tau = 2 ln(255 o / 15)
-    const float o = q0.w;
-    const float tau = 2.0f * __logf(o * (255.0f / 15.0f));
+    const float tau = 2.0f * 0.6931471805599453f * l2;
     const float det = q1.x * q1.z - q1.y * q1.y;
-    float hx, hy;
-    if (!(tau > 0.0f)) {
-        return 0u;  // opacity below 15/255: can never contribute
-    } else if (det > 0.0f && q1.x > 0.0f && q1.z > 0.0f) {
-        const float k = tau / det;
-        hx = sqrtf(k * q1.z) * 1.001f + 0.05f;
-        hy = sqrtf(k * q1.x) * 1.001f + 0.05f;
-    } else {
-        return 0xFu;  // degenerate conic: do not cull
-    }
-    const float lx = q0.x - hx - tile_x0, rx = q0.x + hx - tile_x0;  // bbox relative to the tile origin
-    const float ly = q0.y - hy - tile_y0, ry = q0.y + hy - tile_y0;
-    const bool xl = (rx >= 0.0f) && (lx <= 7.0f), xr = (rx >= 8.0f) && (lx <= 15.0f);
-    const bool yt = (ry >= 0.0f) && (ly <= 7.0f), yb = (ry >= 8.0f) && (ly <= 15.0f);
+    if (!(tau > 0.0f)) return 0u;                                       // opacity below 15/255: can never contribute
+    if (!(det > 0.0f && q1.x > 0.0f && q1.z > 0.0f)) return 0xFu;       // degenerate conic: do not cull
+    const float k = tau * __builtin_amdgcn_rcpf(det);
+    const float hx = __builtin_amdgcn_sqrtf(k * q1.z) * 1.001f + 0.05f, hy = __builtin_amdgcn_sqrtf(k * q1.x) * 1.001f + 0.05f;
+    const float gx = q0.x - tile_x0, gy = q0.y - tile_y0;              // centre relative to the tile origin
+    const bool xl = (gx + hx >= 0.0f) && (gx - hx <= 7.0f), xr = (gx + hx >= 8.0f) && (gx - hx <= 15.0f);
+    const bool yt = (gy + hy >= 0.0f) && (gy - hy <= 7.0f), yb = (gy + hy >= 8.0f) && (gy - hy <= 15.0f);
     return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
 }
 
@@ -90,6 +91,18 @@ __device__ __forceinline__ int build_lists(Staged& s, unsigned code, int tid, in
     return n;
 }
 
+// two-entry form of load4 (fewer live registers: the backward trades a little load batching for occupancy)
+__device__ __forceinline__ void load2(const Staged& s, int wave, int k, float4 (&q0)[2], float4 (&q1)[2]) {
+    const unsigned pk = *reinterpret_cast<const unsigned*>(&s.list[wave][k]);
+    const unsigned off[2] = {pk & 0xffffu, pk >> 16};
+    const char* base = reinterpret_cast<const char*>(s.rec);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        q0[u] = *reinterpret_cast<const float4*>(base + off[u]);
+        q1[u] = *reinterpret_cast<const float4*>(base + off[u] + 16);
+    }
+}
+
 __device__ __forceinline__ void load4(const Staged& s, int wave, int k, float4 (&q0)[4], float4 (&q1)[4]) {
     const uint2 pk = *reinterpret_cast<const uint2*>(&s.list[wave][k]);
     const unsigned off[4] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
@@ -101,6 +114,12 @@ __device__ __forceinline__ void load4(const Staged& s, int wave, int k, float4 (
     }
 }
 
+
+// sentinel record: p2 = 0 but lthr = +big, so it never passes `p2 >= lthr`
+__device__ __forceinline__ void write_sentinel(Staged& s) {
+    s.rec[2 * SENTINEL] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.rec[2 * SENTINEL + 1] = make_float4(0.f, 0.f, __int_as_float(SENTINEL), 3.0e38f);
+}
 
 constexpr int NACC = DGR_ACC_STRIDE;          // accumulator components carried per staged instance (<= 16)
 constexpr int ACC_LD = DGR_TILE_PIX + 1;      // component-major LDS accumulators, +1 pad for the transposed flush

@@ -55,18 +55,16 @@ __global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArg
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f, D_median = 0.f;
     uint32_t last_contributor = 0;
-    // "done" as a threshold: alpha never exceeds 0.99, so a finished pixel compares against +inf
-    float thr = inside ? ALPHA_MIN : __builtin_inff();
+    // "done" as a per-lane upper bound on p2: live pixels accept p2 <= 0 (the reference's `power > 0` test),
+    // finished pixels compare against -inf and accept nothing
+    float ub = inside ? 0.f : -__builtin_inff();
     const float gt_px = inside ? a.gt_depth[pix_id] : 0.f;
-    if (tid == 0) {
-        s.rec[2 * SENTINEL] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s.rec[2 * SENTINEL + 1] = make_float4(0.f, 0.f, __int_as_float(SENTINEL), 0.f);
-    }
+    if (tid == 0) write_sentinel(s);
     bool have_flush = false;
 
     for (int base = 0; base < total; base += DGR_TILE_PIX) {
         // whole tile finished?  (L/cuda_rasterizer/forward.cu:329-332)
-        if (__syncthreads_and(thr > 1.0f)) break;
+        if (__syncthreads_and(ub < 0.f)) break;
         // median statistics of the previous batch: slot tid is flushed by the thread that restages it
         if (have_flush && sf.cnt[tid] != 0u) {
             atomicAdd(&a.gau_uncertainty[s.id[tid]], sf.unc[tid]);
@@ -87,11 +85,12 @@ __global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArg
             for (int u = 0; u < 4; u++) {
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
-                const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
-                if (p2 <= 0.0f && alpha >= thr) {
+                if (p2 <= ub && p2 >= q1[u].w) {  // cheap log-domain pre-test: v_exp stays off the common path
+                  const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
+                  if (alpha >= ALPHA_MIN) {
                     const float test_T = T * (1.0f - alpha);
                     if (test_T < 0.0001f) {
-                        thr = __builtin_inff();  // done; this Gaussian is not blended (forward.cu:368-373)
+                        ub = -__builtin_inff();  // done; this Gaussian is not blended (forward.cu:368-373)
                     } else {
                         const int j = __float_as_int(q1[u].z);
                         const float4 cd = s.rgbd[j];
@@ -108,9 +107,10 @@ __global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArg
                         T = test_T;
                         last_contributor = (uint32_t)(base + j + 1);
                     }
+                  }
                 }
             }
-            if (__all(thr > 1.0f)) break;
+            if (__all(ub < 0.f)) break;
         }
     }
     __syncthreads();
@@ -147,7 +147,6 @@ constexpr int NACC_LIGHT = 14;
 
 struct StagedBwd {
     Staged f;
-    float4 raw[DGR_TILE_PIX];  // {conic a, b, c, unused}
     float acc[NACC_LIGHT * ACC_LD];
     int max_last;
 };
@@ -172,8 +171,7 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
 
     if (tid == 0) {
         sb.max_last = 0;
-        s.rec[2 * SENTINEL] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s.rec[2 * SENTINEL + 1] = make_float4(0.f, 0.f, __int_as_float(SENTINEL), 0.f);
+        write_sentinel(s);
     }
     __syncthreads();
     {
@@ -208,8 +206,8 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
     // which accumulator component this lane's quad delivers after the butterfly (-1: none)
     int my_comp;
     if (DO_MAP) {
-        const int c = wave_reduce16_comp(lane);
-        my_comp = ((lane & 3) == 0 && c < NACC_LIGHT) ? c : -1;
+        const int c = wave_reduce16_comp(lane);  // butterfly slots 0..9 = components 0..9, slot 10 = component 13
+        my_comp = ((lane & 3) != 0 || c > 10) ? -1 : (c == 10 ? (DO_POSE ? 13 : -1) : c);
     } else {
         const int c = wave_reduce4_comp(lane);  // {4: gmx, 5: gmy, 13: pose depth}
         my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
@@ -221,36 +219,36 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
         const int cnt = hi - lo;
         __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
-        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, &sb.raw[tid]);
+        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, nullptr);
 #pragma unroll
         for (int k = 0; k < NACC_LIGHT; k++) sb.acc[k * ACC_LD + tid] = 0.f;
         const int n = build_lists(s, code, tid, wave, lane);
         const int rel_last = last_contributor - lo;  // slots below this are at or before the last contributor
 
-        for (int k = ((n + 3) & ~3) - 4; k >= 0; k -= 4) {
-            float4 q0[4], q1[4];
-            load4(s, wave, k, q0, q1);
+        // (the list is padded with sentinels to a multiple of 4, so a multiple of 2 is always readable)
+        for (int k = ((n + 1) & ~1) - 2; k >= 0; k -= 2) {
+            float4 q0[2], q1[2];
+            load2(s, wave, k, q0, q1);
 #pragma unroll
-            for (int u = 3; u >= 0; u--) {
+            for (int u = 1; u >= 0; u--) {
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
+                const int j = __float_as_int(q1[u].z);
+                // log-domain pre-test; the exact alpha test follows on the rare path
+                if (!__any(j < rel_last && p2 <= 0.0f && p2 >= q1[u].w)) continue;
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, q1[u].y * G);
-                const int j = __float_as_int(q1[u].z);
                 const bool valid = j < rel_last && p2 <= 0.0f && alpha >= ALPHA_MIN;
                 if (!__any(valid)) continue;
 
-                float g[16];
-#pragma unroll
-                for (int c = 0; c < 16; c++) g[c] = 0.f;
+                // per-lane scalars of this pair; they stay 0 on lanes the Gaussian does not reach, so the products
+                // below need no masking:  w = alpha T,  qq = o G dL/dalpha  (dL_dG * G)
+                float w = 0.f, qq = 0.f, e = 0.f;
+                const float4 cd = s.rgbd[j];
                 if (valid) {
-                    const float4 cd = s.rgbd[j];
-                    const float4 rc = sb.raw[j];
-                    const float opac = q1[u].y;
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     T = T * inv;
-                    const float w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
-                    const float dL_ddepth = w * dpix_depth;
+                    w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
                     // colour / depth / variance recurrences (backward.cu:580-608)
                     const float om = 1.f - last_alpha;
                     acc0 = last_alpha * lc0 + om * acc0; lc0 = cd.x;
@@ -258,7 +256,7 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                     acc2 = last_alpha * lc2 + om * acc2; lc2 = cd.z;
                     float dL_dalpha = (cd.x - acc0) * dpix0 + (cd.y - acc1) * dpix1 + (cd.z - acc2) * dpix2;
                     const float c_d = cd.w;
-                    const float e = c_d - gt_px;
+                    e = c_d - gt_px;
                     const float c_var = e * e;
                     acc_depth = last_alpha * last_depth + om * acc_depth; last_depth = c_d;
                     acc_var = last_alpha * last_var + om * acc_var; last_var = c_var;
@@ -267,44 +265,42 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                     dL_dalpha *= T;
                     last_alpha = alpha;
                     dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
-
-                    const float dL_dG = opac * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * rc.x - gdy * rc.y;
-                    const float dG_ddely = -gdy * rc.z - gdx * rc.y;
-                    const float gmx = dL_dG * dG_ddelx * ddelx_dx;  // == dL_dndcs_x of backward.cu:635
-                    const float gmy = dL_dG * dG_ddely * ddely_dy;
-                    if (DO_MAP) {
-                        g[0] = w * dpix0;
-                        g[1] = w * dpix1;
-                        g[2] = w * dpix2;
-                        g[3] = dL_ddepth + dpix_var * w * 2.f * e;
-                        g[4] = gmx;
-                        g[5] = gmy;
-                        g[6] = -0.5f * gdx * dx * dL_dG;
-                        g[7] = -0.5f * gdx * dy * dL_dG;
-                        g[8] = -0.5f * gdy * dy * dL_dG;
-                        g[9] = G * dL_dalpha;
-                        if (T > 0.5f && mid_once) {  // backward.cu:654-664
-                            const float* mg = a.means3D + 3 * (size_t)s.id[j];
-                            const float mul3 = v2 * mg[0] + v6 * mg[1] + v10 * mg[2] + v14;
-                            g[10] = (v2 - v3 * mul3) * dpix_median;
-                            g[11] = (v6 - v7 * mul3) * dpix_median;
-                            g[12] = (v10 - v11 * mul3) * dpix_median;
-                            mid_once = false;
-                        }
-                        if (DO_POSE) g[13] = dL_ddepth;
-                    } else {
-                        g[0] = gmx;
-                        g[1] = gmy;
-                        g[2] = dL_ddepth;
+                    qq = q1[u].y * dL_dalpha * G;
+                    if (DO_MAP && T > 0.5f && mid_once) {  // backward.cu:654-664: once per pixel, straight to LDS
+                        const float* mg = a.means3D + 3 * (size_t)s.id[j];
+                        const float mul3 = v2 * mg[0] + v6 * mg[1] + v10 * mg[2] + v14;
+                        atomicAdd(&sb.acc[10 * ACC_LD + j], (v2 - v3 * mul3) * dpix_median);
+                        atomicAdd(&sb.acc[11 * ACC_LD + j], (v6 - v7 * mul3) * dpix_median);
+                        atomicAdd(&sb.acc[12 * ACC_LD + j], (v10 - v11 * mul3) * dpix_median);
+                        mid_once = false;
                     }
                 }
+                // gradient contributions as products of (w, qq) with per-lane / per-Gaussian factors.  The unscaled
+                // conic is recovered from the staged one: a = a2 * (-2 ln 2), b = b2 * (-ln 2), c = c2 * (-2 ln 2)
+                constexpr float LN2 = 0.6931471805599453f;
+                const float ca = q0[u].z * (-2.f * LN2), cb = q0[u].w * (-LN2), cc = q1[u].x * (-2.f * LN2);
+                const float qdx = qq * dx, qdy = qq * dy;
+                const float gmx = -(ca * qdx + cb * qdy) * ddelx_dx;  // dL_dG * dG_ddelx * ddelx_dx
+                const float gmy = -(cc * qdy + cb * qdx) * ddely_dy;
+                const float wd = w * dpix_depth;
                 float tot;
                 if (DO_MAP) {
-                    tot = wave_reduce16(g, lane);
+                    float g[12];
+                    g[0] = w * dpix0;
+                    g[1] = w * dpix1;
+                    g[2] = w * dpix2;
+                    g[3] = wd + dpix_var * w * 2.f * e;
+                    g[4] = gmx;
+                    g[5] = gmy;
+                    g[6] = -0.5f * qdx * dx;
+                    g[7] = -0.5f * qdx * dy;
+                    g[8] = -0.5f * qdy * dy;
+                    g[9] = qq * __builtin_amdgcn_rcpf(q1[u].y);
+                    g[10] = DO_POSE ? wd : 0.f;  // -> accumulator component 13
+                    g[11] = 0.f;
+                    tot = wave_reduce12(g, lane);
                 } else {
-                    float g4[4] = {g[0], g[1], g[2], 0.f};
+                    float g4[4] = {gmx, gmy, wd, 0.f};
                     tot = wave_reduce4(g4);
                 }
                 // j is wave-uniform here (every lane read the same record)
@@ -325,7 +321,13 @@ __global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, f
 #pragma unroll
     for (int k = 0; k < 16; k++) g[k] = in[k * 64 + lane];
     float g4[4] = {g[0], g[1], g[2], g[3]};
-    out16[lane] = wave_reduce16(g, lane);
+    float g12[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) g12[k] = g[k];
+    const float r12 = wave_reduce12(g12, lane);
+    const float r16 = wave_reduce16(g, lane);
+    // out16: lanes whose component is < 12 must agree between the 12- and 16-value networks; report a mismatch as NaN
+    out16[lane] = (wave_reduce16_comp(lane) < 12 && r12 != r16) ? __builtin_nanf("") : r16;
     out4[lane] = wave_reduce4(g4);
     comp16[lane] = wave_reduce16_comp(lane);
     comp4[lane] = wave_reduce4_comp(lane);

@@ -59,6 +59,26 @@ __device__ __forceinline__ float wave_reduce16(float (&x)[16], int lane) {
     return u;
 }
 
+// Same network for 12 values (x[0..11]): 27 instructions.  Lane quads whose wave_reduce16_comp() is >= 12 hold garbage.
+__device__ __forceinline__ float wave_reduce12(float (&x)[12], int lane) {
+    asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) DGR_SWAP32(2, 3) DGR_SWAP32(4, 5) DGR_SWAP32(6, 7) DGR_SWAP32(8, 9)
+                 DGR_SWAP32(10, 11)
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                   "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
+    float y0 = x[0] + x[1], y1 = x[2] + x[3], y2 = x[4] + x[5], y3 = x[6] + x[7], y4 = x[8] + x[9], y5 = x[10] + x[11];
+    asm volatile("s_nop 1\n\t" DGR_SWAP16(0, 1) DGR_SWAP16(2, 3) DGR_SWAP16(4, 5)
+                 : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5));
+    const float z0 = y0 + y1, z1 = y2 + y3, z2 = y4 + y5;
+    const float a0 = z0 + dpp_mov<DPP_ROW_MIRROR>(z0), b0 = z1 + dpp_mov<DPP_ROW_MIRROR>(z1);
+    const float t1 = z2 + dpp_mov<DPP_ROW_MIRROR>(z2);  // upper half rows would carry values 12..15: unused
+    const float t0 = (lane & 8) ? b0 : a0;
+    const float c0 = t0 + dpp_mov<DPP_ROW_HALF_MIRROR>(t0), c1 = t1 + dpp_mov<DPP_ROW_HALF_MIRROR>(t1);
+    float u = (lane & 4) ? c1 : c0;
+    u += dpp_mov<DPP_QUAD_XOR1>(u);
+    u += dpp_mov<DPP_QUAD_XOR2>(u);
+    return u;
+}
+
 // x[0..3] per lane -> total of value {0,2,1,3}[lane >> 4] in every lane of that 16-lane row (10 instructions).
 __device__ __forceinline__ int wave_reduce4_comp(int lane) {
     const int r = lane >> 4;
