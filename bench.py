@@ -46,10 +46,12 @@ def algorithmic_bytes(stage, P, V, R, N, M):
     sh = 12 * M
     table = {
         # means 12 + scales 12 + rot 16 + opacity 4 in; radii 4 + rect 8 out; SH in, record 48 + depth 4 +
-        # cov3D 24 + clamp 1 out per visible Gaussian; one 4-B histogram RMW per instance
-        "preprocess_fwd": 44 * P + 12 * P + (sh + 77) * V + 4 * R,
+        # cov3D 24 + clamp 1 out per visible Gaussian
+        "preprocess_fwd": 44 * P + 12 * P + (sh + 77) * V,
+        "scan_blocks": 0,
+        "count_rank": 8 * P + 4 * P + 8 * R,              # rect in, offset out; one 4-B histogram RMW + one 4-B rank per instance
         "scan_tiles": 0,
-        "emit_instances": 8 * P + 4 * V + 8 * R,          # rect + depth in, one 8-B key out per instance
+        "emit_instances": 12 * P + 4 * V + 12 * R,        # rect + offset + depth in; rank in, one 8-B key out per instance
         "sort_tiles": 8 * R + 12 * R,                      # keys in; sorted keys + point_list out
         "render_fwd_light": 4 * R + 48 * R + 36 * N,       # id + record per instance; gt in, 7 images + n_contrib out
         "zero_scratch": 64 * P,

@@ -43,9 +43,10 @@ struct StageProf {
     bool on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
-StageProf g_prof[] = {{"preprocess_fwd"}, {"scan_tiles"}, {"emit_instances"}, {"sort_tiles"}, {"render_fwd_light"},
-                      {"zero_scratch"}, {"render_bwd_light"}, {"preprocess_bwd"}};
-enum { ST_PRE_FWD, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD, ST_ZERO, ST_RENDER_BWD, ST_PRE_BWD, ST_COUNT };
+StageProf g_prof[] = {{"preprocess_fwd"}, {"scan_blocks"}, {"count_rank"}, {"scan_tiles"}, {"emit_instances"}, {"sort_tiles"},
+                      {"render_fwd_light"}, {"zero_scratch"}, {"render_bwd_light"}, {"preprocess_bwd"}};
+enum { ST_PRE_FWD, ST_SCAN_BLOCKS, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD, ST_ZERO, ST_RENDER_BWD, ST_PRE_BWD,
+       ST_COUNT };
 std::mutex g_prof_mu;
 
 struct ScopedStage {
@@ -90,8 +91,8 @@ int zero_outputs(const FwdCommon& c, hipStream_t st) {
     return DGR_OK;
 }
 
-// preprocess + tile scan; afterwards img.status[0] = num_rendered, ranges are final
-int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, int capacity, hipStream_t st) {
+// preprocess; afterwards geom.block_tiles holds the instance totals per 256-Gaussian block
+int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, hipStream_t st) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
     // status, tile_count and tile_fill are adjacent: one memset
     HIP_TRY(hipMemsetAsync(img.status, 0, (char*)img.ranges - (char*)img.status, st));
@@ -107,19 +108,29 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
     a.focal_x = c.W / (2.0f * c.tan_fovx);
     a.prefiltered = c.prefiltered;
     a.sh_vec_ok = aligned16(c.shs);
-    a.geom = geom; a.radii_out = c.radii; a.tile_count = img.tile_count; a.status = img.status;
+    a.geom = geom; a.radii_out = c.radii; a.status = img.status;
     { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd(a, st)); }
+    (void)tiles;
+    // per-block instance totals -> exclusive prefix; status[0] = num_rendered
+    { ScopedStage t(ST_SCAN_BLOCKS, st); HIP_TRY(dgr::launch_scan_blocks(c.P, geom, img, st)); }
+    return DGR_OK;
+}
+
+// histogram + ranks, range table (status[0] = num_rendered, status[1] = overflow), key scatter, per-tile sort
+int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, int capacity,
+                   hipStream_t st) {
+    const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
+    { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_rank(c.P, geom, img, bin, gx, capacity, st)); }
     { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, capacity, st)); }
+    { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
+    { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
     return DGR_OK;
 }
 
 int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, bool have_instances,
                  hipStream_t st) {
-    const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
-    if (have_instances) {
-        { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
-        { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
-    }
+    const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
+    (void)have_instances;
     dgr::RenderFwdLightArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
     r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background; r.gt_depth = c.gt_depth;
@@ -133,11 +144,8 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
 // ---- full variant: same front end, different blend
 int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryView geom, dgr::ImageView img,
                       dgr::BinningView bin, bool have_instances, hipStream_t st) {
-    const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
-    if (have_instances) {
-        { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
-        { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
-    }
+    const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
+    (void)have_instances;
     dgr::RenderFwdFullArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
     r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background;
@@ -189,11 +197,11 @@ __global__ void export_geom_kernel(int kind, int P, dgr::GeometryView g, void* d
     }
 }
 // the reference's sorted 64-bit keys: tile id << 32 | depth bits (rasterizer_impl.cu:97-100)
-__global__ void export_keys_kernel(dgr::ImageView img, dgr::BinningView bin, uint64_t* dst) {
+__global__ void export_keys_kernel(dgr::ImageView img, dgr::BinningView bin, dgr::GeometryView g, uint64_t* dst) {
     const int tile = blockIdx.x;
     const uint2 rg = img.ranges[tile];
     for (uint32_t i = rg.x + threadIdx.x; i < rg.y; i += blockDim.x)
-        dst[i] = ((uint64_t)tile << 32) | (bin.keys[i] >> 32);
+        dst[i] = ((uint64_t)tile << 32) | __float_as_uint(g.depths[bin.point_list[i]]);
 }
 
 }  // namespace
@@ -236,7 +244,8 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     dgr::GeometryView geom = dgr::carve_geometry(geometry_buffer, P);
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
-    if ((rc = forward_front(c, geom, img, binning_capacity, st))) return rc;
+    if ((rc = forward_front(c, geom, img, st))) return rc;
+    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
     if ((rc = forward_back(c, geom, img, bin, binning_capacity > 0, st))) return rc;
     if (status) HIP_TRY(hipMemcpyAsync(status, img.status, 16, hipMemcpyDeviceToDevice, st));
     return DGR_OK;
@@ -263,7 +272,7 @@ int dgr_light_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bi
     if (!gptr || !iptr) { g_last_error = "allocation callback returned NULL"; return DGR_ERR_ALLOC; }
     dgr::GeometryView geom = dgr::carve_geometry(gptr, P);
     dgr::ImageView img = dgr::carve_image(iptr, width, height);
-    if ((rc = forward_front(c, geom, img, INT_MAX, st))) return rc;
+    if ((rc = forward_front(c, geom, img, st))) return rc;
     // the one blocking read the reference also has (rasterizer_impl.cu:287): num_rendered sizes the binning buffer
     int status[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(status, img.status, sizeof(status), hipMemcpyDeviceToHost, st));
@@ -278,6 +287,7 @@ int dgr_light_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bi
         binningBuffer(0, alloc_user);
     }
     dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
+    if ((rc = binning_stages(c, geom, img, bin, R, st))) return rc;  // also with R == 0: it writes the (empty) range table
     if ((rc = forward_back(c, geom, img, bin, R > 0, st))) return rc;
     if (debug) HIP_TRY(hipStreamSynchronize(st));  // CHECK_CUDA(..., debug): L/cuda_rasterizer/auxiliary.h:166-173
     return R;
@@ -356,7 +366,8 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     dgr::GeometryView geom = dgr::carve_geometry(geometry_buffer, P);
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
-    if ((rc = forward_front(c, geom, img, binning_capacity, st))) return rc;
+    if ((rc = forward_front(c, geom, img, st))) return rc;
+    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, binning_capacity > 0, st))) return rc;
     if (status) HIP_TRY(hipMemcpyAsync(status, img.status, 16, hipMemcpyDeviceToDevice, st));
     return DGR_OK;
@@ -382,7 +393,7 @@ int dgr_full_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bin
     if (!gptr || !iptr) { g_last_error = "allocation callback returned NULL"; return DGR_ERR_ALLOC; }
     dgr::GeometryView geom = dgr::carve_geometry(gptr, P);
     dgr::ImageView img = dgr::carve_image(iptr, width, height);
-    if ((rc = forward_front(c, geom, img, INT_MAX, st))) return rc;
+    if ((rc = forward_front(c, geom, img, st))) return rc;
     int status[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(status, img.status, sizeof(status), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));  // first blocking read of the reference (F/cuda_rasterizer/rasterizer_impl.cu:435)
@@ -396,6 +407,7 @@ int dgr_full_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bin
         binningBuffer(0, alloc_user);
     }
     dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
+    if ((rc = binning_stages(c, geom, img, bin, R, st))) return rc;  // also with R == 0: it writes the (empty) range table
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, R > 0, st))) return rc;
     if (num_related_primitives) {  // second blocking read of the reference (:498)
         HIP_TRY(hipMemcpyAsync(status, img.status, sizeof(status), hipMemcpyDeviceToHost, st));
@@ -527,7 +539,7 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
     if (n == "tiles_touched") return geomk(EX_TILES_TOUCHED) ? -1 : P;
     if (n == "point_list") return copy(bin.point_list, 4 * (size_t)num_rendered) ? -1 : num_rendered;
     if (n == "keys") {
-        hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)tiles), dim3(256), 0, st, img, bin, (uint64_t*)dst);
+        hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)tiles), dim3(256), 0, st, img, bin, g, (uint64_t*)dst);
         if (hipGetLastError() != hipSuccess) return -1;
         return num_rendered;
     }

@@ -6,14 +6,19 @@
 // 283-323).  The reference sorts all R instances globally on (tile id, depth bits) with a STABLE
 // radix sort whose input is in ascending Gaussian order, so its result is the unique ascending
 // order on the triple (tile id, depth bits, gaussian id).  Here the tile id never enters a key:
-//   1. preprocess already histogrammed instances per tile (tile_count);
+//   1. count_rank histograms instances per tile with ONE returning atomic per instance and keeps the returned
+//      arrival rank, stored Gaussian-major at the Gaussian's instance offset (block base + in-block scan of
+//      tiles_touched: the reference's point_offsets without a device-wide scan kernel);
 //   2. scan_tiles turns the histogram into the range table (this IS identifyTileRanges' output);
-//   3. emit_instances drops (depth bits << 32 | gaussian id) keys into their tile's segment in
-//      arbitrary order (one returning atomic per instance);
-//   4. sort_tiles sorts each segment in LDS -- a total order on unique keys, hence the same
-//      point_list as the reference bit for bit.
-// HBM traffic: 8 B written + 8 B read + 12 B written per instance, against ~6 radix passes x 24 B
-// in the reference.
+//   3. emit_instances writes (depth bits << 32 | gaussian id) to slot range.start + rank: a plain scatter.
+//      Instance order inside a tile segment is arbitrary, which is irrelevant because
+//   4. sort_tiles sorts each segment in LDS -- a total order on unique keys, hence the same point_list as the
+//      reference bit for bit.
+// Atomics are the scarce resource here: MI355X retires ~26 G global atomic operations/s regardless of scope,
+// address spread or whether a value is returned (profiles/microbench/atomics.hip), i.e. ~63 us per 1.65 M; an
+// earlier version paid that twice (histogram in preprocess, slot allocation in emit).
+// HBM traffic: 4 B + 8 B written, 4 B + 8 B read, 12 B written per instance, against ~6 radix passes x 24 B in
+// the reference.
 #include "dgr_common.h"
 #include "kernels.h"
 
@@ -22,6 +27,7 @@ namespace {
 
 constexpr int SCAN_THREADS = 1024;
 constexpr int SORT_THREADS = 256;
+constexpr int COUNT_STAGE = 4096;   // ranks staged per 256-Gaussian block in count_rank (16 KB)
 constexpr int SORT_LDS_MAX = 4096;  // keys per tile sorted in LDS (32 KB); larger tiles sort in global memory
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img, int tiles, int capacity) {
@@ -46,13 +52,98 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img,
     for (int i = lo; i < hi; i++) {
         const uint32_t c = img.tile_count[i];
         img.ranges[i] = overflow ? make_uint2(0u, 0u) : make_uint2(run, run + c);
-        img.tile_fill[i] = 0u;
         run += c;
     }
     if (t == 0) {
         img.status[0] = (int)total;
         img.status[1] = overflow ? 1 : 0;
     }
+}
+
+// One thread per Gaussian.  offset = (instances of all earlier 256-Gaussian blocks, from scan_blocks_kernel) +
+// (exclusive scan inside this block).
+__global__ void __launch_bounds__(256) count_rank_kernel(int P, GeometryView geom, ImageView img, BinningView bin,
+                                                         int grid_x, int capacity) {
+    __shared__ uint32_t wtot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * 256 + tid;
+    // ---- in-block exclusive scan of tiles_touched (block base: scan_blocks_kernel's exclusive prefix)
+    ushort4 r = make_ushort4(0, 0, 0, 0);
+    if (idx < P) r = geom.rect[idx];
+    const uint32_t n = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t base = geom.block_tiles[blockIdx.x];
+    for (int ww = 0; ww < wave; ww++) base += wtot[ww];
+    const uint32_t block_base = geom.block_tiles[blockIdx.x];
+    const uint32_t block_total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    const uint32_t off0 = base + incl - n;
+    if (idx < P) geom.goff[idx] = off0;
+    // Ranks of one block are contiguous in the output: stage them in LDS and write them out coalesced (the per-thread
+    // 4-byte stores of the direct form are scattered).  Blocks with more instances than the stage holds, and
+    // anything past the capacity, take the direct path / are only counted.
+    __shared__ uint32_t stage[COUNT_STAGE];
+    const bool staged = block_total <= (uint32_t)COUNT_STAGE;
+    const bool store = off0 + n <= (uint32_t)capacity;  // past the capacity an instance is still counted, so that
+                                                        // scan_tiles sees the true total and flags the overflow
+    const uint32_t loc = off0 - block_base;
+    const uint32_t w = (uint32_t)(r.z - r.x);
+    // four returning atomics in flight per thread
+    for (uint32_t k = 0; k < n; k += 4) {
+        uint32_t rank[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t kk = k + u;
+            if (kk < n) {
+                const uint32_t yy = kk / w, xx = kk - yy * w;  // row-major over the rect, as duplicateWithKeys enumerates
+                rank[u] = atomicAdd(&img.tile_count[(r.y + yy) * grid_x + r.x + xx], 1u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (k + u < n) {
+                if (staged) stage[loc + k + u] = rank[u];
+                else if (store) bin.ranks[off0 + k + u] = rank[u];
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        const uint32_t lim = (block_base >= (uint32_t)capacity) ? 0u : min(block_total, (uint32_t)capacity - block_base);
+        for (uint32_t i = tid; i < lim; i += 256) bin.ranks[block_base + i] = stage[i];
+    }
+}
+
+// In-place exclusive scan of the per-block instance totals (P/256 values, one 1024-thread block); the grand total
+// = num_rendered goes to status[0] (the callback entry points read it before sizing the binning buffer).
+__global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* block_tiles, int nblocks, int* status) {
+    __shared__ uint32_t part[SCAN_THREADS];
+    const int t = threadIdx.x;
+    const int per = (nblocks + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = min(t * per, nblocks), hi = min(lo + per, nblocks);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += block_tiles[i];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        uint32_t v = (t >= off) ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int i = lo; i < hi; i++) {
+        const uint32_t c = block_tiles[i];
+        block_tiles[i] = run;
+        run += c;
+    }
+    if (t == 0) status[0] = (int)part[SCAN_THREADS - 1];
 }
 
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, GeometryView geom, ImageView img, BinningView bin,
@@ -63,49 +154,43 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, GeometryView
     const ushort4 r = geom.rect[idx];
     if (r.z <= r.x || r.w <= r.y) return;
     const uint64_t key = ((uint64_t)__float_as_uint(geom.depths[idx]) << 32) | (uint32_t)idx;
+    const uint32_t* rk = bin.ranks + geom.goff[idx];
     for (int y = r.y; y < r.w; y++)
-        for (int x = r.x; x < r.z; x++) {
-            const int tile = y * grid_x + x;
-            const uint32_t slot = img.ranges[tile].x + atomicAdd(&img.tile_fill[tile], 1u);
-            bin.keys[slot] = key;
-        }
+        for (int x = r.x; x < r.z; x++) bin.keys[img.ranges[y * grid_x + x].x + *rk++] = key;
 }
 
-// All-ascending bitonic network ("flip" then "disperse" steps).  Every comparator moves the smaller
-// key to the lower index, so indices >= n behave as +inf padding and comparators that touch them are
-// skipped: no power-of-two padding is materialised.
-template <typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort(KeyPtr k, int n, int tid) {
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    const int half = np2 >> 1;
-    for (int size = 2; size <= np2; size <<= 1) {
-        // flip: i in the lower half of its `size` block pairs with the mirrored index
-        {
-            const int hs = size >> 1;
-            for (int t = tid; t < half; t += SORT_THREADS) {
-                const int blk = t / hs, off = t - blk * hs;
-                const int i = blk * size + off, j = blk * size + (size - 1 - off);
-                if (j < n) {
-                    const uint64_t a = k[i], b = k[j];
-                    if (a > b) { k[i] = b; k[j] = a; }
-                }
-            }
-            __syncthreads();
-        }
-        for (int d = size >> 2; d > 0; d >>= 1) {
-            for (int t = tid; t < half; t += SORT_THREADS) {
-                const int blk = t / d, off = t - blk * d;
-                const int i = blk * 2 * d + off, j = i + d;
-                if (j < n) {
-                    const uint64_t a = k[i], b = k[j];
-                    if (a > b) { k[i] = b; k[j] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    }
+// ---- per-tile sort ------------------------------------------------------------------------------
+// All-ascending bitonic network ("flip" then "disperse" steps): every comparator moves the smaller key to the
+// lower index, so +inf padding never moves and the network sorts any n <= np2.
+// gfx950 shape: a wave sorts a 64-key chunk entirely in registers -- one key per lane, partner exchange with
+// __shfl_xor (ds_bpermute: the LDS crossbar, no bank conflicts, no barrier): all 21 steps of sizes 2..64.  Larger
+// merge stages do their cross-wave steps (distance >= 64) on the LDS array with a barrier each, then return to
+// registers for distances 32..1.  n = 256 costs 7 barriers instead of the 36 of a plain LDS network.
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
 }
+__device__ __forceinline__ uint64_t cmpx(uint64_t v, int lane, int mask, int lowbit) {
+    const uint64_t o = shfl_xor64(v, mask);
+    const bool lower = (lane & lowbit) == 0;  // this lane holds the lower index of the pair
+    return (lower == (v < o)) ? v : o;         // lower keeps the minimum, upper the maximum
+}
+__device__ __forceinline__ uint64_t chunk_sort64(uint64_t v, int lane) {
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1) {
+        v = cmpx(v, lane, size - 1, size >> 1);  // flip: partner = lane ^ (size-1); lower half has bit size/2 clear
+#pragma unroll
+        for (int d = size >> 2; d > 0; d >>= 1) v = cmpx(v, lane, d, d);
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t chunk_tail64(uint64_t v, int lane) {  // disperse steps 32..1
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = cmpx(v, lane, d, d);
+    return v;
+}
+
+constexpr uint64_t KEY_INF = ~0ull;
 
 __global__ void __launch_bounds__(SORT_THREADS) sort_tiles_kernel(ImageView img, BinningView bin) {
     __shared__ uint64_t sk[SORT_LDS_MAX];
@@ -115,27 +200,86 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_tiles_kernel(ImageView img,
     if (n <= 0) return;
     uint64_t* gk = bin.keys + rg.x;
     uint32_t* pl = bin.point_list + rg.x;
-    const int tid = threadIdx.x;
-    if (n <= SORT_LDS_MAX) {
-        for (int i = tid; i < n; i += SORT_THREADS) sk[i] = gk[i];
-        __syncthreads();
-        bitonic_sort(sk, n, tid);
-        for (int i = tid; i < n; i += SORT_THREADS) {
-            const uint64_t v = sk[i];
-            gk[i] = v;
-            pl[i] = (uint32_t)v;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n > SORT_LDS_MAX) {  // oversize tile: same network, in place in global memory, one barrier per step
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        const int half = np2 >> 1;
+        for (int size = 2; size <= np2; size <<= 1) {
+            const int hs = size >> 1;
+            for (int t = tid; t < half; t += SORT_THREADS) {
+                const int blk = t / hs, off = t - blk * hs;
+                const int i = blk * size + off, j = blk * size + (size - 1 - off);
+                if (j < n) { const uint64_t x = gk[i], y = gk[j]; if (x > y) { gk[i] = y; gk[j] = x; } }
+            }
+            __syncthreads();
+            for (int d = size >> 2; d > 0; d >>= 1) {
+                for (int t = tid; t < half; t += SORT_THREADS) {
+                    const int blk = t / d, off = t - blk * d;
+                    const int i = blk * 2 * d + off, j = i + d;
+                    if (j < n) { const uint64_t x = gk[i], y = gk[j]; if (x > y) { gk[i] = y; gk[j] = x; } }
+                }
+                __syncthreads();
+            }
         }
-    } else {
-        __syncthreads();
-        bitonic_sort(gk, n, tid);
         for (int i = tid; i < n; i += SORT_THREADS) pl[i] = (uint32_t)gk[i];
+        return;
     }
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    const int chunks = np2 >> 6;
+    // load + phase A: every 64-chunk sorted in registers
+    for (int c = wave; c < chunks; c += 4) {
+        const int e = c * 64 + lane;
+        uint64_t v = (e < n) ? gk[e] : KEY_INF;
+        sk[e] = chunk_sort64(v, lane);
+    }
+    __syncthreads();
+    const int half = np2 >> 1;
+    for (int size = 128; size <= np2; size <<= 1) {
+        {  // flip across the `size` block (distance >= 64 for every pair once the chunks are sorted ... not always:
+           // pairs i <-> blk*size + size-1-off span all distances, so this step runs on the LDS array)
+            const int hs = size >> 1;
+            for (int t = tid; t < half; t += SORT_THREADS) {
+                const int blk = t / hs, off = t - blk * hs;
+                const int i = blk * size + off, j = blk * size + (size - 1 - off);
+                const uint64_t x = sk[i], y = sk[j];
+                if (x > y) { sk[i] = y; sk[j] = x; }
+            }
+            __syncthreads();
+        }
+        for (int d = size >> 2; d >= 64; d >>= 1) {
+            for (int t = tid; t < half; t += SORT_THREADS) {
+                const int blk = t / d, off = t - blk * d;
+                const int i = blk * 2 * d + off, j = i + d;
+                const uint64_t x = sk[i], y = sk[j];
+                if (x > y) { sk[i] = y; sk[j] = x; }
+            }
+            __syncthreads();
+        }
+        for (int c = wave; c < chunks; c += 4) {
+            const int e = c * 64 + lane;
+            sk[e] = chunk_tail64(sk[e], lane);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += SORT_THREADS) pl[i] = (uint32_t)sk[i];
 }
 
 }  // namespace
 
 hipError_t launch_scan_tiles(ImageView img, int tiles, int capacity, hipStream_t stream) {
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, img, tiles, capacity);
+    return hipGetLastError();
+}
+hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,
+                             hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    hipLaunchKernelGGL(count_rank_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom, img, bin, grid_x, capacity);
+    return hipGetLastError();
+}
+hipError_t launch_scan_blocks(int P, GeometryView geom, ImageView img, hipStream_t stream) {
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, geom.block_tiles, (P + 255) / 256, img.status);
     return hipGetLastError();
 }
 hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream) {

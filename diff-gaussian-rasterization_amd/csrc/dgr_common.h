@@ -6,7 +6,7 @@
 //   geometry : one 48-byte render record per Gaussian (3 x float4, gathered as whole 16-B
 //              pieces by the blend kernels), depth, radius, cov3D, tile rect (4 x u16), clamp bits
 //   image    : per-tile {count, fill, range} + per-pixel n_contrib (+ full: final T, n_valid)
-//   binning  : per-instance 64-bit sort keys (depth bits << 32 | gaussian id) and the sorted id list
+//   binning  : per-instance 64-bit sort keys (depth bits << 32 | gaussian id), the sorted id list, arrival ranks
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,6 +31,10 @@ struct GeometryView {
     float* cov3D;       // [6P]
     ushort4* rect;      // [P] {xmin, ymin, xmax, ymax} in tiles; all-zero when culled
     uint8_t* clamped;   // [P] bit c set <=> channel c was clamped at 0
+    uint32_t* goff;     // [P] index of the Gaussian's first instance in Gaussian-major order (the reference's
+                        //     point_offsets, exclusive form); written by count_rank
+    uint32_t* block_tiles;  // [ceil(P/256)] instances produced by each 256-Gaussian block of preprocess; turned into its
+                            //     exclusive prefix in place by scan_blocks
     size_t bytes;
 };
 __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
@@ -42,6 +46,8 @@ __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
     g.cov3D = (float*)(base + o);     o = align_up(o + sizeof(float) * 6 * (size_t)P, 256);
     g.rect = (ushort4*)(base + o);    o = align_up(o + sizeof(ushort4) * (size_t)P, 256);
     g.clamped = (uint8_t*)(base + o); o = align_up(o + (size_t)P, 256);
+    g.goff = (uint32_t*)(base + o);   o = align_up(o + sizeof(uint32_t) * (size_t)P, 256);
+    g.block_tiles = (uint32_t*)(base + o); o = align_up(o + sizeof(uint32_t) * (((size_t)P + 255) / 256), 256);
     g.bytes = o;
     return g;
 }
@@ -78,7 +84,8 @@ __host__ __device__ inline ImageView carve_image(char* base, int W, int H) {
 struct BinningView {
     uint32_t* point_list;  // [cap] sorted gaussian ids (binningState.point_list); at offset 0 so that the
                            //       backward can find it without knowing the capacity
-    uint64_t* keys;        // [cap] (depth bits << 32 | gaussian id), grouped by tile, sorted in place
+    uint64_t* keys;        // [cap] (depth bits << 32 | gaussian id), grouped by tile, unsorted (sort_tiles reads them)
+    uint32_t* ranks;       // [cap] Gaussian-major: arrival rank of each instance within its tile (count_rank -> emit)
     size_t bytes;
 };
 __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
@@ -86,6 +93,7 @@ __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
     size_t o = 0;
     b.point_list = (uint32_t*)(base + o); o = align_up(o + 4 * cap, 256);
     b.keys = (uint64_t*)(base + o);       o = align_up(o + 8 * cap, 256);
+    b.ranks = (uint32_t*)(base + o);      o = align_up(o + 4 * cap, 256);
     b.bytes = o;
     return b;
 }

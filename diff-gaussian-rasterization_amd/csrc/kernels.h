@@ -22,7 +22,6 @@ struct PreprocessFwdArgs {
     bool sh_vec_ok;
     GeometryView geom;
     int* radii_out;        // caller's radii tensor (may be NULL)
-    uint32_t* tile_count;  // zeroed before launch
     int* status;
 };
 
@@ -134,6 +133,9 @@ hipError_t launch_mark_visible(int P, const float* means, const float* view, uin
 
 // binning: tile_count -> ranges (+ total in status[0], overflow in status[1]); emit keys; sort tiles
 hipError_t launch_scan_tiles(ImageView img, int tiles, int capacity, hipStream_t stream);
+hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,
+                             hipStream_t stream);
+hipError_t launch_scan_blocks(int P, GeometryView geom, ImageView img, hipStream_t stream);
 hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream);
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);
 

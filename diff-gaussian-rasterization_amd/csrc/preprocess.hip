@@ -152,10 +152,9 @@ __device__ __forceinline__ M3 diag3(float a, float b, float c) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-
     int radius = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
+    if (idx < a.P) {
     const float3 p_orig = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
 
     // in_frustum (cuda_rasterizer/auxiliary.h:139-164)
@@ -242,17 +241,23 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
                 rec[0] = make_float4(pix, piy, p_view.z, a.opacities[idx]);
                 rec[1] = make_float4(conic.x, conic.y, conic.z, 0.0f);
                 rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
-                // per-tile histogram: replaces tiles_touched + the scan over P; the order in which
-                // instances later land inside a tile segment is irrelevant because every segment is
-                // sorted on (depth bits, gaussian id).
-                for (int y = y0; y < y1; y++)
-                    for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.grid_x + x], 1u);
             }
         }
     }
     a.geom.radii[idx] = radius;
     if (a.radii_out) a.radii_out[idx] = radius;
     a.geom.rect[idx] = rect;
+    }  // idx < P
+
+    // instances (tiles_touched) of this block, for count_rank's offsets (the reference scans tiles_touched over P,
+    // L/cuda_rasterizer/rasterizer_impl.cu:283)
+    __shared__ uint32_t wsum[4];
+    uint32_t n = (uint32_t)(rect.z - rect.x) * (uint32_t)(rect.w - rect.y);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) a.geom.block_tiles[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // ------------------------------------------------------------------------------------------------

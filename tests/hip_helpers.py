@@ -70,7 +70,7 @@ def binning_capacity(d, W, H):
     capacity and equal sizes imply equal sub-array offsets, so any capacity that reproduces the size will do."""
     lib = _capi.load()
     nbytes = d["binning"].numel()
-    lo, hi = 0, nbytes // 12 + 1
+    lo, hi = 0, nbytes // 16 + 2
     while lo < hi:
         mid = (lo + hi) // 2
         if lib.dgr_binning_bytes(mid, W, H) >= nbytes:
@@ -78,7 +78,9 @@ def binning_capacity(d, W, H):
         else:
             lo = mid + 1
     assert lib.dgr_binning_bytes(lo, W, H) == nbytes or nbytes <= 1, (lo, nbytes)
-    return lo
+    # alignment padding can make several capacities share one size (and hence one layout): never report less than R
+    R = d["num_rendered"]
+    return lo if lo >= R else R
 
 
 def hip_backward(s, deg, out, colors_precomp=None, cov3D_precomp=None, track_off=False, map_off=False,
