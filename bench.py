@@ -88,7 +88,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DGR_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -114,7 +114,7 @@ def main():
     gC, gD, gM, gV = t(s.gC), t(s.gD[None]), t(s.gM[None]), t(s.gV[None])
     rast = GaussianRasterizer(make_settings(s, deg, dev))
     params = [means3D, means2D, shs, opac, scales, rots]
-    arena = GradientArena(params) if world > 1 else None
+    arena = GradientArena(params) if dist is not None else None
 
     def step():
         for p_ in params + [view]:
