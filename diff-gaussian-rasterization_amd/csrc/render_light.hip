@@ -197,9 +197,11 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
         gt_px = a.gt_depth[pix_id];
     }
     const float bg_dot_dpixel = a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_depth = 0.f, acc_var = 0.f;  // accum_rec*
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f, last_var = 0.f;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
+    // The reference keeps five "accumulated behind me" recurrences (3 colours, depth, variance: backward.cu:580-608)
+    // only to form dL/dalpha = sum_c (c_j - accum_rec_c) dL/dpixel_c.  They are linear, so one scalar suffices:
+    //   X_j = <features_j, dL/dpixel>,   S <- alpha_last X_last + (1 - alpha_last) S,   dL/dalpha = X_j - S.
+    float S = 0.f, X_last = 0.f, last_alpha = 0.f;
     bool mid_once = true;
     const float v2 = a.view[2], v3 = a.view[3], v6 = a.view[6], v7 = a.view[7], v10 = a.view[10], v11 = a.view[11],
                 v14 = a.view[14];
@@ -249,20 +251,11 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     T = T * inv;
                     w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
-                    // colour / depth / variance recurrences (backward.cu:580-608)
-                    const float om = 1.f - last_alpha;
-                    acc0 = last_alpha * lc0 + om * acc0; lc0 = cd.x;
-                    acc1 = last_alpha * lc1 + om * acc1; lc1 = cd.y;
-                    acc2 = last_alpha * lc2 + om * acc2; lc2 = cd.z;
-                    float dL_dalpha = (cd.x - acc0) * dpix0 + (cd.y - acc1) * dpix1 + (cd.z - acc2) * dpix2;
-                    const float c_d = cd.w;
-                    e = c_d - gt_px;
-                    const float c_var = e * e;
-                    acc_depth = last_alpha * last_depth + om * acc_depth; last_depth = c_d;
-                    acc_var = last_alpha * last_var + om * acc_var; last_var = c_var;
-                    dL_dalpha += (c_d - acc_depth) * dpix_depth;
-                    dL_dalpha += (c_var - acc_var) * dpix_var;
-                    dL_dalpha *= T;
+                    e = cd.w - gt_px;
+                    const float X = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2 + cd.w * dpix_depth + (e * e) * dpix_var;
+                    S = last_alpha * X_last + (1.f - last_alpha) * S;
+                    X_last = X;
+                    float dL_dalpha = (X - S) * T;
                     last_alpha = alpha;
                     dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
                     qq = q1[u].y * dL_dalpha * G;
@@ -275,13 +268,9 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                         mid_once = false;
                     }
                 }
-                // gradient contributions as products of (w, qq) with per-lane / per-Gaussian factors.  The unscaled
-                // conic is recovered from the staged one: a = a2 * (-2 ln 2), b = b2 * (-ln 2), c = c2 * (-2 ln 2)
-                constexpr float LN2 = 0.6931471805599453f;
-                const float ca = q0[u].z * (-2.f * LN2), cb = q0[u].w * (-LN2), cc = q1[u].x * (-2.f * LN2);
+                // Per-lane contributions are the raw moments of qq over the pixel offsets; the factors that depend on the
+                // Gaussian only (conic, 1/opacity, the ndc scale) are applied once per (tile, Gaussian) in finish_rows().
                 const float qdx = qq * dx, qdy = qq * dy;
-                const float gmx = -(ca * qdx + cb * qdy) * ddelx_dx;  // dL_dG * dG_ddelx * ddelx_dx
-                const float gmy = -(cc * qdy + cb * qdx) * ddely_dy;
                 const float wd = w * dpix_depth;
                 float tot;
                 if (DO_MAP) {
@@ -290,17 +279,17 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                     g[1] = w * dpix1;
                     g[2] = w * dpix2;
                     g[3] = wd + dpix_var * w * 2.f * e;
-                    g[4] = gmx;
-                    g[5] = gmy;
-                    g[6] = -0.5f * qdx * dx;
-                    g[7] = -0.5f * qdx * dy;
-                    g[8] = -0.5f * qdy * dy;
-                    g[9] = qq * __builtin_amdgcn_rcpf(q1[u].y);
+                    g[4] = qdx;        // sum q dx
+                    g[5] = qdy;        // sum q dy
+                    g[6] = qdx * dx;   // sum q dx^2
+                    g[7] = qdx * dy;   // sum q dx dy
+                    g[8] = qdy * dy;   // sum q dy^2
+                    g[9] = qq;         // sum q
                     g[10] = DO_POSE ? wd : 0.f;  // -> accumulator component 13
                     g[11] = 0.f;
                     tot = wave_reduce12(g, lane);
                 } else {
-                    float g4[4] = {gmx, gmy, wd, 0.f};
+                    float g4[4] = {qdx, qdy, wd, 0.f};
                     tot = wave_reduce4(g4);
                 }
                 // j is wave-uniform here (every lane read the same record)
@@ -308,6 +297,23 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
             }
         }
 
+        __syncthreads();
+        // moments -> gradients, one thread per staged Gaussian (backward.cu:627-631, 669-678):
+        //   dL/dmean2D = -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2;  dL/dconic = -Sxx/2, -Sxy/2, -Syy/2;  dL/dopacity = S0/o
+        if (tid < cnt) {
+            constexpr float LN2 = 0.6931471805599453f;
+            const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
+            const float ca = r0.z * (-2.f * LN2), cb = r0.w * (-LN2), cc = r1.x * (-2.f * LN2);  // unscaled conic
+            const float Sx = sb.acc[4 * ACC_LD + tid], Sy = sb.acc[5 * ACC_LD + tid];
+            sb.acc[4 * ACC_LD + tid] = -(ca * Sx + cb * Sy) * ddelx_dx;
+            sb.acc[5 * ACC_LD + tid] = -(cc * Sy + cb * Sx) * ddely_dy;
+            if (DO_MAP) {
+                sb.acc[6 * ACC_LD + tid] *= -0.5f;
+                sb.acc[7 * ACC_LD + tid] *= -0.5f;
+                sb.acc[8 * ACC_LD + tid] *= -0.5f;
+                sb.acc[9 * ACC_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
+            }
+        }
         __syncthreads();
         flush_acc<NACC_LIGHT>(sb.acc, s.id, cnt, a.acc, tid);
     }
