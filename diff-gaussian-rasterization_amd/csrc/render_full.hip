@@ -38,29 +38,29 @@ __global__ void __launch_bounds__(256) render_fwd_full_kernel(RenderFwdFullArgs 
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, U = 0.f, Dd = 0.f;
     uint32_t last_contributor = 0, first_contributor = 0, nvalid = 0;
-    float thr = inside ? ALPHA_MIN : __builtin_inff();
+    float ub = inside ? 0.f : -__builtin_inff();  // finished pixels accept nothing (see render_light.hip)
     if (tid == 0) {
-        s.rec[2 * SENTINEL] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s.rec[2 * SENTINEL + 1] = make_float4(0.f, 0.f, __int_as_float(SENTINEL), 0.f);
+        write_sentinel(s);
         s_nvalid = 0;
     }
 
     for (int base = 0; base < total; base += DGR_TILE_PIX) {
-        if (__syncthreads_and(thr > 1.0f)) break;
+        if (__syncthreads_and(ub < 0.f)) break;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
         if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0, nullptr);
         const int n = build_lists(s, code, tid, wave, lane);
 
-        for (int k = 0; k < n; k += 4) {
-            float4 q0[4], q1[4];
-            load4(s, wave, k, q0, q1);
+        for (int k = 0; k < n; k += 2) {
+            float4 q0[2], q1[2];
+            load2(s, wave, k, q0, q1);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 2; u++) {
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
-                const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
-                if (p2 <= 0.0f && alpha >= thr) {
+                if (p2 <= ub && p2 >= q1[u].w) {
+                  const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
+                  if (alpha >= ALPHA_MIN) {
                     const int j = __float_as_int(q1[u].z);
                     const float4 cd = s.rgbd[j];
                     const float w = alpha * T;
@@ -71,10 +71,11 @@ __global__ void __launch_bounds__(256) render_fwd_full_kernel(RenderFwdFullArgs 
                     T = T * (1.0f - alpha);
                     last_contributor = (uint32_t)(base + j + 1);
                     if (first_contributor == 0) first_contributor = last_contributor;
-                    if (T < 0.0001f) thr = __builtin_inff();  // blended first, then done (forward.cu:370-381)
+                    if (T < 0.0001f) ub = -__builtin_inff();  // blended first, then done (forward.cu:370-381)
+                  }
                 }
             }
-            if (__all(thr > 1.0f)) break;
+            if (__all(ub < 0.f)) break;
         }
     }
 
@@ -107,7 +108,6 @@ constexpr int NACC_FULL = 15;
 
 struct StagedBwdFull {
     Staged f;
-    float4 raw[DGR_TILE_PIX];  // {conic a, b, c, unused}
     float acc[NACC_FULL * ACC_LD];
     int max_last;
 };
@@ -132,8 +132,7 @@ __global__ void __launch_bounds__(256) render_bwd_full_kernel(RenderBwdFullArgs 
 
     if (tid == 0) {
         sb.max_last = 0;
-        s.rec[2 * SENTINEL] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s.rec[2 * SENTINEL + 1] = make_float4(0.f, 0.f, __int_as_float(SENTINEL), 0.f);
+        write_sentinel(s);
     }
     __syncthreads();
     {
@@ -158,8 +157,10 @@ __global__ void __launch_bounds__(256) render_bwd_full_kernel(RenderBwdFullArgs 
         gt_px = a.gt_depth[pix_id];
     }
     const float bg_dot_dpixel = a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc_depth = 0.f, acc_unc = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f, last_unc = 0.f;
+    // Linear recurrences instead of the reference's five accum_rec_* (see render_light.hip): the full variant needs
+    // the colour part and the depth part of dL/dalpha separately (pose terms), hence three scalars:
+    //   Xc = <rgb_j, dL/dpixel>, Xd = depth_j, Xu = (depth_j - gt)^2 ; S* <- alpha_last X*_last + (1 - alpha_last) S*
+    float Sc = 0.f, Sd = 0.f, Su = 0.f, Xc_last = 0.f, Xd_last = 0.f, Xu_last = 0.f, last_alpha = 0.f;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     const int c16 = wave_reduce16_comp(lane);
     const int my_comp = ((lane & 3) == 0 && c16 < NACC_FULL) ? c16 : -1;
@@ -169,82 +170,93 @@ __global__ void __launch_bounds__(256) render_bwd_full_kernel(RenderBwdFullArgs 
         const int cnt = hi - lo;
         __syncthreads();
         unsigned code = 0;
-        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, &sb.raw[tid]);
+        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, nullptr);
 #pragma unroll
         for (int k = 0; k < NACC_FULL; k++) sb.acc[k * ACC_LD + tid] = 0.f;
         const int n = build_lists(s, code, tid, wave, lane);
         const int rel_last = last_contributor - lo;
         const int rel_first = first_contributor - 1 - lo;  // slot of the front-most valid contributor, if in this batch
 
-        for (int k = ((n + 3) & ~3) - 4; k >= 0; k -= 4) {
-            float4 q0[4], q1[4];
-            load4(s, wave, k, q0, q1);
+        for (int k = ((n + 1) & ~1) - 2; k >= 0; k -= 2) {
+            float4 q0[2], q1[2];
+            load2(s, wave, k, q0, q1);
 #pragma unroll
-            for (int u = 3; u >= 0; u--) {
+            for (int u = 1; u >= 0; u--) {
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
+                const int j = __float_as_int(q1[u].z);
+                if (!__any(j < rel_last && p2 <= 0.0f && p2 >= q1[u].w)) continue;
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, q1[u].y * G);
-                const int j = __float_as_int(q1[u].z);
                 const bool valid = j < rel_last && p2 <= 0.0f && alpha >= ALPHA_MIN;
                 if (!__any(valid)) continue;
 
-                float g[16];
-#pragma unroll
-                for (int c = 0; c < 16; c++) g[c] = 0.f;
+                // per-lane scalars (0 on lanes the Gaussian does not reach): w = alpha T, qq = o G dL/dalpha,
+                // qc = o G * (colour-only part of dL/dalpha), and the front-most-pair depth terms
+                float w = 0.f, qq = 0.f, qc = 0.f, e = 0.f, fw = 0.f, fq = 0.f;
+                const float4 cd = s.rgbd[j];
                 if (valid) {
-                    const float4 cd = s.rgbd[j];
-                    const float4 rc = sb.raw[j];
-                    const float opac = q1[u].y;
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                     T = T * inv;
-                    const float w = alpha * T;  // dchannel_dcolor
+                    w = alpha * T;  // dchannel_dcolor
+                    e = cd.w - gt_px;
+                    const float Xc = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2, Xd = cd.w, Xu = e * e;
                     const float om = 1.f - last_alpha;
-                    acc0 = last_alpha * lc0 + om * acc0; lc0 = cd.x;
-                    acc1 = last_alpha * lc1 + om * acc1; lc1 = cd.y;
-                    acc2 = last_alpha * lc2 + om * acc2; lc2 = cd.z;
-                    const float dcol = (cd.x - acc0) * dpix0 + (cd.y - acc1) * dpix1 + (cd.z - acc2) * dpix2;
-                    float dL_dalpha = dcol;
-                    const float c_d = cd.w;
-                    const float e = c_d - gt_px;
-                    const float c_u = e * e;
-                    acc_depth = last_alpha * last_depth + om * acc_depth; last_depth = c_d;
-                    acc_unc = last_alpha * last_unc + om * acc_unc; last_unc = c_u;
-                    dL_dalpha += (c_d - acc_depth) * dL_depth;
-                    dL_dalpha += (c_u - acc_unc) * dL_dunc;
-                    const float ddepth_dalpha = T * (c_d - acc_depth);  // backward.cu:709
+                    Sc = last_alpha * Xc_last + om * Sc; Xc_last = Xc;
+                    Sd = last_alpha * Xd_last + om * Sd; Xd_last = Xd;
+                    Su = last_alpha * Xu_last + om * Su; Xu_last = Xu;
+                    const float dcol = Xc - Sc;
+                    float dL_dalpha = dcol + (Xd - Sd) * dL_depth + (Xu - Su) * dL_dunc;
                     dL_dalpha *= T;
                     last_alpha = alpha;
                     dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
-
-                    const float dL_dG = opac * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * rc.x - gdy * rc.y;
-                    const float dG_ddely = -gdy * rc.z - gdx * rc.y;
-                    const float sx = opac * dG_ddelx * ddelx_dx, sy = opac * dG_ddely * ddely_dy;
-                    g[0] = w * dpix0;
-                    g[1] = w * dpix1;
-                    g[2] = w * dpix2;
-                    g[3] = w * dL_depth + 2.f * e * w * dL_dunc;  // backward.cu:708
-                    g[4] = dL_dG * dG_ddelx * ddelx_dx;
-                    g[5] = dL_dG * dG_ddely * ddely_dy;
-                    g[6] = -0.5f * gdx * dx * dL_dG;
-                    g[7] = -0.5f * gdx * dy * dL_dG;
-                    g[8] = -0.5f * gdy * dy * dL_dG;
-                    g[9] = G * dL_dalpha;
-                    // pose, part 2-1: sum_ch dL_dpixel[ch] * dpixel_dalpha[ch] = T * dcol (colour terms only)
-                    const float dla_col = T * dcol;
-                    g[10] = dla_col * sx;
-                    g[11] = dla_col * sy;
+                    const float oG = q1[u].y * G;
+                    qq = oG * dL_dalpha;
+                    qc = oG * (T * dcol);  // sum_ch dL_dpixel[ch] * dpixel_dalpha[ch] = T * dcol (backward.cu:693)
                     if (j == rel_first) {  // the pair ComputePG matches last: its dd_dvK survive (backward.cu:1278-1289)
-                        g[12] = dL_depth * w;
-                        g[13] = dL_depth * (ddepth_dalpha * sx);
-                        g[14] = dL_depth * (ddepth_dalpha * sy);
+                        fw = dL_depth * w;
+                        fq = oG * (dL_depth * (T * (Xd - Sd)));  // dL_depth * ddepth_dalpha * o * G
                     }
                 }
+                const float qdx = qq * dx, qdy = qq * dy;
+                float g[16];
+                g[0] = w * dpix0;
+                g[1] = w * dpix1;
+                g[2] = w * dpix2;
+                g[3] = w * dL_depth + 2.f * e * w * dL_dunc;  // backward.cu:708
+                g[4] = qdx;
+                g[5] = qdy;
+                g[6] = qdx * dx;
+                g[7] = qdx * dy;
+                g[8] = qdy * dy;
+                g[9] = qq;
+                g[10] = qc * dx;  // colour-only sums for pose part 2-1
+                g[11] = qc * dy;
+                g[12] = fw;
+                g[13] = fq * dx;  // front-most depth sums
+                g[14] = fq * dy;
+                g[15] = 0.f;
                 const float tot = wave_reduce16(g, lane);
                 if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * ACC_LD + j], tot);
             }
+        }
+        __syncthreads();
+        // moments -> gradients per staged Gaussian: every "d/d(ndc)" sum is -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2
+        if (tid < cnt) {
+            constexpr float LN2 = 0.6931471805599453f;
+            const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
+            const float ca = r0.z * (-2.f * LN2), cb = r0.w * (-LN2), cc = r1.x * (-2.f * LN2);
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+                const int cx = (p == 0) ? 4 : (p == 1) ? 10 : 13, cy = cx + 1;
+                const float Sx = sb.acc[cx * ACC_LD + tid], Sy = sb.acc[cy * ACC_LD + tid];
+                sb.acc[cx * ACC_LD + tid] = -(ca * Sx + cb * Sy) * ddelx_dx;
+                sb.acc[cy * ACC_LD + tid] = -(cc * Sy + cb * Sx) * ddely_dy;
+            }
+            sb.acc[6 * ACC_LD + tid] *= -0.5f;
+            sb.acc[7 * ACC_LD + tid] *= -0.5f;
+            sb.acc[8 * ACC_LD + tid] *= -0.5f;
+            sb.acc[9 * ACC_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
         }
         __syncthreads();
         flush_acc<NACC_FULL>(sb.acc, s.id, cnt, a.acc, tid);

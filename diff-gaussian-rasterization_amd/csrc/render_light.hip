@@ -31,13 +31,18 @@ namespace dgr {
 namespace {
 
 // ================================================================================ forward
+#ifndef DGR_FWD_UNROLL
+#define DGR_FWD_UNROLL 2
+#endif
+constexpr int FWD_UNROLL = DGR_FWD_UNROLL;
+
 struct StagedFwd {
     Staged f;
     float unc[DGR_TILE_PIX];   // per staged instance: sum of (d - gt)^2 alpha T over its median pixels (forward.cu:386)
     uint32_t cnt[DGR_TILE_PIX];
 };
 
-__global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArgs a) {
+__global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
     __shared__ StagedFwd sf;
     Staged& s = sf.f;
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
@@ -76,16 +81,19 @@ __global__ void __launch_bounds__(256) render_fwd_light_kernel(RenderFwdLightArg
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
         if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0, nullptr);
-        const int n = build_lists(s, code, tid, wave, lane);
+        int n = build_lists(s, code, tid, wave, lane);
+        if (a.debug_mode == 1) n = 0;                       // ablation: staging only
+        const float dbg_ub = (a.debug_mode == 2) ? -3.0e38f : 0.f;  // ablation: traversal, nothing ever valid
 
-        for (int k = 0; k < n; k += 4) {
-            float4 q0[4], q1[4];
-            load4(s, wave, k, q0, q1);
+        for (int k = 0; k < n; k += FWD_UNROLL) {
+            float4 q0[FWD_UNROLL], q1[FWD_UNROLL];
+            if (FWD_UNROLL == 4) load4(s, wave, k, reinterpret_cast<float4(&)[4]>(q0), reinterpret_cast<float4(&)[4]>(q1));
+            else load2(s, wave, k, reinterpret_cast<float4(&)[2]>(q0), reinterpret_cast<float4(&)[2]>(q1));
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < FWD_UNROLL; u++) {
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
-                if (p2 <= ub && p2 >= q1[u].w) {  // cheap log-domain pre-test: v_exp stays off the common path
+                if (p2 <= ub + dbg_ub && p2 >= q1[u].w) {  // cheap log-domain pre-test: v_exp stays off the common path
                   const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
                   if (alpha >= ALPHA_MIN) {
                     const float test_T = T * (1.0f - alpha);
