@@ -53,9 +53,9 @@ def algorithmic_bytes(stage, P, V, R, N, M):
         "scan_tiles": 0,
         "emit_instances": 12 * P + 4 * V + 12 * R,        # rect + offset + depth in; rank in, one 8-B key out per instance
         "sort_tiles": 8 * R + 12 * R,                      # keys in; sorted keys + point_list out
-        "render_fwd_light": 4 * R + 48 * R + 36 * N,       # id + record per instance; gt in, 7 images + n_contrib out
+        "render_fwd": 4 * R + 48 * R + 36 * N,             # id + record per instance; gt in, 7 images + n_contrib out
         "zero_scratch": 64 * P,
-        "render_bwd_light": 4 * R + 48 * R + 56 * R + 36 * N,  # + 14 accumulator floats RMW per instance; 9 images in
+        "render_bwd": 4 * R + 48 * R + 56 * R + 36 * N,        # + 14 accumulator floats RMW per instance; 9 images in
         # accumulator row 64 + means 12 + cov3D 24 + SH + scale/rot 28 in per visible; dense outputs
         # (dmeans3D 12, dmeans2D 12, dsh, dscales 12, drot 16, dopacity 4, dcov3D 24, dcolors 12) per Gaussian
         "preprocess_bwd": 4 * P + (128 + sh) * V + (92 + sh) * P,
@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
+    ap.add_argument("--variant", default="light", choices=["light", "full"],
+                    help="light = the headline (config 3); full = the -full flavour (use with --workload config2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--sync-mode", default="lazy", choices=["lazy", "strict"],
@@ -98,7 +100,11 @@ def main():
     from dgr_amd import _capi, light
     from dgr_amd.multiview import GradientArena, make_settings
     from dgr_amd.synth import make_scene
-    from diff_gaussian_rasterization import GaussianRasterizer
+    if args.variant == "full":
+        from dgr_amd import full as V
+    else:
+        from dgr_amd import light as V
+    GaussianRasterizer = V.GaussianRasterizer
 
     P, W, H, deg = WORKLOADS[args.workload]
     s = make_scene(P, W, H, seed=0, view_index=rank)  # rank r renders view r of the same Gaussians
@@ -112,17 +118,29 @@ def main():
     view = t(s.view).requires_grad_(True)
     gt = t(s.gt)
     gC, gD, gM, gV = t(s.gC), t(s.gD[None]), t(s.gM[None]), t(s.gV[None])
-    rast = GaussianRasterizer(make_settings(s, deg, dev))
+    if args.variant == "full":
+        tt = lambda a: torch.as_tensor(a, dtype=torch.float32, device=dev)  # noqa: E731
+        settings = V.GaussianRasterizationSettings(
+            image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=tt(s.bg), scale_modifier=1.0,
+            viewmatrix=tt(s.view), projmatrix=tt(s.proj), sh_degree=deg, campos=tt(s.campos), prefiltered=False,
+            perspec_matrix=tt(s.persp))
+    else:
+        settings = make_settings(s, deg, dev)
+    rast = GaussianRasterizer(settings)
     params = [means3D, means2D, shs, opac, scales, rots]
     arena = GradientArena(params) if dist is not None else None
 
     def step():
         for p_ in params + [view]:
             p_.grad = None
-        color, radii, depth, median, var, alpha, unc, px = rast(
-            means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots,
-            viewmatrix=view, gt_depth=gt)
-        torch.autograd.backward([color, depth, median, var], [gC, gD, gM, gV])
+        outs = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots,
+                    viewmatrix=view, gt_depth=gt)
+        if args.variant == "full":
+            color, radii, depth, unc = outs
+            torch.autograd.backward([color, depth, unc], [gC, gD, gV])
+        else:
+            color, radii, depth, median, var, alpha, unc, px = outs
+            torch.autograd.backward([color, depth, median, var], [gC, gD, gM, gV])
         if arena is not None:
             arena.all_reduce(dist)  # one fused RCCL all-reduce of the per-Gaussian gradients
         return radii
@@ -190,7 +208,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, light variant, "
+            "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
                                    f"fwd+bwd incl. viewmatrix gradient, one view per GPU", "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},

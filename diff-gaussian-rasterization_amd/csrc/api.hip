@@ -45,7 +45,7 @@ struct StageProf {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
 StageProf g_prof[] = {{"preprocess_fwd"}, {"scan_blocks"}, {"count_rank"}, {"scan_tiles"}, {"emit_instances"}, {"sort_tiles"},
-                      {"render_fwd_light"}, {"zero_scratch"}, {"render_bwd_light"}, {"preprocess_bwd"}};
+                      {"render_fwd"}, {"zero_scratch"}, {"render_bwd"}, {"preprocess_bwd"}};
 enum { ST_PRE_FWD, ST_SCAN_BLOCKS, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD, ST_ZERO, ST_RENDER_BWD, ST_PRE_BWD,
        ST_COUNT };
 std::mutex g_prof_mu;

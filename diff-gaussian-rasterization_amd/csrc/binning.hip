@@ -31,28 +31,57 @@ constexpr int COUNT_STAGE = 4096;   // ranks staged per 256-Gaussian block in co
 constexpr int SORT_LDS_MAX = 4096;  // keys per tile sorted in LDS (32 KB); larger tiles sort in global memory
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img, int tiles, int capacity) {
-    __shared__ uint32_t part[SCAN_THREADS];
-    const int t = threadIdx.x;
+    __shared__ uint32_t wsum[SCAN_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (tiles + SCAN_THREADS - 1) / SCAN_THREADS;
     const int lo = min(t * per, tiles), hi = min(lo + per, tiles);
+    // Up to 8 counters per thread stay in registers (every frame up to 8192 tiles, i.e. 1080p); larger grids read
+    // the counters a second time.  The padded counters are one cache line each, so the loads are issued together.
+    constexpr int REG = 8;
+    uint32_t c[REG];
     uint32_t s = 0;
-    for (int i = lo; i < hi; i++) s += img.tile_count[i];
-    part[t] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partials
-    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
-        uint32_t v = (t >= off) ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    if (per <= REG) {
+#pragma unroll
+        for (int k = 0; k < REG; k++) {
+            c[k] = (lo + k < hi) ? img.tile_count[(size_t)(lo + k) * DGR_COUNT_STRIDE] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < REG; k++) s += c[k];
+    } else {
+        for (int i = lo; i < hi; i++) s += img.tile_count[(size_t)i * DGR_COUNT_STRIDE];
     }
-    const uint32_t total = part[SCAN_THREADS - 1];
+    // wave-level inclusive scan, then the 16 wave totals through LDS: one barrier
+    uint32_t incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int ww = 0; ww < SCAN_THREADS / 64; ww++) {
+        const uint32_t v = wsum[ww];
+        if (ww < wave) before += v;
+        total += v;
+    }
     const bool overflow = total > (uint32_t)capacity;
-    uint32_t run = part[t] - s;  // exclusive prefix of this thread's chunk
-    for (int i = lo; i < hi; i++) {
-        const uint32_t c = img.tile_count[i];
-        img.ranges[i] = overflow ? make_uint2(0u, 0u) : make_uint2(run, run + c);
-        run += c;
+    uint32_t run = before + incl - s;  // exclusive prefix of this thread's chunk
+    if (per <= REG) {
+#pragma unroll
+        for (int k = 0; k < REG; k++) {
+            if (lo + k < hi) {
+                img.ranges[lo + k] = overflow ? make_uint2(0u, 0u) : make_uint2(run, run + c[k]);
+                run += c[k];
+            }
+        }
+    } else {
+        for (int i = lo; i < hi; i++) {
+            const uint32_t cc = img.tile_count[(size_t)i * DGR_COUNT_STRIDE];
+            img.ranges[i] = overflow ? make_uint2(0u, 0u) : make_uint2(run, run + cc);
+            run += cc;
+        }
     }
     if (t == 0) {
         img.status[0] = (int)total;
@@ -102,7 +131,7 @@ __global__ void __launch_bounds__(256) count_rank_kernel(int P, GeometryView geo
             const uint32_t kk = k + u;
             if (kk < n) {
                 const uint32_t yy = kk / w, xx = kk - yy * w;  // row-major over the rect, as duplicateWithKeys enumerates
-                rank[u] = atomicAdd(&img.tile_count[(r.y + yy) * grid_x + r.x + xx], 1u);
+                rank[u] = atomicAdd(&img.tile_count[(size_t)((r.y + yy) * grid_x + r.x + xx) * DGR_COUNT_STRIDE], 1u);
             }
         }
 #pragma unroll
@@ -123,27 +152,34 @@ __global__ void __launch_bounds__(256) count_rank_kernel(int P, GeometryView geo
 // In-place exclusive scan of the per-block instance totals (P/256 values, one 1024-thread block); the grand total
 // = num_rendered goes to status[0] (the callback entry points read it before sizing the binning buffer).
 __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* block_tiles, int nblocks, int* status) {
-    __shared__ uint32_t part[SCAN_THREADS];
-    const int t = threadIdx.x;
+    __shared__ uint32_t wsum[SCAN_THREADS / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (nblocks + SCAN_THREADS - 1) / SCAN_THREADS;
     const int lo = min(t * per, nblocks), hi = min(lo + per, nblocks);
     uint32_t s = 0;
     for (int i = lo; i < hi; i++) s += block_tiles[i];
-    part[t] = s;
-    __syncthreads();
-    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
-        uint32_t v = (t >= off) ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    uint32_t incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    uint32_t run = part[t] - s;
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int ww = 0; ww < SCAN_THREADS / 64; ww++) {
+        const uint32_t v = wsum[ww];
+        if (ww < wave) before += v;
+        total += v;
+    }
+    uint32_t run = before + incl - s;
     for (int i = lo; i < hi; i++) {
         const uint32_t c = block_tiles[i];
         block_tiles[i] = run;
         run += c;
     }
-    if (t == 0) status[0] = (int)part[SCAN_THREADS - 1];
+    if (t == 0) status[0] = (int)total;
 }
 
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, GeometryView geom, ImageView img, BinningView bin,

@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  (must be imported before the HIP library is mapped)
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libdgr_hip.so")
+# DGR_HIP_LIB points at another build of the same ABI (kernel experiments); the default is the in-tree library
+LIB_PATH = os.environ.get("DGR_HIP_LIB") or os.path.join(_PKG, "lib", "libdgr_hip.so")
 
 DGR_OK = 0
 DGR_ERR_BAD_ARGUMENT = -1
