@@ -138,7 +138,6 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_median = c.out_median_depth; r.out_alpha = c.out_alpha;
     r.out_depth_var = c.out_depth_var; r.n_contrib = img.n_contrib; r.gau_uncertainty = c.gau_uncertainty;
     r.gau_related_pixels = c.gau_related_pixels;
-    { const char* e = getenv("DGR_DEBUG_FWD"); r.debug_mode = e ? atoi(e) : 0; }
     { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_light(r, st)); }
     return DGR_OK;
 }

@@ -73,7 +73,6 @@ struct RenderFwdLightArgs {
     uint32_t* n_contrib;
     float* gau_uncertainty;
     int* gau_related_pixels;
-    int debug_mode;  // DGR_DEBUG_FWD ablation switch (0 = normal)
 };
 
 struct RenderBwdLightArgs {

@@ -6,6 +6,10 @@
 #include "wave_reduce.h"
 
 namespace dgr {
+
+// wave-uniform "any lane": one v_cmp into an SGPR pair + s_cmp (HIP's __any() goes through v_cndmask + v_cmp)
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;

@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) render_fwd_full_kernel(RenderFwdFullArgs 
             for (int u = 0; u < 2; u++) {
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
-                if (p2 <= ub && p2 >= q1[u].w) {
+                if ((p2 <= ub) & (p2 >= q1[u].w)) {
                   const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
                   if (alpha >= ALPHA_MIN) {
                     const int j = __float_as_int(q1[u].z);
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) render_fwd_full_kernel(RenderFwdFullArgs 
                   }
                 }
             }
-            if (__all(ub < 0.f)) break;
+            if (!wave_any(ub >= 0.f)) break;
         }
     }
 
@@ -185,11 +185,11 @@ __global__ void __launch_bounds__(256) render_bwd_full_kernel(RenderBwdFullArgs 
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
                 const int j = __float_as_int(q1[u].z);
-                if (!__any(j < rel_last && p2 <= 0.0f && p2 >= q1[u].w)) continue;
+                if (!wave_any((j < rel_last) & (p2 <= 0.0f) & (p2 >= q1[u].w))) continue;
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, q1[u].y * G);
                 const bool valid = j < rel_last && p2 <= 0.0f && alpha >= ALPHA_MIN;
-                if (!__any(valid)) continue;
+                if (!wave_any(valid)) continue;
 
                 // per-lane scalars (0 on lanes the Gaussian does not reach): w = alpha T, qq = o G dL/dalpha,
                 // qc = o G * (colour-only part of dL/dalpha), and the front-most-pair depth terms

@@ -81,9 +81,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
         if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0, nullptr);
-        int n = build_lists(s, code, tid, wave, lane);
-        if (a.debug_mode == 1) n = 0;                       // ablation: staging only
-        const float dbg_ub = (a.debug_mode == 2) ? -3.0e38f : 0.f;  // ablation: traversal, nothing ever valid
+        const int n = build_lists(s, code, tid, wave, lane);
 
         for (int k = 0; k < n; k += FWD_UNROLL) {
             float4 q0[FWD_UNROLL], q1[FWD_UNROLL];
@@ -93,7 +91,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
             for (int u = 0; u < FWD_UNROLL; u++) {
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
-                if (p2 <= ub + dbg_ub && p2 >= q1[u].w) {  // cheap log-domain pre-test: v_exp stays off the common path
+                if ((p2 <= ub) & (p2 >= q1[u].w)) {  // cheap log-domain pre-test: v_exp stays off the common path
                   const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
                   if (alpha >= ALPHA_MIN) {
                     const float test_T = T * (1.0f - alpha);
@@ -118,7 +116,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
                   }
                 }
             }
-            if (__all(ub < 0.f)) break;
+            if (!wave_any(ub >= 0.f)) break;
         }
     }
     __syncthreads();
@@ -245,11 +243,11 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
                 const int j = __float_as_int(q1[u].z);
                 // log-domain pre-test; the exact alpha test follows on the rare path
-                if (!__any(j < rel_last && p2 <= 0.0f && p2 >= q1[u].w)) continue;
+                if (!wave_any((j < rel_last) & (p2 <= 0.0f) & (p2 >= q1[u].w))) continue;
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, q1[u].y * G);
                 const bool valid = j < rel_last && p2 <= 0.0f && alpha >= ALPHA_MIN;
-                if (!__any(valid)) continue;
+                if (!wave_any(valid)) continue;
 
                 // per-lane scalars of this pair; they stay 0 on lanes the Gaussian does not reach, so the products
                 // below need no masking:  w = alpha T,  qq = o G dL/dalpha  (dL_dG * G)
