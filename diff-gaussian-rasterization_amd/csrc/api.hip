@@ -159,6 +159,7 @@ int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryV
 
 int check_common(const FwdCommon& c) {
     if (c.P < 0 || c.W <= 0 || c.H <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
+    if ((unsigned)c.P > DGR_ID_MASK) { g_last_error = "more than 2^28 Gaussians"; return DGR_ERR_BAD_ARGUMENT; }
     if (c.P > 0 && !c.shs && !c.colors_precomp) { g_last_error = "need SHs or precomputed colours"; return DGR_ERR_BAD_ARGUMENT; }
     if (c.P > 0 && !c.cov3D_precomp && (!c.scales || !c.rotations)) { g_last_error = "need scale/rotation or cov3D"; return DGR_ERR_BAD_ARGUMENT; }
     if (dgr::tiles_x(c.W) > 65535 || dgr::tiles_y(c.H) > 65535) { g_last_error = "image too large"; return DGR_ERR_BAD_ARGUMENT; }
@@ -202,7 +203,17 @@ __global__ void export_keys_kernel(dgr::ImageView img, dgr::BinningView bin, dgr
     const int tile = blockIdx.x;
     const uint2 rg = img.ranges[tile];
     for (uint32_t i = rg.x + threadIdx.x; i < rg.y; i += blockDim.x)
-        dst[i] = ((uint64_t)tile << 32) | __float_as_uint(g.depths[bin.point_list[i]]);
+        dst[i] = ((uint64_t)tile << 32) | __float_as_uint(g.depths[bin.point_list[i] & DGR_ID_MASK]);
+}
+// the sorted Gaussian ids without the light forward's contribution tags (top 4 bits; render_common.h)
+__global__ void export_point_list_kernel(const uint32_t* src, uint32_t* dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i] & DGR_ID_MASK;
+}
+// ... and the tags alone (tests)
+__global__ void export_tags_kernel(const uint32_t* src, uint8_t* dst, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (uint8_t)(src[i] >> DGR_TAG_SHIFT);
 }
 
 }  // namespace
@@ -538,7 +549,17 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
     if (n == "rgb") return geomk(EX_RGB) ? -1 : 3L * P;
     if (n == "clamped") return geomk(EX_CLAMPED) ? -1 : 3L * P;
     if (n == "tiles_touched") return geomk(EX_TILES_TOUCHED) ? -1 : P;
-    if (n == "point_list") return copy(bin.point_list, 4 * (size_t)num_rendered) ? -1 : num_rendered;
+    if (n == "point_list" || n == "contribution_tags") {
+        if (num_rendered > 0) {
+            const dim3 grid((num_rendered + 255) / 256);
+            if (n == "point_list")
+                hipLaunchKernelGGL(export_point_list_kernel, grid, dim3(256), 0, st, bin.point_list, (uint32_t*)dst, num_rendered);
+            else
+                hipLaunchKernelGGL(export_tags_kernel, grid, dim3(256), 0, st, bin.point_list, (uint8_t*)dst, num_rendered);
+            if (hipGetLastError() != hipSuccess) return -1;
+        }
+        return num_rendered;
+    }
     if (n == "keys") {
         hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)tiles), dim3(256), 0, st, img, bin, g, (uint64_t*)dst);
         if (hipGetLastError() != hipSuccess) return -1;

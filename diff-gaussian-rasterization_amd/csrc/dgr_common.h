@@ -15,6 +15,9 @@
 #define DGR_BLOCK_Y 16
 #define DGR_TILE_PIX 256
 #define DGR_NEAR 0.2f  // cuda_rasterizer/auxiliary.h:152
+// point_list entries: Gaussian id in the low 28 bits, the light forward's contribution tag in the top 4
+#define DGR_TAG_SHIFT 28
+#define DGR_ID_MASK ((1u << DGR_TAG_SHIFT) - 1u)
 #ifndef DGR_COUNT_STRIDE
 #define DGR_COUNT_STRIDE 16
 #endif  // tile counters are padded to one per 64-byte line: returning atomics on one line serialise

@@ -67,6 +67,29 @@ __device__ __forceinline__ unsigned stage_one(Staged& s, int slot, uint32_t gid,
     return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
 }
 
+// Contribution tags.  The forward blend kernel marks every tile-list entry with the set of quadrant waves in which at
+// least one pixel blended it (4 bits, kept in the top bits of the point_list entry: Gaussian ids stay below 2^28).
+// A (pixel, Gaussian) pair is valid in the backward exactly when the forward blended it (same alpha expression, and
+// position <= the pixel's last contributor), so the backward builds its per-wave lists from the tags: no bounding-box
+// test, no wave-level pre-test, and instances no pixel blended are never loaded.
+constexpr int TAG_SHIFT = DGR_TAG_SHIFT;
+constexpr uint32_t ID_MASK = DGR_ID_MASK;
+
+// backward staging: returns the entry's tag; untagged entries are not loaded
+__device__ __forceinline__ unsigned stage_tagged(Staged& s, int slot, uint32_t entry, const float4* __restrict__ rec) {
+    const unsigned code = entry >> TAG_SHIFT;
+    if (code == 0u) return 0u;
+    const uint32_t gid = entry & ID_MASK;
+    const float4 q0 = rec[3 * (size_t)gid + 0];
+    const float4 q1 = rec[3 * (size_t)gid + 1];
+    const float4 q2 = rec[3 * (size_t)gid + 2];
+    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -LOG2E * q1.y);
+    s.rec[2 * slot + 1] = make_float4(-0.5f * LOG2E * q1.z, q0.w, __int_as_float(slot), 0.f);
+    s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
+    s.id[slot] = gid;
+    return code;
+}
+
 __device__ __forceinline__ int lanes_below(unsigned long long m) {
     return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }

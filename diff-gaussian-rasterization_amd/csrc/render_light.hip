@@ -40,7 +40,22 @@ struct StagedFwd {
     Staged f;
     float unc[DGR_TILE_PIX];   // per staged instance: sum of (d - gt)^2 alpha T over its median pixels (forward.cu:386)
     uint32_t cnt[DGR_TILE_PIX];
+    uint32_t hit[DGR_TILE_PIX];  // byte w of word j != 0: some pixel of quadrant wave w blended staged instance j
 };
+
+// Per-slot results of the batch staged at list position `pos0`: the median statistics go to the Gaussian, the
+// contribution tag into the top bits of the list entry (render_common.h).
+__device__ __forceinline__ void flush_slot(const StagedFwd& sf, const RenderFwdLightArgs& a, uint32_t pos0, int tid) {
+    const uint32_t h = sf.hit[tid];
+    if (h == 0u) return;  // nothing blended this instance (never-staged slots included)
+    const uint32_t gid = sf.f.id[tid];
+    if (sf.cnt[tid] != 0u) {
+        atomicAdd(&a.gau_uncertainty[gid], sf.unc[tid]);
+        atomicAdd(&a.gau_related_pixels[gid], (int)sf.cnt[tid]);
+    }
+    const uint32_t tag = (h & 1u) | ((h >> 7) & 2u) | ((h >> 14) & 4u) | ((h >> 21) & 8u);
+    a.point_list[pos0 + tid] = gid | (tag << TAG_SHIFT);
+}
 
 __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
     __shared__ StagedFwd sf;
@@ -66,17 +81,17 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
     const float gt_px = inside ? a.gt_depth[pix_id] : 0.f;
     if (tid == 0) write_sentinel(s);
     bool have_flush = false;
+    int last_base = 0;
 
     for (int base = 0; base < total; base += DGR_TILE_PIX) {
         // whole tile finished?  (L/cuda_rasterizer/forward.cu:329-332)
         if (__syncthreads_and(ub < 0.f)) break;
+        last_base = base;
         // median statistics of the previous batch: slot tid is flushed by the thread that restages it
-        if (have_flush && sf.cnt[tid] != 0u) {
-            atomicAdd(&a.gau_uncertainty[s.id[tid]], sf.unc[tid]);
-            atomicAdd(&a.gau_related_pixels[s.id[tid]], (int)sf.cnt[tid]);
-        }
+        if (have_flush) flush_slot(sf, a, range.x + base - DGR_TILE_PIX, tid);
         sf.unc[tid] = 0.f;
         sf.cnt[tid] = 0u;
+        sf.hit[tid] = 0u;
         have_flush = true;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
@@ -100,6 +115,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
                     } else {
                         const int j = __float_as_int(q1[u].z);
                         const float4 cd = s.rgbd[j];
+                        reinterpret_cast<unsigned char*>(sf.hit)[4 * j + wave] = 1;  // contribution tag
                         const float w = alpha * T;
                         C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
                         weight += w;
@@ -120,10 +136,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         }
     }
     __syncthreads();
-    if (have_flush && sf.cnt[tid] != 0u) {
-        atomicAdd(&a.gau_uncertainty[s.id[tid]], sf.unc[tid]);
-        atomicAdd(&a.gau_related_pixels[s.id[tid]], (int)sf.cnt[tid]);
-    }
+    if (have_flush) flush_slot(sf, a, range.x + last_base, tid);
 
     if (inside) {
         const size_t N = (size_t)a.W * a.H;
@@ -170,7 +183,6 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
     const size_t pix_id = (size_t)a.W * py + px;
     const size_t N = (size_t)a.W * a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
 
     const uint2 range = a.ranges[tile];
     const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
@@ -227,7 +239,7 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
         const int cnt = hi - lo;
         __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
-        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, nullptr);
+        if (tid < cnt) code = stage_tagged(s, tid, a.point_list[range.x + lo + tid], a.rec);
 #pragma unroll
         for (int k = 0; k < NACC_LIGHT; k++) sb.acc[k * ACC_LD + tid] = 0.f;
         const int n = build_lists(s, code, tid, wave, lane);
@@ -242,12 +254,10 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
                 const int j = __float_as_int(q1[u].z);
-                // log-domain pre-test; the exact alpha test follows on the rare path
-                if (!wave_any((j < rel_last) & (p2 <= 0.0f) & (p2 >= q1[u].w))) continue;
+                // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, q1[u].y * G);
-                const bool valid = j < rel_last && p2 <= 0.0f && alpha >= ALPHA_MIN;
-                if (!wave_any(valid)) continue;
+                const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
 
                 // per-lane scalars of this pair; they stay 0 on lanes the Gaussian does not reach, so the products
                 // below need no masking:  w = alpha T,  qq = o G dL/dalpha  (dL_dG * G)
@@ -306,7 +316,7 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
         __syncthreads();
         // moments -> gradients, one thread per staged Gaussian (backward.cu:627-631, 669-678):
         //   dL/dmean2D = -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2;  dL/dconic = -Sxx/2, -Sxy/2, -Syy/2;  dL/dopacity = S0/o
-        if (tid < cnt) {
+        if (code != 0u) {
             constexpr float LN2 = 0.6931471805599453f;
             const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
             const float ca = r0.z * (-2.f * LN2), cb = r0.w * (-LN2), cc = r1.x * (-2.f * LN2);  // unscaled conic

@@ -66,6 +66,33 @@ def test_forward_images(oracle, case):
     assert np.mean(d["gau_related_pixels"] != ref["gau_related_pixels"]) <= 1e-3
 
 
+@pytest.mark.parametrize("case", CASES[:4])
+def test_contribution_tags(oracle, case):
+    """The forward marks each tile-list entry with the 8x8 quadrants in which some pixel blended it (the backward
+    builds its lists from these marks).  Checked against n_contrib: a pixel's last contributor is blended by that
+    pixel, and nothing past a quadrant's deepest last contributor is marked for that quadrant."""
+    P, W, H, deg, seed = case
+    s = make_scene(P, W, H, seed)
+    _, d = hh.hip_forward(s, deg)
+    tags = hh.hip_state("contribution_tags", s, d)
+    ranges = hh.hip_state("ranges", s, d).reshape(-1, 2)
+    nc = hh.hip_state("n_contrib", s, d).reshape(H, W)
+    gx = (W + 15) // 16
+    assert tags.max(initial=0) < 16
+    for tile, (lo, hi) in enumerate(ranges):
+        tx, ty = tile % gx, tile // gx
+        t = tags[lo:hi]
+        for q in range(4):
+            x0, y0 = tx * 16 + (q & 1) * 8, ty * 16 + (q >> 1) * 8
+            blk = nc[y0:y0 + 8, x0:x0 + 8]
+            marked = np.nonzero((t >> q) & 1)[0]
+            if blk.size == 0 or blk.max() == 0:
+                assert marked.size == 0
+                continue
+            assert marked.size and marked.max() == blk.max() - 1
+            assert np.all(((t[blk[blk > 0] - 1] >> q) & 1) == 1)
+
+
 GRAD_NAMES = ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
 
 
