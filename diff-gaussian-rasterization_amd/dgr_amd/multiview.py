@@ -42,14 +42,28 @@ class GradientArena:
                 return None
         return arena[:n]
 
-    def all_reduce(self, dist, group=None):
+    def all_reduce(self, dist, group=None, async_op=False):
+        """Sums the gradients over the ranks.  Returns the number of collectives issued, or with `async_op` a
+        `PendingReduce` whose wait() orders the current stream after them: the collective runs on the backend's own
+        stream, so the next view's forward/backward (which writes a fresh arena) overlaps it."""
         span = self.fused_span()
-        if span is not None:
-            dist.all_reduce(span, op=dist.ReduceOp.SUM, group=group)
-            return 1
-        n = 0
-        for p in self.params:  # fallback: gradients were copied by autograd; reduce them one by one
-            if p.grad is not None:
-                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group)
-                n += 1
-        return n
+        tensors = [span] if span is not None else [p.grad for p in self.params if p.grad is not None]
+        works = [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op) for t in tensors]
+        if async_op:
+            return PendingReduce(works, tensors)
+        return len(tensors)
+
+
+class PendingReduce:
+    """Handles of an in-flight gradient sum; keeps the reduced buffers alive until wait()."""
+
+    def __init__(self, works, tensors):
+        self.works, self.tensors = works, tensors
+
+    def __len__(self):
+        return len(self.works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return self.tensors

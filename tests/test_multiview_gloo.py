@@ -33,7 +33,7 @@ def view_grads(P, W, H, deg, k):
                             *grads, s.gt, s.shs, deg, s.campos, out["opacity_map"], s.persp)
 
 
-def worker(rank, world, port, fused, q):
+def worker(rank, world, port, fused, q, async_op=False):
     for p in (ROOT, PKG):
         sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -52,7 +52,21 @@ def worker(rank, world, port, fused, q):
         p.grad = seg[n] if fused else seg[n].clone()  # aliasing (autograd stole the view) vs copied gradient
         params.append(p)
     arena = GradientArena(params)
-    ncoll = arena.all_reduce(dist)
+    if async_op:  # overlapped form (bench.py --allreduce overlap): issue, do other work, wait
+        pending = arena.all_reduce(dist, async_op=True)
+        for p in params:
+            p.grad = None  # the next view's step drops the references; the pending reduce keeps the buffers alive
+        ncoll = len(pending)
+        reduced = pending.wait()
+        if fused:
+            views = {n: seg[n] for n in NAMES}
+            assert reduced[0].data_ptr() == seg["means3D"].data_ptr()
+        else:
+            views = dict(zip(NAMES, reduced))
+        for n, p in zip(NAMES, params):
+            p.grad = views[n]
+    else:
+        ncoll = arena.all_reduce(dist)
     q.put((rank, ncoll, {n: p.grad.numpy().copy() for n, p in zip(NAMES, params)}, g["dL_dview"]))
     dist.barrier()
     dist.destroy_process_group()
@@ -64,13 +78,13 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("fused", [True, False])
-def test_gradient_all_reduce_equals_serial_sum_over_views(oracle, fused):
+@pytest.mark.parametrize("fused,async_op", [(True, False), (False, False), (True, True), (False, True)])
+def test_gradient_all_reduce_equals_serial_sum_over_views(oracle, fused, async_op):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = free_port()
-    procs = [ctx.Process(target=worker, args=(r, world, port, fused, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, fused, q, async_op)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
