@@ -95,10 +95,8 @@ int zero_outputs(const FwdCommon& c, hipStream_t st) {
 // preprocess; afterwards geom.block_tiles holds the instance totals per 256-Gaussian block
 int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, hipStream_t st) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
-    // status, tile_count and tile_fill are adjacent: one memset
-    HIP_TRY(hipMemsetAsync(img.status, 0, (char*)img.ranges - (char*)img.status, st));
-    if (c.gau_uncertainty) HIP_TRY(hipMemsetAsync(c.gau_uncertainty, 0, (size_t)c.P * 4, st));
-    if (c.gau_related_pixels) HIP_TRY(hipMemsetAsync(c.gau_related_pixels, 0, (size_t)c.P * 4, st));
+    // No memsets: preprocess clears the tile counters and the per-Gaussian median statistics, scan_blocks
+    // initialises the status word.
     dgr::PreprocessFwdArgs a{};
     a.P = c.P; a.D = c.D; a.M = c.M; a.W = c.W; a.H = c.H; a.grid_x = gx; a.grid_y = gy;
     a.means3D = c.means3D; a.scales = c.scales; a.scale_modifier = c.scale_modifier; a.rotations = c.rotations;
@@ -109,7 +107,9 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
     a.focal_x = c.W / (2.0f * c.tan_fovx);
     a.prefiltered = c.prefiltered;
     a.sh_vec_ok = aligned16(c.shs);
-    a.geom = geom; a.radii_out = c.radii; a.status = img.status;
+    a.geom = geom; a.radii_out = c.radii;
+    a.zero_words = img.tile_count; a.n_zero_words = (int)(((char*)img.ranges - (char*)img.tile_count) / 4);
+    a.gau_uncertainty = c.gau_uncertainty; a.gau_related_pixels = c.gau_related_pixels;
     { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd(a, st)); }
     (void)tiles;
     // per-block instance totals -> exclusive prefix; status[0] = num_rendered
@@ -255,11 +255,11 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     }
     dgr::GeometryView geom = dgr::carve_geometry(geometry_buffer, P);
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
+    if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
     if ((rc = forward_front(c, geom, img, st))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
     if ((rc = forward_back(c, geom, img, bin, binning_capacity > 0, st))) return rc;
-    if (status) HIP_TRY(hipMemcpyAsync(status, img.status, 16, hipMemcpyDeviceToDevice, st));
     return DGR_OK;
 }
 
@@ -377,11 +377,11 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     }
     dgr::GeometryView geom = dgr::carve_geometry(geometry_buffer, P);
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
+    if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
     if ((rc = forward_front(c, geom, img, st))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, binning_capacity > 0, st))) return rc;
-    if (status) HIP_TRY(hipMemcpyAsync(status, img.status, 16, hipMemcpyDeviceToDevice, st));
     return DGR_OK;
 }
 

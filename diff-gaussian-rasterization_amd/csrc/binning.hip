@@ -153,11 +153,17 @@ __global__ void __launch_bounds__(256) count_rank_kernel(int P, GeometryView geo
 // = num_rendered goes to status[0] (the callback entry points read it before sizing the binning buffer).
 __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* block_tiles, int nblocks, int* status) {
     __shared__ uint32_t wsum[SCAN_THREADS / 64];
+    __shared__ uint32_t any_flag;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (nblocks + SCAN_THREADS - 1) / SCAN_THREADS;
     const int lo = min(t * per, nblocks), hi = min(lo + per, nblocks);
-    uint32_t s = 0;
-    for (int i = lo; i < hi; i++) s += block_tiles[i];
+    if (t == 0) any_flag = 0u;
+    uint32_t s = 0, flag = 0;
+    for (int i = lo; i < hi; i++) {
+        const uint32_t v = block_tiles[i];  // bit 31: `prefiltered` violation seen by that block (preprocess_fwd)
+        s += v & 0x7fffffffu;
+        flag |= v >> 31;
+    }
     uint32_t incl = s;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -166,6 +172,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* blo
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
+    if (flag) any_flag = 1u;
     uint32_t before = 0, total = 0;
 #pragma unroll
     for (int ww = 0; ww < SCAN_THREADS / 64; ww++) {
@@ -175,11 +182,17 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* blo
     }
     uint32_t run = before + incl - s;
     for (int i = lo; i < hi; i++) {
-        const uint32_t c = block_tiles[i];
+        const uint32_t c = block_tiles[i] & 0x7fffffffu;
         block_tiles[i] = run;
         run += c;
     }
-    if (t == 0) status[0] = (int)total;
+    __syncthreads();
+    if (t == 0) {  // the whole status word is (re)initialised here: no memset before the forward
+        status[0] = (int)total;
+        status[1] = 0;               // overflow: scan_tiles
+        status[2] = (int)any_flag;   // prefiltered violation
+        status[3] = 0;               // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
+    }
 }
 
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, GeometryView geom, ImageView img, BinningView bin,

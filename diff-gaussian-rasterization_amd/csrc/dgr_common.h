@@ -61,7 +61,6 @@ __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
 struct ImageView {
     int* status;          // [4] {num_rendered, overflow, prefiltered violation, reserved}
     uint32_t* tile_count; // [tiles * DGR_COUNT_STRIDE] instances per tile (histogram filled by count_rank), one per line
-    uint32_t* tile_fill;  // [tiles] slot allocator used while emitting instances
     uint2* ranges;        // [tiles] {start, end} into point_list
     uint32_t* n_contrib;  // [N]
     float* final_T;       // [N]   (full variant)
@@ -77,7 +76,6 @@ __host__ __device__ inline ImageView carve_image(char* base, int W, int H) {
     size_t o = 0;
     v.status = (int*)(base + o);          o = align_up(o + 4 * sizeof(int), 256);
     v.tile_count = (uint32_t*)(base + o); o = align_up(o + tiles * 4 * DGR_COUNT_STRIDE, 256);
-    v.tile_fill = (uint32_t*)(base + o);  o = align_up(o + tiles * 4, 256);
     v.ranges = (uint2*)(base + o);        o = align_up(o + tiles * 8, 256);
     v.n_contrib = (uint32_t*)(base + o);  o = align_up(o + N * 4, 256);
     v.final_T = (float*)(base + o);       o = align_up(o + N * 4, 256);

@@ -22,7 +22,10 @@ struct PreprocessFwdArgs {
     bool sh_vec_ok;
     GeometryView geom;
     int* radii_out;        // caller's radii tensor (may be NULL)
-    int* status;
+    uint32_t* zero_words;  // n_zero_words 32-bit words to clear (the padded tile counters)
+    int n_zero_words;
+    float* gau_uncertainty;   // [P] cleared here, accumulated by the forward blend (may be NULL)
+    int* gau_related_pixels;  // [P] likewise
 };
 
 struct PreprocessBwdArgs {

@@ -154,7 +154,13 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
     const int idx = blockIdx.x * 256 + threadIdx.x;
     int radius = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
+    bool violation = false;
+    // Zeroing that would otherwise be stream memsets (one launch each): the tile counters count_rank increments and
+    // the two per-Gaussian median statistics the forward blend accumulates into.
+    for (int i = idx; i < a.n_zero_words; i += gridDim.x * 256) a.zero_words[i] = 0u;
     if (idx < a.P) {
+    if (a.gau_uncertainty) a.gau_uncertainty[idx] = 0.0f;
+    if (a.gau_related_pixels) a.gau_related_pixels[idx] = 0;
     const float3 p_orig = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
 
     // in_frustum (cuda_rasterizer/auxiliary.h:139-164)
@@ -163,7 +169,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
     const float3 p_proj = make_float3(p_hom.x * p_w, p_hom.y * p_w, p_hom.z * p_w);
     const float3 p_view = xform4x3(p_orig, a.view);
     bool live = !(p_view.z <= DGR_NEAR);
-    if (!live && a.prefiltered) a.status[2] = 1;
+    violation = !live && a.prefiltered;  // `prefiltered` promised that nothing is culled (auxiliary.h:154-160)
 
     if (live) {
         float c3[6];
@@ -255,9 +261,16 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
     uint32_t n = (uint32_t)(rect.z - rect.x) * (uint32_t)(rect.w - rect.y);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    // bit 31 of the block total carries "some Gaussian of this block violated `prefiltered`" (scan_blocks moves it
+    // into status[2]); block totals stay far below 2^31
+    if (__builtin_amdgcn_ballot_w64(violation) != 0ull) n |= 0x80000000u;
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
     __syncthreads();
-    if (threadIdx.x == 0) a.geom.block_tiles[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        const uint32_t flag = (wsum[0] | wsum[1] | wsum[2] | wsum[3]) & 0x80000000u;
+        a.geom.block_tiles[blockIdx.x] = ((wsum[0] & 0x7fffffffu) + (wsum[1] & 0x7fffffffu) + (wsum[2] & 0x7fffffffu) +
+                                          (wsum[3] & 0x7fffffffu)) | flag;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -162,6 +162,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_related_gaussians = num_related_gaussians
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, viewmatrix, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer, gt_depth)
+        ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for radii on every backward
+        ctx.mark_non_differentiable(radii)
         return color, radii, depth, uncertainty
 
     @staticmethod
@@ -171,6 +173,12 @@ class _RasterizeGaussians(torch.autograd.Function):
         raster_settings = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, viewmatrix, radii, sh, geomBuffer, binningBuffer,
          imgBuffer, gt_depth) = ctx.saved_tensors
+        # outputs that did not take part in the loss arrive as None: zeros, as the reference's autograd would have passed
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        zeros = lambda c: torch.zeros((c, H, W), dtype=torch.float32, device=means3D.device)  # noqa: E731
+        grad_out_color = zeros(3) if grad_out_color is None else grad_out_color
+        grad_out_depth = zeros(1) if grad_out_depth is None else grad_out_depth
+        grad_out_uncertainty = zeros(1) if grad_out_uncertainty is None else grad_out_uncertainty
         # argument packing of F/diff_gaussian_rasterization/__init__.py:104-131
         args = (raster_settings.bg,
                 means3D,

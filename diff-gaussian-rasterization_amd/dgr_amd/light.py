@@ -329,6 +329,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, viewmatrix, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer, opacity_map, gt_depth)
+        # Four of the eight outputs (radii, opacity_map, gau_uncertainty, gau_related_pixels) have no gradient input in
+        # the C++ backward; autograd would still zero-fill a gradient tensor for each of them on every backward.
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(radii, gau_related_pixels)
         return color, radii, depth, depth_median, depth_var, opacity_map, gau_uncertainty, gau_related_pixels
 
     @staticmethod
@@ -338,6 +342,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         raster_settings = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, viewmatrix, radii, sh, geomBuffer,
          binningBuffer, imgBuffer, opacity_map, gt_depth) = ctx.saved_tensors
+        # an output that did not take part in the loss arrives as None (gradients are not materialised): zeros, as the
+        # reference's autograd would have passed
+        H, W = int(raster_settings.image_height), int(raster_settings.image_width)
+        zeros = lambda c: torch.zeros((c, H, W), dtype=torch.float32, device=means3D.device)  # noqa: E731
+        grad_color = zeros(3) if grad_color is None else grad_color
+        grad_depth = zeros(1) if grad_depth is None else grad_depth
+        grad_depth_median = zeros(1) if grad_depth_median is None else grad_depth_median
+        grad_depth_var = zeros(1) if grad_depth_var is None else grad_depth_var
 
         # argument packing of L/diff_gaussian_rasterization/__init__.py:116-146
         args = (raster_settings.bg,

@@ -167,3 +167,30 @@ def test_light_autograd_surface_and_gradient_arena():
     assert span is not None and span.numel() >= s.P * (3 + 3 + 48 + 1 + 3 + 4)  # one contiguous all-reduce payload
     vis = rast.markVisible(means3D.detach())
     assert vis.dtype == torch.bool and vis.shape == (s.P,)
+
+
+def test_loss_on_a_subset_of_outputs():
+    """Outputs left out of the loss reach the backward as None (gradients are not materialised): the result must be
+    what explicit zero gradients give."""
+    from dgr_amd import light as D
+    from dgr_amd.multiview import make_settings
+    s = make_scene(3000, 96, 64, 11)
+    dev = hh.dev()
+    rast = D.GaussianRasterizer(make_settings(s, 3, dev))
+
+    def run(explicit_zeros):
+        means3D, shs, opac = hh.T(s.means).requires_grad_(), hh.T(s.shs).requires_grad_(), hh.T(s.opac).requires_grad_()
+        scales, rots, view = hh.T(s.scales).requires_grad_(), hh.T(s.rots).requires_grad_(), hh.T(s.view).requires_grad_()
+        means2D = torch.zeros((s.P, 3), device=dev, requires_grad=True)
+        color, radii, depth, median, var, alpha, unc, px = rast(
+            means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots, viewmatrix=view,
+            gt_depth=hh.T(s.gt))
+        if explicit_zeros:
+            z = torch.zeros_like(depth)
+            torch.autograd.backward([color, depth, median, var], [hh.T(s.gC), z, z, z])
+        else:
+            torch.autograd.backward([color], [hh.T(s.gC)])
+        return [t.grad.cpu().numpy() for t in (means3D, shs, opac, scales, rots, view, means2D)]
+
+    for a, b in zip(run(False), run(True)):
+        assert_grad_close(a, b, "subset", rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-3)
