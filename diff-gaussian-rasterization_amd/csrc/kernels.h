@@ -100,7 +100,7 @@ struct RenderBwdLightArgs {
 struct RenderFwdFullArgs {
     int W, H, grid_x, grid_y;
     const uint2* ranges;
-    const uint32_t* point_list;
+    uint32_t* point_list;  // read; the kernel writes the contribution tags into the top bits
     const float4* rec;
     const float* bg;
     float* out_color;

@@ -14,8 +14,6 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float ALPHA_MIN = 15.0f / 255.0f;  // forward.cu:365
-constexpr int SENTINEL = DGR_TILE_PIX;       // record slot that can never contribute (opacity 0)
-constexpr int LIST_LD = DGR_TILE_PIX + 8;    // list row: 256 entries + sentinel padding, 8-byte aligned rows
 
 // bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of tiles
 __device__ __forceinline__ int xcd_tile(int b, int n) {
@@ -25,14 +23,21 @@ __device__ __forceinline__ int xcd_tile(int b, int n) {
     return base + local;
 }
 
-struct Staged {
-    float4 rec[2 * (DGR_TILE_PIX + 1)];  // [2*slot] = {x, y, a2, b2}, [2*slot+1] = {c2, opacity, slot (int bits), lthr}
-                                         //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power
-    float4 rgbd[DGR_TILE_PIX];           // {r, g, b, depth}
-    uint32_t id[DGR_TILE_PIX];
-    unsigned short list[4][LIST_LD];     // per consumer wave: byte offsets (slot * 32) into rec, tile-list order
-    int cnt4[4][4];                      // [staging wave][consumer wave] entries contributed
+// NB = instances staged per batch (<= 256, one per thread).  The forward uses 256; the light backward 128, which
+// halves its LDS footprint (it is occupancy-bound: see DESIGN.md s4.2).
+template <int NB>
+struct StagedT {
+    static constexpr int SLOTS = NB;
+    static constexpr int SENTINEL = NB;       // record slot that can never contribute (opacity 0)
+    static constexpr int LIST_LD = NB + 8;    // list row: NB entries + sentinel padding, 8-byte aligned rows
+    float4 rec[2 * (NB + 1)];  // [2*slot] = {x, y, a2, b2}, [2*slot+1] = {c2, opacity, slot (int bits), lthr}
+                               //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power
+    float4 rgbd[NB];           // {r, g, b, depth}
+    uint32_t id[NB];
+    unsigned short list[4][LIST_LD];  // per consumer wave: byte offsets (slot * 32) into rec, tile-list order
+    int cnt4[4][4];                   // [staging wave][consumer wave] entries contributed
 };
+using Staged = StagedT<DGR_TILE_PIX>;
 
 // Stage one instance and return the 4-bit "may touch quadrant" code.
 // A quadrant is kept when the bounding box of the region alpha >= 15/255, i.e. q(d) <= tau = 2 ln(255 o / 15), reaches
@@ -40,7 +45,8 @@ struct Staged {
 // fast rcp / sqrt used here), so every dropped (pixel, Gaussian) pair is one the per-pixel test rejects.
 // (An exact ellipse-vs-quadrant test was measured: it removes almost no list entries beyond the box -- the
 // iterations without a valid lane are finished pixels and sub-pixel splats -- and costs more VALU than it saves.)
-__device__ __forceinline__ unsigned stage_one(Staged& s, int slot, uint32_t gid, const float4* __restrict__ rec,
+template <int NB>
+__device__ __forceinline__ unsigned stage_one(StagedT<NB>& s, int slot, uint32_t gid, const float4* __restrict__ rec,
                                               float tile_x0, float tile_y0, float4* raw_conic) {
     const float4 q0 = rec[3 * (size_t)gid + 0];
     const float4 q1 = rec[3 * (size_t)gid + 1];
@@ -76,7 +82,8 @@ constexpr int TAG_SHIFT = DGR_TAG_SHIFT;
 constexpr uint32_t ID_MASK = DGR_ID_MASK;
 
 // backward staging: returns the entry's tag; untagged entries are not loaded
-__device__ __forceinline__ unsigned stage_tagged(Staged& s, int slot, uint32_t entry, const float4* __restrict__ rec) {
+template <int NB>
+__device__ __forceinline__ unsigned stage_tagged(StagedT<NB>& s, int slot, uint32_t entry, const float4* __restrict__ rec) {
     const unsigned code = entry >> TAG_SHIFT;
     if (code == 0u) return 0u;
     const uint32_t gid = entry & ID_MASK;
@@ -96,7 +103,8 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
 
 // Builds the four per-consumer lists from the staging threads' quadrant codes.  Contains two barriers;
 // returns the (uniform) length of the calling wave's list, padded to a multiple of 4 with sentinels.
-__device__ __forceinline__ int build_lists(Staged& s, unsigned code, int tid, int wave, int lane) {
+template <int NB>
+__device__ __forceinline__ int build_lists(StagedT<NB>& s, unsigned code, int tid, int wave, int lane) {
     unsigned long long bal[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -114,12 +122,13 @@ __device__ __forceinline__ int build_lists(Staged& s, unsigned code, int tid, in
     }
     const int n = __builtin_amdgcn_readfirstlane(s.cnt4[0][wave] + s.cnt4[1][wave] + s.cnt4[2][wave] + s.cnt4[3][wave]);
     __syncthreads();
-    if (lane < 4) s.list[wave][n + lane] = (unsigned short)(SENTINEL * 32);  // own list, own wave: program order suffices
+    if (lane < 4) s.list[wave][n + lane] = (unsigned short)(StagedT<NB>::SENTINEL * 32);  // own list, own wave: program order suffices
     return n;
 }
 
 // two-entry form of load4 (fewer live registers: the backward trades a little load batching for occupancy)
-__device__ __forceinline__ void load2(const Staged& s, int wave, int k, float4 (&q0)[2], float4 (&q1)[2]) {
+template <int NB>
+__device__ __forceinline__ void load2(const StagedT<NB>& s, int wave, int k, float4 (&q0)[2], float4 (&q1)[2]) {
     const unsigned pk = *reinterpret_cast<const unsigned*>(&s.list[wave][k]);
     const unsigned off[2] = {pk & 0xffffu, pk >> 16};
     const char* base = reinterpret_cast<const char*>(s.rec);
@@ -130,7 +139,8 @@ __device__ __forceinline__ void load2(const Staged& s, int wave, int k, float4 (
     }
 }
 
-__device__ __forceinline__ void load4(const Staged& s, int wave, int k, float4 (&q0)[4], float4 (&q1)[4]) {
+template <int NB>
+__device__ __forceinline__ void load4(const StagedT<NB>& s, int wave, int k, float4 (&q0)[4], float4 (&q1)[4]) {
     const uint2 pk = *reinterpret_cast<const uint2*>(&s.list[wave][k]);
     const unsigned off[4] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
     const char* base = reinterpret_cast<const char*>(s.rec);
@@ -143,21 +153,22 @@ __device__ __forceinline__ void load4(const Staged& s, int wave, int k, float4 (
 
 
 // sentinel record: p2 = 0 but lthr = +big, so it never passes `p2 >= lthr`
-__device__ __forceinline__ void write_sentinel(Staged& s) {
-    s.rec[2 * SENTINEL] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s.rec[2 * SENTINEL + 1] = make_float4(0.f, 0.f, __int_as_float(SENTINEL), 3.0e38f);
+template <int NB>
+__device__ __forceinline__ void write_sentinel(StagedT<NB>& s) {
+    s.rec[2 * NB] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s.rec[2 * NB + 1] = make_float4(0.f, 0.f, __int_as_float(NB), 3.0e38f);
 }
 
 constexpr int NACC = DGR_ACC_STRIDE;          // accumulator components carried per staged instance (<= 16)
 constexpr int ACC_LD = DGR_TILE_PIX + 1;      // component-major LDS accumulators, +1 pad for the transposed flush
 
 // flush of the per-batch LDS accumulators: 16 consecutive lanes cover one Gaussian's 64-byte accumulator row
-template <int NCOMP>
+template <int NCOMP, int LD = ACC_LD>
 __device__ __forceinline__ void flush_acc(const float* lds_acc, const uint32_t* ids, int cnt, float* global_acc, int tid) {
     const int comp = tid & 15;
     if (comp < NCOMP) {
         for (int r = tid >> 4; r < cnt; r += 16) {
-            const float v = lds_acc[comp * ACC_LD + r];
+            const float v = lds_acc[comp * LD + r];
             if (v != 0.f) atomicAdd(global_acc + (size_t)ids[r] * DGR_ACC_STRIDE + comp, v);
         }
     }

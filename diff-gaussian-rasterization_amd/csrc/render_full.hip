@@ -20,8 +20,17 @@ namespace dgr {
 namespace {
 
 // ================================================================================ forward
-__global__ void __launch_bounds__(256) render_fwd_full_kernel(RenderFwdFullArgs a) {
+// contribution tag of the batch staged at list position pos0 -> top bits of the point_list entry (render_common.h)
+__device__ __forceinline__ void flush_tags(const Staged& s, const uint32_t* hit, uint32_t* point_list, uint32_t pos0, int tid) {
+    const uint32_t h = hit[tid];
+    if (h == 0u) return;
+    const uint32_t tag = (h & 1u) | ((h >> 7) & 2u) | ((h >> 14) & 4u) | ((h >> 21) & 8u);
+    point_list[pos0 + tid] = s.id[tid] | (tag << TAG_SHIFT);
+}
+
+__global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullArgs a) {
     __shared__ Staged s;
+    __shared__ uint32_t hit[DGR_TILE_PIX];  // byte w of word j: quadrant wave w blended staged instance j
     __shared__ int s_nvalid;
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -44,8 +53,14 @@ __global__ void __launch_bounds__(256) render_fwd_full_kernel(RenderFwdFullArgs 
         s_nvalid = 0;
     }
 
+    bool have_flush = false;
+    int last_base = 0;
     for (int base = 0; base < total; base += DGR_TILE_PIX) {
         if (__syncthreads_and(ub < 0.f)) break;
+        if (have_flush) flush_tags(s, hit, a.point_list, range.x + base - DGR_TILE_PIX, tid);
+        hit[tid] = 0u;
+        have_flush = true;
+        last_base = base;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
         if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0, nullptr);
@@ -63,6 +78,7 @@ __global__ void __launch_bounds__(256) render_fwd_full_kernel(RenderFwdFullArgs 
                   if (alpha >= ALPHA_MIN) {
                     const int j = __float_as_int(q1[u].z);
                     const float4 cd = s.rgbd[j];
+                    reinterpret_cast<unsigned char*>(hit)[4 * j + wave] = 1;  // contribution tag
                     const float w = alpha * T;
                     C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
                     Dd += cd.w * w;
@@ -78,6 +94,9 @@ __global__ void __launch_bounds__(256) render_fwd_full_kernel(RenderFwdFullArgs 
             if (!wave_any(ub >= 0.f)) break;
         }
     }
+
+    __syncthreads();
+    if (have_flush) flush_tags(s, hit, a.point_list, range.x + last_base, tid);
 
     if (inside) {
         const size_t N = (size_t)a.W * a.H;
@@ -106,15 +125,17 @@ __global__ void __launch_bounds__(256) render_fwd_full_kernel(RenderFwdFullArgs 
 // ================================================================================ backward
 constexpr int NACC_FULL = 15;
 
+constexpr int BWD_NB = 128;          // list positions staged per batch (occupancy: see render_light.hip)
+constexpr int BWD_LD = BWD_NB + 1;
 struct StagedBwdFull {
-    Staged f;
-    float acc[NACC_FULL * ACC_LD];
+    StagedT<BWD_NB> f;
+    float acc[NACC_FULL * BWD_LD];
     int max_last;
 };
 
-__global__ void __launch_bounds__(256) render_bwd_full_kernel(RenderBwdFullArgs a) {
+__global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullArgs a) {
     __shared__ StagedBwdFull sb;
-    Staged& s = sb.f;
+    StagedT<BWD_NB>& s = sb.f;
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -124,7 +145,6 @@ __global__ void __launch_bounds__(256) render_bwd_full_kernel(RenderBwdFullArgs 
     const size_t pix_id = (size_t)a.W * py + px;
     const size_t N = (size_t)a.W * a.H;
     const float pxf = (float)px, pyf = (float)py;
-    const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
 
     const uint2 range = a.ranges[tile];
     const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
@@ -165,14 +185,15 @@ __global__ void __launch_bounds__(256) render_bwd_full_kernel(RenderBwdFullArgs 
     const int c16 = wave_reduce16_comp(lane);
     const int my_comp = ((lane & 3) == 0 && c16 < NACC_FULL) ? c16 : -1;
 
-    for (int hi = total; hi > 0; hi -= DGR_TILE_PIX) {
-        const int lo = max(0, hi - DGR_TILE_PIX);
+    for (int hi = total; hi > 0; hi -= BWD_NB) {
+        const int lo = max(0, hi - BWD_NB);
         const int cnt = hi - lo;
         __syncthreads();
         unsigned code = 0;
-        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0, nullptr);
+        if (tid < cnt) code = stage_tagged(s, tid, a.point_list[range.x + lo + tid], a.rec);
 #pragma unroll
-        for (int k = 0; k < NACC_FULL; k++) sb.acc[k * ACC_LD + tid] = 0.f;
+        for (int k = 0; k < NACC_FULL; k++)
+            if (tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
         const int n = build_lists(s, code, tid, wave, lane);
         const int rel_last = last_contributor - lo;
         const int rel_first = first_contributor - 1 - lo;  // slot of the front-most valid contributor, if in this batch
@@ -185,11 +206,10 @@ __global__ void __launch_bounds__(256) render_bwd_full_kernel(RenderBwdFullArgs 
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
                 const int j = __float_as_int(q1[u].z);
-                if (!wave_any((j < rel_last) & (p2 <= 0.0f) & (p2 >= q1[u].w))) continue;
+                // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, q1[u].y * G);
-                const bool valid = j < rel_last && p2 <= 0.0f && alpha >= ALPHA_MIN;
-                if (!wave_any(valid)) continue;
+                const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
 
                 // per-lane scalars (0 on lanes the Gaussian does not reach): w = alpha T, qq = o G dL/dalpha,
                 // qc = o G * (colour-only part of dL/dalpha), and the front-most-pair depth terms
@@ -237,29 +257,29 @@ __global__ void __launch_bounds__(256) render_bwd_full_kernel(RenderBwdFullArgs 
                 g[14] = fq * dy;
                 g[15] = 0.f;
                 const float tot = wave_reduce16(g, lane);
-                if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * ACC_LD + j], tot);
+                if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * BWD_LD + j], tot);
             }
         }
         __syncthreads();
         // moments -> gradients per staged Gaussian: every "d/d(ndc)" sum is -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2
-        if (tid < cnt) {
+        if (code != 0u) {
             constexpr float LN2 = 0.6931471805599453f;
             const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
             const float ca = r0.z * (-2.f * LN2), cb = r0.w * (-LN2), cc = r1.x * (-2.f * LN2);
 #pragma unroll
             for (int p = 0; p < 3; p++) {
                 const int cx = (p == 0) ? 4 : (p == 1) ? 10 : 13, cy = cx + 1;
-                const float Sx = sb.acc[cx * ACC_LD + tid], Sy = sb.acc[cy * ACC_LD + tid];
-                sb.acc[cx * ACC_LD + tid] = -(ca * Sx + cb * Sy) * ddelx_dx;
-                sb.acc[cy * ACC_LD + tid] = -(cc * Sy + cb * Sx) * ddely_dy;
+                const float Sx = sb.acc[cx * BWD_LD + tid], Sy = sb.acc[cy * BWD_LD + tid];
+                sb.acc[cx * BWD_LD + tid] = -(ca * Sx + cb * Sy) * ddelx_dx;
+                sb.acc[cy * BWD_LD + tid] = -(cc * Sy + cb * Sx) * ddely_dy;
             }
-            sb.acc[6 * ACC_LD + tid] *= -0.5f;
-            sb.acc[7 * ACC_LD + tid] *= -0.5f;
-            sb.acc[8 * ACC_LD + tid] *= -0.5f;
-            sb.acc[9 * ACC_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
+            sb.acc[6 * BWD_LD + tid] *= -0.5f;
+            sb.acc[7 * BWD_LD + tid] *= -0.5f;
+            sb.acc[8 * BWD_LD + tid] *= -0.5f;
+            sb.acc[9 * BWD_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
         }
         __syncthreads();
-        flush_acc<NACC_FULL>(sb.acc, s.id, cnt, a.acc, tid);
+        flush_acc<NACC_FULL, BWD_LD>(sb.acc, s.id, cnt, a.acc, tid);
     }
 }
 

@@ -164,16 +164,30 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
 // Tracking mode (map_off) needs only the three sums the pose gradient is built from: a 4-value butterfly.
 constexpr int NACC_LIGHT = 14;
 
+#ifndef DGR_BWD_LDS_PAD
+#define DGR_BWD_LDS_PAD 0
+#endif
+#ifndef DGR_BWD_BATCH
+#define DGR_BWD_BATCH 128
+#endif
+constexpr int BWD_NB = DGR_BWD_BATCH;      // list positions staged per batch
+constexpr int BWD_LD = BWD_NB + 1;         // accumulator row length
 struct StagedBwd {
-    Staged f;
-    float acc[NACC_LIGHT * ACC_LD];
+    StagedT<BWD_NB> f;
+    float acc[NACC_LIGHT * BWD_LD];
     int max_last;
+#if DGR_BWD_LDS_PAD
+    char pad[DGR_BWD_LDS_PAD];  // occupancy experiment
+#endif
 };
 
+#ifndef DGR_BWD_WAVES
+#define DGR_BWD_WAVES 8  // waves per SIMD the register allocation must allow (measured: 4 -> 258 us, 8 -> 247 us)
+#endif
 template <bool DO_MAP, bool DO_POSE>
-__global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArgs a) {
+__global__ void __launch_bounds__(256, DGR_BWD_WAVES) render_bwd_light_kernel(RenderBwdLightArgs a) {
     __shared__ StagedBwd sb;
-    Staged& s = sb.f;
+    StagedT<BWD_NB>& s = sb.f;
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -190,6 +204,9 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
     if (tid == 0) {
         sb.max_last = 0;
         write_sentinel(s);
+#if DGR_BWD_LDS_PAD
+        sb.pad[a.W & 7] = 1;
+#endif
     }
     __syncthreads();
     {
@@ -234,14 +251,15 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
     }
 
     // back-to-front: batches cover list positions [lo, hi) with hi walking down from `total`
-    for (int hi = total; hi > 0; hi -= DGR_TILE_PIX) {
-        const int lo = max(0, hi - DGR_TILE_PIX);
+    for (int hi = total; hi > 0; hi -= BWD_NB) {
+        const int lo = max(0, hi - BWD_NB);
         const int cnt = hi - lo;
         __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
         if (tid < cnt) code = stage_tagged(s, tid, a.point_list[range.x + lo + tid], a.rec);
 #pragma unroll
-        for (int k = 0; k < NACC_LIGHT; k++) sb.acc[k * ACC_LD + tid] = 0.f;
+        for (int k = 0; k < NACC_LIGHT; k++)
+            if (BWD_NB == DGR_TILE_PIX || tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
         const int n = build_lists(s, code, tid, wave, lane);
         const int rel_last = last_contributor - lo;  // slots below this are at or before the last contributor
 
@@ -278,9 +296,9 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                     if (DO_MAP && T > 0.5f && mid_once) {  // backward.cu:654-664: once per pixel, straight to LDS
                         const float* mg = a.means3D + 3 * (size_t)s.id[j];
                         const float mul3 = v2 * mg[0] + v6 * mg[1] + v10 * mg[2] + v14;
-                        atomicAdd(&sb.acc[10 * ACC_LD + j], (v2 - v3 * mul3) * dpix_median);
-                        atomicAdd(&sb.acc[11 * ACC_LD + j], (v6 - v7 * mul3) * dpix_median);
-                        atomicAdd(&sb.acc[12 * ACC_LD + j], (v10 - v11 * mul3) * dpix_median);
+                        atomicAdd(&sb.acc[10 * BWD_LD + j], (v2 - v3 * mul3) * dpix_median);
+                        atomicAdd(&sb.acc[11 * BWD_LD + j], (v6 - v7 * mul3) * dpix_median);
+                        atomicAdd(&sb.acc[12 * BWD_LD + j], (v10 - v11 * mul3) * dpix_median);
                         mid_once = false;
                     }
                 }
@@ -309,7 +327,7 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
                     tot = wave_reduce4(g4);
                 }
                 // j is wave-uniform here (every lane read the same record)
-                if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * ACC_LD + j], tot);
+                if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * BWD_LD + j], tot);
             }
         }
 
@@ -320,18 +338,18 @@ __global__ void __launch_bounds__(256) render_bwd_light_kernel(RenderBwdLightArg
             constexpr float LN2 = 0.6931471805599453f;
             const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
             const float ca = r0.z * (-2.f * LN2), cb = r0.w * (-LN2), cc = r1.x * (-2.f * LN2);  // unscaled conic
-            const float Sx = sb.acc[4 * ACC_LD + tid], Sy = sb.acc[5 * ACC_LD + tid];
-            sb.acc[4 * ACC_LD + tid] = -(ca * Sx + cb * Sy) * ddelx_dx;
-            sb.acc[5 * ACC_LD + tid] = -(cc * Sy + cb * Sx) * ddely_dy;
+            const float Sx = sb.acc[4 * BWD_LD + tid], Sy = sb.acc[5 * BWD_LD + tid];
+            sb.acc[4 * BWD_LD + tid] = -(ca * Sx + cb * Sy) * ddelx_dx;
+            sb.acc[5 * BWD_LD + tid] = -(cc * Sy + cb * Sx) * ddely_dy;
             if (DO_MAP) {
-                sb.acc[6 * ACC_LD + tid] *= -0.5f;
-                sb.acc[7 * ACC_LD + tid] *= -0.5f;
-                sb.acc[8 * ACC_LD + tid] *= -0.5f;
-                sb.acc[9 * ACC_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
+                sb.acc[6 * BWD_LD + tid] *= -0.5f;
+                sb.acc[7 * BWD_LD + tid] *= -0.5f;
+                sb.acc[8 * BWD_LD + tid] *= -0.5f;
+                sb.acc[9 * BWD_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
             }
         }
         __syncthreads();
-        flush_acc<NACC_LIGHT>(sb.acc, s.id, cnt, a.acc, tid);
+        flush_acc<NACC_LIGHT, BWD_LD>(sb.acc, s.id, cnt, a.acc, tid);
     }
 }
 
