@@ -6,7 +6,11 @@ TAG=${1:-r1}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+# kernel trace of the default bench command (several views in flight: kernel durations include time-sharing), and of
+# the same workload one view at a time (isolated kernel durations); the counter passes use the isolated form
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/stats_default -o trace -- $BENCH > $OUT/bench_stats_default.log 2>&1
+CMD="$BENCH --views-in-flight 1"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- $CMD > $OUT/bench_stats.log 2>&1
 # PMC passes, one counter group per run (SQ: 8 slots; TCC: FETCH_SIZE 3 + WRITE_SIZE 2 do not fit together)
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS -d $OUT/pmc_sq1 -o pmc -- $CMD > $OUT/bench_pmc1.log 2>&1

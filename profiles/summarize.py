@@ -18,8 +18,13 @@ def short(name):
 
 
 def main(src, dst):
+    kernel_stats(os.path.join(src, "stats_default", "trace_results.db"), dst + "_default_cmd_kernel_stats.txt")
+    kernel_stats(os.path.join(src, "stats", "trace_results.db"), dst + "_kernel_stats.txt")
+    pmc(src, dst)
+
+
+def kernel_stats(db, path):
     out = []
-    db = os.path.join(src, "stats", "trace_results.db")
     if os.path.exists(db):
         con = sqlite3.connect(db)
         rows = con.execute("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
@@ -28,8 +33,11 @@ def main(src, dst):
         out.append(f"{'kernel':72s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'total_us':>11s} {'%':>6s}")
         for r in rows:
             out.append(f"{short(r[0]):72s} {r[1]:6d} {r[2]/1e3:10.1f} {r[3]/1e3:10.1f} {r[4]/1e3:10.1f} {r[5]/1e3:11.1f} {100*r[5]/tot:6.2f}")
-        open(dst + "_kernel_stats.txt", "w").write("\n".join(out) + "\n")
+        open(path, "w").write("\n".join(out) + "\n")
         print("\n".join(out[:12]))
+
+
+def pmc(src, dst):
     lines = []
     for db in sorted(glob.glob(os.path.join(src, "pmc_*", "*.db"))):
         con = sqlite3.connect(db)
