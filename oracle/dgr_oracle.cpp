@@ -1106,7 +1106,114 @@ void renderBackwardFull(const State& st, const float* bg, const float* colors, c
 }  // namespace
 
 // =================================================================== C entry points
+// ---------------------------------------------------------------------------------------------------------
+// Analysis aid (not part of the reference): how many (pixel block, Gaussian) pairs a blend kernel has to visit when a
+// 16x16 tile is split into 8x8 quadrants or into 4x4 blocks.  Light-variant termination rules.  out[0..9]:
+//  0 blended (pixel, Gaussian) pairs            1 instances blended by at least one pixel
+//  2 (8x8, Gaussian) pairs with a blended pixel 3 (4x4, Gaussian) pairs with a blended pixel
+//  4 (8x8, Gaussian) pairs a box-culled forward visits (box of alpha >= 15/255 meets the block, block not finished)
+//  5 the same for 4x4 blocks
+//  6 sum over quadrants of max over its four 4x4 blocks of [5]-type counts (iterations of a wave whose 16-lane rows
+//    walk one block's list each)               7 the same for [3]-type counts (backward)
+//  8 sum over tiles of max over 4 quadrants of [4]-type counts   9 the same for [2]
+void pairStats(const State& st, double* out) {
+    const int W = st.W, H = st.H;
+    const int tiles = st.gx * st.gy;
+    double acc[10] = {0};
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < tiles; tile++) {
+        const uint32_t r0 = st.ranges[2 * tile], r1 = st.ranges[2 * tile + 1];
+        const int tx = tile % st.gx, ty = tile / st.gx;
+        float T[256];
+        bool done[256], inside[256];
+        for (int p = 0; p < 256; p++) {
+            const uint32_t px = tx * 16 + (p & 15), py = ty * 16 + (p >> 4);
+            inside[p] = px < (uint32_t)W && py < (uint32_t)H;
+            T[p] = 1.f;
+            done[p] = !inside[p];
+        }
+        double loc[10] = {0};
+        int q_tested[4] = {0}, q_valid[4] = {0}, b_tested[16] = {0}, b_valid[16] = {0};
+        for (uint32_t k = r0; k < r1; k++) {
+            bool all_done = true;
+            for (int p = 0; p < 256; p++) all_done = all_done && done[p];
+            if (all_done) break;
+            const uint32_t id = st.point_list[k];
+            const float gx_ = st.means2D[2 * (size_t)id], gy_ = st.means2D[2 * (size_t)id + 1];
+            const float* co = &st.conic_opacity[4 * (size_t)id];
+            // box of the region alpha >= 15/255
+            const float tau = 2.f * std::log(co[3] * 255.f / 15.f);
+            const float det = co[0] * co[2] - co[1] * co[1];
+            float hx = 1e9f, hy = 1e9f;
+            if (det > 0 && tau > 0) { hx = std::sqrt(tau * co[2] / det); hy = std::sqrt(tau * co[0] / det); }
+            const float lx = gx_ - tx * 16, ly = gy_ - ty * 16;
+            bool blended[256];
+            bool any = false;
+            for (int p = 0; p < 256; p++) {
+                blended[p] = false;
+                if (done[p]) continue;
+                const float pfx = (float)(tx * 16 + (p & 15)), pfy = (float)(ty * 16 + (p >> 4));
+                const float dx = gx_ - pfx, dy = gy_ - pfy;
+                const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                if (power > 0.0f) continue;
+                const float alpha = std::min(0.99f, co[3] * std::exp(power));
+                if (alpha < 15.0f / 255.0f) continue;
+                const float test_T = T[p] * (1 - alpha);
+                if (test_T < 0.0001f) { done[p] = true; continue; }
+                T[p] = test_T;
+                blended[p] = true;
+                any = true;
+                loc[0] += 1;
+            }
+            if (any) loc[1] += 1;
+            for (int q = 0; q < 4; q++) {
+                const int x0 = (q & 1) * 8, y0 = (q >> 1) * 8;
+                bool v = false, alive = false;
+                for (int yy = 0; yy < 8; yy++)
+                    for (int xx = 0; xx < 8; xx++) {
+                        const int p = (y0 + yy) * 16 + x0 + xx;
+                        v = v || blended[p];
+                        alive = alive || !done[p] || blended[p];
+                    }
+                const bool box = tau > 0 && lx + hx >= x0 && lx - hx <= x0 + 7 && ly + hy >= y0 && ly - hy <= y0 + 7;
+                if (v) { loc[2] += 1; q_valid[q]++; }
+                if (box && alive) { loc[4] += 1; q_tested[q]++; }
+            }
+            for (int b = 0; b < 16; b++) {
+                const int x0 = (b & 3) * 4, y0 = (b >> 2) * 4;
+                bool v = false, alive = false;
+                for (int yy = 0; yy < 4; yy++)
+                    for (int xx = 0; xx < 4; xx++) {
+                        const int p = (y0 + yy) * 16 + x0 + xx;
+                        v = v || blended[p];
+                        alive = alive || !done[p] || blended[p];
+                    }
+                const bool box = tau > 0 && lx + hx >= x0 && lx - hx <= x0 + 3 && ly + hy >= y0 && ly - hy <= y0 + 3;
+                if (v) { loc[3] += 1; b_valid[b]++; }
+                if (box && alive) { loc[5] += 1; b_tested[b]++; }
+            }
+        }
+        for (int q = 0; q < 4; q++) {
+            int mt = 0, mv = 0;
+            for (int r = 0; r < 4; r++) {
+                const int b = ((q >> 1) * 2 + (r >> 1)) * 4 + (q & 1) * 2 + (r & 1);
+                mt = std::max(mt, b_tested[b]);
+                mv = std::max(mv, b_valid[b]);
+            }
+            loc[6] += mt;
+            loc[7] += mv;
+        }
+        loc[8] += std::max(std::max(q_tested[0], q_tested[1]), std::max(q_tested[2], q_tested[3]));
+        loc[9] += std::max(std::max(q_valid[0], q_valid[1]), std::max(q_valid[2], q_valid[3]));
+#pragma omp critical
+        for (int i = 0; i < 10; i++) acc[i] += loc[i];
+    }
+    for (int i = 0; i < 10; i++) out[i] = acc[i];
+}
+
 extern "C" {
+void dgro_pair_stats(void* st, double* out) { pairStats(*(State*)st, out); }
+
 
 void* dgro_state_new() { return new State(); }
 void dgro_state_free(void* s) { delete static_cast<State*>(s); }
