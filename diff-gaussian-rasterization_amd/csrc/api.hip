@@ -21,6 +21,10 @@
 #include "dgr_common.h"
 #include "kernels.h"
 
+namespace dgr {
+thread_local LaunchEvents* g_launch_events = nullptr;
+}
+
 namespace {
 
 thread_local std::string g_last_error = "";
@@ -50,21 +54,35 @@ enum { ST_PRE_FWD, ST_SCAN_BLOCKS, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_
        ST_COUNT };
 std::mutex g_prof_mu;
 
+// A kernel stage hands its two events to the stage's first kernel launch (dgr::launch, kernels.h): they then hold
+// that kernel's start and end.  A stage without a kernel (the scratch memset) is bracketed with hipEventRecord.
 struct ScopedStage {
     StageProf* p = nullptr;
     hipStream_t st;
-    hipEvent_t a{}, b{};
-    ScopedStage(int id, hipStream_t s) : st(s) {
+    dgr::LaunchEvents le{};
+    bool kernel_stage;
+    ScopedStage(int id, hipStream_t s, bool is_kernel = true) : st(s), kernel_stage(is_kernel) {
         if (!g_prof[id].on) return;
         p = &g_prof[id];
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { p = nullptr; return; }
-        (void)hipEventRecord(a, st);
+        if (hipEventCreate(&le.start) != hipSuccess || hipEventCreate(&le.stop) != hipSuccess) { p = nullptr; return; }
+        le.used = false;
+        if (kernel_stage) dgr::g_launch_events = &le;
+        else (void)hipEventRecord(le.start, st);
     }
     ~ScopedStage() {
         if (!p) return;
-        (void)hipEventRecord(b, st);
+        if (kernel_stage) {
+            dgr::g_launch_events = nullptr;
+            if (!le.used) {  // nothing was launched (empty input)
+                (void)hipEventDestroy(le.start);
+                (void)hipEventDestroy(le.stop);
+                return;
+            }
+        } else {
+            (void)hipEventRecord(le.stop, st);
+        }
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        p->ev.emplace_back(a, b);
+        p->ev.emplace_back(le.start, le.stop);
     }
 };
 
@@ -331,7 +349,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    { ScopedStage t(ST_ZERO, st); HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
+    { ScopedStage t(ST_ZERO, st, false); HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
 
     dgr::RenderBwdLightArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
@@ -458,7 +476,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    { ScopedStage t(ST_ZERO, st); HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
+    { ScopedStage t(ST_ZERO, st, false); HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
 
     dgr::RenderBwdFullArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;

@@ -318,26 +318,26 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_tiles_kernel(ImageView img,
 }  // namespace
 
 hipError_t launch_scan_tiles(ImageView img, int tiles, int capacity, hipStream_t stream) {
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, img, tiles, capacity);
+    launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, capacity);
     return hipGetLastError();
 }
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,
                              hipStream_t stream) {
     if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(count_rank_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom, img, bin, grid_x, capacity);
+    launch(count_rank_kernel, dim3((P + 255) / 256), dim3(256), stream, P, geom, img, bin, grid_x, capacity);
     return hipGetLastError();
 }
 hipError_t launch_scan_blocks(int P, GeometryView geom, ImageView img, hipStream_t stream) {
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, geom.block_tiles, (P + 255) / 256, img.status);
+    launch(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), stream, geom.block_tiles, (P + 255) / 256, img.status);
     return hipGetLastError();
 }
 hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, geom, img, bin, grid_x);
+    launch(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), stream, P, geom, img, bin, grid_x);
     return hipGetLastError();
 }
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream) {
-    hipLaunchKernelGGL(sort_tiles_kernel, dim3(tiles), dim3(SORT_THREADS), 0, stream, img, bin);
+    launch(sort_tiles_kernel, dim3(tiles), dim3(SORT_THREADS), stream, img, bin);
     return hipGetLastError();
 }
 

@@ -1,8 +1,32 @@
 // kernels.h -- argument blocks and launch entry points of the gfx950 kernels (internal).
 #pragma once
+#include <hip/hip_ext.h>
 #include "dgr_common.h"
 
 namespace dgr {
+
+// Kernel launches go through dgr::launch().  When the profiler (dgr_profile_*) brackets a stage it sets
+// `g_launch_events` for the calling thread and the next kernel is launched with hipExtLaunchKernelGGL, which puts
+// the two events into the kernel's own dispatch packet: they hold the kernel's start and end, the same
+// timestamps rocprofv3 reports, also when other streams keep the GPU busy (a hipEventRecord bracket would include
+// the time the kernel's waves wait for compute units).
+struct LaunchEvents {
+    hipEvent_t start, stop;
+    bool used;
+};
+extern thread_local LaunchEvents* g_launch_events;  // api.hip
+
+template <typename K, typename... Args>
+inline void launch(K kernel, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+    LaunchEvents* ev = g_launch_events;
+    if (ev && !ev->used) {
+        ev->used = true;
+        hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, ev->start, ev->stop, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
+    }
+}
+
 
 struct PreprocessFwdArgs {
     int P, D, M, W, H, grid_x, grid_y;

@@ -662,22 +662,22 @@ __global__ void __launch_bounds__(1024) pose_reduce_kernel(const float* __restri
 namespace dgr {
 hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream) {
     if (a.P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, stream, a);
+    launch(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), stream, a);
     return hipGetLastError();
 }
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hipStream_t stream) {
     const int blocks = (a.P + 255) / 256;
     if (blocks > 0) {
-        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        launch(preprocess_bwd_kernel, dim3(blocks), dim3(256), stream, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(pose_reduce_kernel, dim3(1), dim3(1024), 0, stream, a.pose_part, blocks, dL_dview, a.track_off);
+    launch(pose_reduce_kernel, dim3(1), dim3(1024), stream, a.pose_part, blocks, dL_dview, a.track_off);
     return hipGetLastError();
 }
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream) {
     if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, stream, P, means, view, present);
+    launch(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), stream, P, means, view, present);
     return hipGetLastError();
 }
 }  // namespace dgr

@@ -288,13 +288,13 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
 hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_fwd_full_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    launch(render_fwd_full_kernel, dim3(tiles), dim3(256), stream, a);
     return hipGetLastError();
 }
 hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_bwd_full_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    launch(render_bwd_full_kernel, dim3(tiles), dim3(256), stream, a);
     return hipGetLastError();
 }
 

@@ -378,22 +378,22 @@ __global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, f
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(render_fwd_light_kernel, dim3(tiles), dim3(256), 0, stream, a);
+    launch(render_fwd_light_kernel, dim3(tiles), dim3(256), stream, a);
     return hipGetLastError();
 }
 hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0 || (a.track_off && a.map_off)) return hipSuccess;
     if (!a.map_off && !a.track_off)
-        hipLaunchKernelGGL((render_bwd_light_kernel<true, true>), dim3(tiles), dim3(256), 0, stream, a);
+        launch((render_bwd_light_kernel<true, true>), dim3(tiles), dim3(256), stream, a);
     else if (!a.map_off)
-        hipLaunchKernelGGL((render_bwd_light_kernel<true, false>), dim3(tiles), dim3(256), 0, stream, a);
+        launch((render_bwd_light_kernel<true, false>), dim3(tiles), dim3(256), stream, a);
     else
-        hipLaunchKernelGGL((render_bwd_light_kernel<false, true>), dim3(tiles), dim3(256), 0, stream, a);
+        launch((render_bwd_light_kernel<false, true>), dim3(tiles), dim3(256), stream, a);
     return hipGetLastError();
 }
 hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, hipStream_t stream) {
-    hipLaunchKernelGGL(wave_reduce_test_kernel, dim3(1), dim3(64), 0, stream, in, out16, out4, comp16, comp4);
+    launch(wave_reduce_test_kernel, dim3(1), dim3(64), stream, in, out16, out4, comp16, comp4);
     return hipGetLastError();
 }
 
