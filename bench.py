@@ -106,7 +106,7 @@ def main():
 
     os.environ["DGR_SYNC_MODE"] = args.sync_mode
     from dgr_amd import _capi, light
-    from dgr_amd.multiview import GradientArena, make_settings
+    from dgr_amd.multiview import GradientArena, ViewStreams, make_settings
     from dgr_amd.synth import make_scene
     if args.variant == "full":
         from dgr_amd import full as V
@@ -171,15 +171,16 @@ def main():
         torch.cuda.synchronize(dev)
 
     K = max(1, args.views_in_flight)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(K)] if K > 1 else [torch.cuda.current_stream(dev)]
-    for st_ in streams:
-        st_.wait_stream(torch.cuda.current_stream(dev))
+    views = ViewStreams(K, dev) if K > 1 else None  # dgr_amd.multiview: independent views on K HIP streams
 
     def run(n):
         r = None
         for i in range(n):
-            with torch.cuda.stream(streams[i % K]):
+            if views is None:
                 r = step()
+            else:
+                with views.next():
+                    r = step()
         return r
 
     for _ in range(args.warmup):
