@@ -149,12 +149,69 @@ __device__ __forceinline__ M3 diag3(float a, float b, float c) {
 
 }  // namespace
 
+// ---- SH rows <-> lanes through LDS
+// A lane that reads (or writes) its own 192-byte SH row touches 12 cache lines, one per instruction, and a wave
+// instruction 64 different lines: four times the requests the data needs.  Here a wave moves the rows of 32 Gaussians
+// at a time with contiguous 1-KB accesses and transposes them in LDS (row stride 52 dwords: b128-aligned, and the 64
+// lanes' rows fall on all banks evenly).  Used for blocks that lie entirely inside [0, P).
+constexpr int SHT_ROWS = 32, SHT_LD = 52;
+__device__ __forceinline__ void sh_rows_to_lanes(const float* __restrict__ src, size_t g_block, float* lds, float (&f)[48]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* my = lds + wave * (SHT_ROWS * SHT_LD);
+    const float4* base = reinterpret_cast<const float4*>(src) + (g_block + (size_t)wave * 64) * 12;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const float4* p = base + (size_t)r * SHT_ROWS * 12;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int e = i * 64 + lane;  // float4 index inside the 32-row slab
+            const int g = e / 12, c = e - 12 * g;
+            *reinterpret_cast<float4*>(my + g * SHT_LD + 4 * c) = p[e];
+        }
+        __syncthreads();
+        if ((lane >> 5) == r) {
+            const float* row = my + (lane & 31) * SHT_LD;
+#pragma unroll
+            for (int c = 0; c < 12; c++) {
+                const float4 v = *reinterpret_cast<const float4*>(row + 4 * c);
+                f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w;
+            }
+        }
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void lanes_to_sh_rows(const float (&f)[48], float* __restrict__ dst, size_t g_block, float* lds) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* my = lds + wave * (SHT_ROWS * SHT_LD);
+    float4* base = reinterpret_cast<float4*>(dst) + (g_block + (size_t)wave * 64) * 12;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if ((lane >> 5) == r) {
+            float* row = my + (lane & 31) * SHT_LD;
+#pragma unroll
+            for (int c = 0; c < 12; c++)
+                *reinterpret_cast<float4*>(row + 4 * c) = make_float4(f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]);
+        }
+        __syncthreads();
+        float4* p = base + (size_t)r * SHT_ROWS * 12;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int e = i * 64 + lane;
+            const int g = e / 12, c = e - 12 * g;
+            p[e] = *reinterpret_cast<const float4*>(my + g * SHT_LD + 4 * c);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     int radius = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
     bool violation = false;
+    float3 p_sh = make_float3(0.f, 0.f, 0.f);  // position of a Gaussian whose colour still has to be evaluated from SH
+    bool need_sh = false;
     // Zeroing that would otherwise be stream memsets (one launch each): the tile counters count_rank increments and
     // the two per-Gaussian median statistics the forward blend accumulates into.
     for (int i = idx; i < a.n_zero_words; i += gridDim.x * 256) a.zero_words[i] = 0u;
@@ -211,34 +268,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
                     rgb = make_float3(a.colors_precomp[3 * (size_t)idx], a.colors_precomp[3 * (size_t)idx + 1],
                                       a.colors_precomp[3 * (size_t)idx + 2]);
                 } else {
-                    // computeColorFromSH (forward.cu:20-71)
-                    SHCoeffs s;
-                    load_sh(a.shs, idx, a.D, a.M, a.sh_vec_ok, s);
-                    const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
-                    float3 dir = p_orig - cam;
-                    const float len = sqrtf(dot3(dir, dir));
-                    dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
-                    float3 res = SH_C0 * s.c[0];
-                    if (a.D > 0) {
-                        const float x = dir.x, y = dir.y, z = dir.z;
-                        res = res - SH_C1 * y * s.c[1] + SH_C1 * z * s.c[2] - SH_C1 * x * s.c[3];
-                        if (a.D > 1) {
-                            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                            res = res + SH_C2[0] * xy * s.c[4] + SH_C2[1] * yz * s.c[5] +
-                                  SH_C2[2] * (2.0f * zz - xx - yy) * s.c[6] + SH_C2[3] * xz * s.c[7] +
-                                  SH_C2[4] * (xx - yy) * s.c[8];
-                            if (a.D > 2) {
-                                res = res + SH_C3[0] * y * (3.0f * xx - yy) * s.c[9] + SH_C3[1] * xy * z * s.c[10] +
-                                      SH_C3[2] * y * (4.0f * zz - xx - yy) * s.c[11] +
-                                      SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * s.c[12] +
-                                      SH_C3[4] * x * (4.0f * zz - xx - yy) * s.c[13] +
-                                      SH_C3[5] * z * (xx - yy) * s.c[14] + SH_C3[6] * x * (xx - 3.0f * yy) * s.c[15];
-                            }
-                        }
-                    }
-                    res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
-                    a.geom.clamped[idx] = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
-                    rgb = make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
+                    need_sh = true;  // evaluated below, after the geometry: a whole block then fetches its SH rows together
+                    p_sh = p_orig;
+                    rgb = make_float3(0.f, 0.f, 0.f);
                 }
                 radius = (int)my_radius;
                 rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
@@ -246,7 +278,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
                 float4* rec = a.geom.rec + 3 * (size_t)idx;
                 rec[0] = make_float4(pix, piy, p_view.z, a.opacities[idx]);
                 rec[1] = make_float4(conic.x, conic.y, conic.z, 0.0f);
-                rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
+                if (!need_sh) rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
             }
         }
     }
@@ -254,6 +286,53 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
     if (a.radii_out) a.radii_out[idx] = radius;
     a.geom.rect[idx] = rect;
     }  // idx < P
+
+    // computeColorFromSH (forward.cu:20-71) for the Gaussians that survived
+    if (a.shs && !a.colors_precomp) {  // uniform
+        __shared__ float sht[4 * SHT_ROWS * SHT_LD];
+        // whole block in range, 16 coefficients, 16-byte aligned rows: SH rows move through LDS (block-uniform)
+        const bool blk_fast = a.sh_vec_ok && a.M == 16 && (size_t)blockIdx.x * 256 + 256 <= (size_t)a.P &&
+                              __syncthreads_or(need_sh);
+        float shf[48];
+        if (blk_fast) sh_rows_to_lanes(a.shs, (size_t)blockIdx.x * 256, sht, shf);
+        if (need_sh) {
+            const float3 p_orig = p_sh;
+            SHCoeffs s;
+            if (blk_fast) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) s.c[k] = make_float3(shf[3 * k], shf[3 * k + 1], shf[3 * k + 2]);
+            } else {
+                load_sh(a.shs, idx, a.D, a.M, a.sh_vec_ok, s);
+            }
+            float3 rgb;
+            const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
+            float3 dir = p_orig - cam;
+            const float len = sqrtf(dot3(dir, dir));
+            dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
+            float3 res = SH_C0 * s.c[0];
+            if (a.D > 0) {
+                const float x = dir.x, y = dir.y, z = dir.z;
+                res = res - SH_C1 * y * s.c[1] + SH_C1 * z * s.c[2] - SH_C1 * x * s.c[3];
+                if (a.D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                    res = res + SH_C2[0] * xy * s.c[4] + SH_C2[1] * yz * s.c[5] +
+                          SH_C2[2] * (2.0f * zz - xx - yy) * s.c[6] + SH_C2[3] * xz * s.c[7] +
+                          SH_C2[4] * (xx - yy) * s.c[8];
+                    if (a.D > 2) {
+                        res = res + SH_C3[0] * y * (3.0f * xx - yy) * s.c[9] + SH_C3[1] * xy * z * s.c[10] +
+                              SH_C3[2] * y * (4.0f * zz - xx - yy) * s.c[11] +
+                              SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * s.c[12] +
+                              SH_C3[4] * x * (4.0f * zz - xx - yy) * s.c[13] +
+                              SH_C3[5] * z * (xx - yy) * s.c[14] + SH_C3[6] * x * (xx - 3.0f * yy) * s.c[15];
+                    }
+                }
+            }
+            res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+            a.geom.clamped[idx] = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
+            rgb = make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
+            a.geom.rec[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
+        }
+    }
 
     // instances (tiles_touched) of this block, for count_rank's offsets (the reference scans tiles_touched over P,
     // L/cuda_rasterizer/rasterizer_impl.cu:283)
@@ -285,7 +364,10 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
 // ------------------------------------------------------------------------------------------------
 // Fused per-Gaussian backward.  Order of the dL_dmean3D accumulation follows the reference's kernel
 // order: blend-kernel median term, computeCov2DCUDA, preprocessCUDA (2D mean, depth, SH).
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+#ifndef DGR_PRE_BWD_WAVES
+#define DGR_PRE_BWD_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, DGR_PRE_BWD_WAVES) preprocess_bwd_kernel(PreprocessBwdArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     float pose[12];
 #pragma unroll
@@ -422,9 +504,22 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
         // ---------------- SH backward (L/cuda_rasterizer/backward.cu:20-139); writes the dense dL_dsh row
         if (a.dL_dsh && ncoef_out > 0) {
             float3* out = reinterpret_cast<float3*>(a.dL_dsh) + (size_t)idx * ncoef_out;
+            // whole block in range, 16 coefficients, 16-byte aligned rows: SH rows move through LDS (block-uniform)
+            __shared__ float sht[4 * SHT_ROWS * SHT_LD];
+            const bool blk_fast = a.sh_vec_ok && ncoef_out == 16 && a.shs != nullptr && (size_t)blockIdx.x * 256 + 256 <= (size_t)a.P;
+            float shf[48];
+            if (blk_fast) sh_rows_to_lanes(a.shs, (size_t)blockIdx.x * 256, sht, shf);
+            float outf[48];
+#pragma unroll
+            for (int k = 0; k < 48; k++) outf[k] = 0.0f;
             if (do_map && a.shs) {
                 SHCoeffs s;
-                load_sh(a.shs, idx, a.D, a.M, a.sh_vec_ok, s);
+                if (blk_fast) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) s.c[k] = make_float3(shf[3 * k], shf[3 * k + 1], shf[3 * k + 2]);
+                } else {
+                    load_sh(a.shs, idx, a.D, a.M, a.sh_vec_ok, s);
+                }
                 const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
                 const float3 dir_orig = m - cam;
                 const float len = sqrtf(dot3(dir_orig, dir_orig));
@@ -500,7 +595,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
                     dmean.y += (-vv.x * vv.y * dv.x + (sum2 - vv.y * vv.y) * dv.y - vv.z * vv.y * dv.z) * invsum32;
                     dmean.z += (-vv.x * vv.z * dv.x - vv.y * vv.z * dv.y + (sum2 - vv.z * vv.z) * dv.z) * invsum32;
                 }
-                if (a.sh_vec_ok && ncoef_out == 16) {
+                if (blk_fast) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) { outf[3 * k] = g[k].x; outf[3 * k + 1] = g[k].y; outf[3 * k + 2] = g[k].z; }
+                } else if (a.sh_vec_ok && ncoef_out == 16) {
                     float f[48];
 #pragma unroll
                     for (int k = 0; k < 16; k++) { f[3 * k] = g[k].x; f[3 * k + 1] = g[k].y; f[3 * k + 2] = g[k].z; }
@@ -512,7 +610,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
                     for (int k = 0; k < 16; k++)
                         if (k < ncoef_out) out[k] = g[k];
                 }
-            } else {
+            } else if (!blk_fast) {
                 if (a.sh_vec_ok && ncoef_out == 16) {
                     float4* o4 = reinterpret_cast<float4*>(out);
 #pragma unroll
@@ -521,6 +619,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessBwdArgs a
                     for (int k = 0; k < ncoef_out; k++) out[k] = make_float3(0, 0, 0);
                 }
             }
+            if (blk_fast) lanes_to_sh_rows(outf, a.dL_dsh, (size_t)blockIdx.x * 256, sht);
         }
 
         // ---------------- computeCov3D backward (L/cuda_rasterizer/backward.cu:280-343)
