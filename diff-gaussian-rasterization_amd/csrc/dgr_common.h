@@ -115,7 +115,7 @@ __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
 #define DGR_ACC_STRIDE 16
 struct BackwardScratch {
     float* acc;         // [P * 16]
-    float* pose_part;   // [blocks * 12] per-block partial sums of the pose gradient
+    double* pose_part;  // [blocks * 12] per-block partial sums of the pose gradient
     size_t bytes;
 };
 __host__ __device__ inline BackwardScratch carve_backward_scratch(char* base, int P) {
@@ -123,7 +123,7 @@ __host__ __device__ inline BackwardScratch carve_backward_scratch(char* base, in
     size_t o = 0;
     s.acc = (float*)(base + o);       o = align_up(o + sizeof(float) * DGR_ACC_STRIDE * (size_t)P, 256);
     const size_t blocks = ((size_t)P + 255) / 256;
-    s.pose_part = (float*)(base + o); o = align_up(o + sizeof(float) * 12 * blocks, 256);
+    s.pose_part = (double*)(base + o); o = align_up(o + sizeof(double) * 12 * blocks, 256);
     s.bytes = o;
     return s;
 }

@@ -82,7 +82,7 @@ struct PreprocessBwdArgs {
     float* dL_dsh;      // [P,M,3] optional (M == 0)
     float* dL_dscale;   // [P,3]
     float* dL_drot;     // [P,4]
-    float* pose_part;   // [blocks,12]
+    double* pose_part;  // [blocks,12]
 };
 
 struct RenderFwdLightArgs {

@@ -708,12 +708,13 @@ __global__ void __launch_bounds__(256, DGR_PRE_BWD_WAVES) preprocess_bwd_kernel(
     }
 
     if (!a.track_off) {
-        // block reduction of the 12 pose terms: wave64 butterfly, then the 4 waves through LDS
-        __shared__ float red[4][12];
+        // block reduction of the 12 pose terms: wave64 butterfly, then the 4 waves through LDS.  In double: the sum
+        // over 4e5 Gaussians cancels to ~1e-3 of its terms, so float partial sums would cost ~2e-5 of the result.
+        __shared__ double red[4][12];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
         for (int i = 0; i < 12; i++) {
-            float v = pose[i];
+            double v = (double)pose[i];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
             if (lane == 0) red[wv][i] = v;
@@ -728,7 +729,7 @@ __global__ void __launch_bounds__(256, DGR_PRE_BWD_WAVES) preprocess_bwd_kernel(
 // Final pose reduction: fixed-order double sum of the per-block partials -> dL_dview[16].
 // 1024 threads = 64 row groups x 16 slots (12 used): each thread sums every 64th partial row, then 16 threads fold
 // the 64 groups.  (A single 256-thread block walking all rows took 30 us at P = 500k.)
-__global__ void __launch_bounds__(1024) pose_reduce_kernel(const float* __restrict__ part, int nblocks, float* dL_dview,
+__global__ void __launch_bounds__(1024) pose_reduce_kernel(const double* __restrict__ part, int nblocks, float* dL_dview,
                                                            int track_off) {
     __shared__ double sm[64][16];
     const int s = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -736,10 +737,10 @@ __global__ void __launch_bounds__(1024) pose_reduce_kernel(const float* __restri
     if (!track_off && s < 12) {
         int b = grp;
         for (; b + 64 < nblocks; b += 128) {  // two independent chains keep two loads in flight
-            v0 += (double)part[(size_t)b * 12 + s];
-            v1 += (double)part[(size_t)(b + 64) * 12 + s];
+            v0 += part[(size_t)b * 12 + s];
+            v1 += part[(size_t)(b + 64) * 12 + s];
         }
-        if (b < nblocks) v0 += (double)part[(size_t)b * 12 + s];
+        if (b < nblocks) v0 += part[(size_t)b * 12 + s];
     }
     sm[grp][s] = v0 + v1;
     __syncthreads();

@@ -95,8 +95,12 @@ def ptr(t):
     return t.data_ptr()
 
 
-def stream_handle():
-    return torch.cuda.current_stream().cuda_stream
+def stream_handle(device_index=None):
+    """Raw handle of the current HIP stream (the private torch binding is ~20x cheaper than building a Stream object)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if device_index is None else device_index)
+    except AttributeError:  # pragma: no cover -- other torch builds
+        return torch.cuda.current_stream().cuda_stream
 
 
 def profile_select(stage=""):

@@ -28,6 +28,8 @@ def cpu_deep_copy_tuple(input_tuple):
 
 def _f32c(t, dev):
     """contiguous fp32 tensor on `dev` (L/rasterize_points.cu:101-125 calls .contiguous() on every input)."""
+    if t.dtype is torch.float32 and t.is_contiguous() and t.device == dev:
+        return t  # the common case, checked first
     if t.device != dev:
         t = t.to(dev)
     if t.dtype != torch.float32:

@@ -19,6 +19,7 @@ CASES = [  # P, W, H, deg, seed
     (10000, 256, 256, 0, 0),   # BASELINE config 1
     (10000, 256, 256, 3, 0),
     (100000, 640, 480, 3, 0),  # BASELINE config 2 shape (light variant)
+    (500000, 1920, 1080, 3, 0),  # BASELINE config 3 at full size (the oracle needs ~1 s per pass on the GPU box's host)
 ]
 
 
@@ -62,7 +63,10 @@ def test_forward_images(oracle, case):
     assert np.all(d["depth_var"] == 0)
     nc = hh.hip_state("n_contrib", s, d)
     assert np.mean(nc != st.get("n_contrib")) <= 1e-4
-    assert_grad_close(d["gau_uncertainty"], ref["gau_uncertainty"], "gau_uncertainty", rel_to_max=1e-3)
+    # A pixel whose median Gaussian changes (T crossing 0.5 within rounding: a hard threshold, like the alpha and T cuts)
+    # moves one whole term from one Gaussian to another, so this is an outlier-fraction bar like the images'.
+    gu, gur = d["gau_uncertainty"].astype(np.float64), ref["gau_uncertainty"].astype(np.float64)
+    assert np.mean(np.abs(gu - gur) > 1e-5 * (1.0 + np.abs(gur))) <= 1e-4
     assert np.mean(d["gau_related_pixels"] != ref["gau_related_pixels"]) <= 1e-3
 
 
@@ -125,17 +129,22 @@ def test_backward_gradients(oracle, case, mode):
             if map_off:
                 assert not g[k].any(), k  # tracking mode: no Gaussian gradients (L/cr/backward.cu:593,609,654,666)
             elif tight:
-                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-4)
+                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-4,
+                                  outlier_rows=P // 50000)  # threshold flips of single pairs: see tests/util.py
             else:
-                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=3e-3, elem_rtol=2e-2, elem_frac=2e-2)
+                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=3e-3, elem_rtol=2e-2, elem_frac=2e-2,
+                                  outlier_rows=P // 50000)
         assert g["dL_dview"].shape == (4, 4)
         if track_off:
             assert not g["dL_dview"].any()
         else:
             assert not g["dL_dview"].reshape(-1)[[3, 7, 11, 15]].any()
             if tight:
-                assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=1e-5, elem_rtol=1e-3,
-                                  elem_frac=0.0)
+                # (a flipped pair -- see outlier_rows above -- also moves the pose gradient, by its Gaussian's share)
+                assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]",
+                                  rel_to_max=1e-5 if P < 200000 else 5e-5, elem_rtol=1e-3,
+                                  elem_frac=0.0 if P < 200000 else 0.1)
             else:
                 assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=3e-3, elem_rtol=2e-2,
                                   elem_frac=0.1)
+

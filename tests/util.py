@@ -23,17 +23,22 @@ def assert_image_close(a, ref, name, tol=1e-5, max_outliers=1e-4):
     assert frac <= max_outliers, f"{name}: {frac:.2e} of values off by > {tol} (max |d| = {np.abs(a - ref).max():.3e})"
 
 
-def assert_grad_close(a, ref, name, rel_to_max=2e-4, elem_rtol=2e-3, elem_frac=2e-3):
+def assert_grad_close(a, ref, name, rel_to_max=2e-4, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=0):
     """Gradients are sums over many pixels of float atomics (order-nondeterministic in the reference too)
     and inherit the forward's threshold flips: bound the worst element relative to the tensor's scale,
-    and the fraction of elements that miss a per-element relative tolerance."""
+    and the fraction of elements that miss a per-element relative tolerance.
+    `outlier_rows`: rows (Gaussians) allowed to miss the worst-element bound.  One (pixel, Gaussian) pair whose alpha sits
+    within rounding of 15/255 is blended by one implementation and skipped by the other -- a whole term of that
+    Gaussian's sums; among the 4e8 pair evaluations of a 1080p frame that happens to a handful of Gaussians."""
     a = np.asarray(a, np.float64)
     ref = np.asarray(ref, np.float64)
     scale = np.abs(ref).max()
     if scale == 0:
         assert np.abs(a).max() == 0, f"{name}: reference is all zero, got max {np.abs(a).max():.3e}"
         return
-    err = np.abs(a - ref).max() / scale
-    assert err <= rel_to_max, f"{name}: max |d| / max |ref| = {err:.3e} > {rel_to_max}"
+    row_err = np.abs(a - ref).reshape(a.shape[0], -1).max(1) / scale if a.ndim > 1 else np.abs(a - ref) / scale
+    n_out = int((row_err > rel_to_max).sum())
+    assert n_out <= outlier_rows, (f"{name}: {n_out} rows with max |d| / max |ref| > {rel_to_max} "
+                                   f"(worst {row_err.max():.3e}, allowed rows {outlier_rows})")
     frac = float(np.mean(np.abs(a - ref) > (1e-7 * scale + elem_rtol * np.abs(ref))))
     assert frac <= elem_frac, f"{name}: {frac:.2e} of elements off by > {elem_rtol} relative"
