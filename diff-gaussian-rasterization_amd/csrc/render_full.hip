@@ -176,11 +176,12 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
         dL_dunc = a.dL_duncertainties[pix_id];
         gt_px = a.gt_depth[pix_id];
     }
-    const float bg_dot_dpixel = a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2;
+    const float bg_term = -T_final * (a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2);  // times 1/(1 - alpha): background term of dL/dalpha
+    const float dunc2 = 2.f * dL_dunc;
     // Linear recurrences instead of the reference's five accum_rec_* (see render_light.hip): the full variant needs
     // the colour part and the depth part of dL/dalpha separately (pose terms), hence three scalars:
     //   Xc = <rgb_j, dL/dpixel>, Xd = depth_j, Xu = (depth_j - gt)^2 ; S* <- alpha_last X*_last + (1 - alpha_last) S*
-    float Sc = 0.f, Sd = 0.f, Su = 0.f, Xc_last = 0.f, Xd_last = 0.f, Xu_last = 0.f, last_alpha = 0.f;
+    float Sc = 0.f, Sd = 0.f, Su = 0.f, Xc_last = 0.f, Xd_last = 0.f, Xu_last = 0.f, last_alpha = 0.f, last_om = 1.f;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     const int c16 = wave_reduce16_comp(lane);
     const int my_comp = ((lane & 3) == 0 && c16 < NACC_FULL) ? c16 : -1;
@@ -207,8 +208,8 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
-                const float G = __builtin_amdgcn_exp2f(p2);
-                const float alpha = fminf(0.99f, q1[u].y * G);
+                const float oG = q1[u].y * __builtin_amdgcn_exp2f(p2);  // o G: alpha before the 0.99 clamp
+                const float alpha = fminf(0.99f, oG);
                 const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
 
                 // per-lane scalars (0 on lanes the Gaussian does not reach): w = alpha T, qq = o G dL/dalpha,
@@ -216,21 +217,22 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
                 float w = 0.f, qq = 0.f, qc = 0.f, e = 0.f, fw = 0.f, fq = 0.f;
                 const float4 cd = s.rgbd[j];
                 if (valid) {
-                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                    const float om_now = 1.f - alpha;
+                    const float inv = __builtin_amdgcn_rcpf(om_now);
                     T = T * inv;
                     w = alpha * T;  // dchannel_dcolor
                     e = cd.w - gt_px;
                     const float Xc = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2, Xd = cd.w, Xu = e * e;
-                    const float om = 1.f - last_alpha;
+                    const float om = last_om;
                     Sc = last_alpha * Xc_last + om * Sc; Xc_last = Xc;
                     Sd = last_alpha * Xd_last + om * Sd; Xd_last = Xd;
                     Su = last_alpha * Xu_last + om * Su; Xu_last = Xu;
+                    last_om = om_now;
                     const float dcol = Xc - Sc;
                     float dL_dalpha = dcol + (Xd - Sd) * dL_depth + (Xu - Su) * dL_dunc;
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
-                    const float oG = q1[u].y * G;
+                    dL_dalpha += bg_term * inv;
                     qq = oG * dL_dalpha;
                     qc = oG * (T * dcol);  // sum_ch dL_dpixel[ch] * dpixel_dalpha[ch] = T * dcol (backward.cu:693)
                     if (j == rel_first) {  // the pair ComputePG matches last: its dd_dvK survive (backward.cu:1278-1289)
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
                 g[0] = w * dpix0;
                 g[1] = w * dpix1;
                 g[2] = w * dpix2;
-                g[3] = w * dL_depth + 2.f * e * w * dL_dunc;  // backward.cu:708
+                g[3] = w * dL_depth + (dunc2 * w) * e;  // backward.cu:708
                 g[4] = qdx;
                 g[5] = qdy;
                 g[6] = qdx * dx;

@@ -231,12 +231,15 @@ __global__ void __launch_bounds__(256, DGR_BWD_WAVES) render_bwd_light_kernel(Re
         dpix_var = a.dL_dpix_var[pix_id];
         gt_px = a.gt_depth[pix_id];
     }
-    const float bg_dot_dpixel = a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2;
+    // per-pixel constants of the loop: -T_final <bg, dL/dpixel> (the background term of dL/dalpha is this times
+    // 1/(1 - alpha)) and 2 dL/dvar
+    const float bg_term = -T_final * (a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2);
+    const float dvar2 = 2.f * dpix_var;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     // The reference keeps five "accumulated behind me" recurrences (3 colours, depth, variance: backward.cu:580-608)
     // only to form dL/dalpha = sum_c (c_j - accum_rec_c) dL/dpixel_c.  They are linear, so one scalar suffices:
     //   X_j = <features_j, dL/dpixel>,   S <- alpha_last X_last + (1 - alpha_last) S,   dL/dalpha = X_j - S.
-    float S = 0.f, X_last = 0.f, last_alpha = 0.f;
+    float S = 0.f, X_last = 0.f, last_alpha = 0.f, last_om = 1.f;  // last_om = 1 - last_alpha
     bool mid_once = true;
     const float v2 = a.view[2], v3 = a.view[3], v6 = a.view[6], v7 = a.view[7], v10 = a.view[10], v11 = a.view[11],
                 v14 = a.view[14];
@@ -273,8 +276,8 @@ __global__ void __launch_bounds__(256, DGR_BWD_WAVES) render_bwd_light_kernel(Re
                 const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
-                const float G = __builtin_amdgcn_exp2f(p2);
-                const float alpha = fminf(0.99f, q1[u].y * G);
+                const float oG = q1[u].y * __builtin_amdgcn_exp2f(p2);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
+                const float alpha = fminf(0.99f, oG);
                 const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
 
                 // per-lane scalars of this pair; they stay 0 on lanes the Gaussian does not reach, so the products
@@ -282,17 +285,18 @@ __global__ void __launch_bounds__(256, DGR_BWD_WAVES) render_bwd_light_kernel(Re
                 float w = 0.f, qq = 0.f, e = 0.f;
                 const float4 cd = s.rgbd[j];
                 if (valid) {
-                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                    const float om = 1.f - alpha;
+                    const float inv = __builtin_amdgcn_rcpf(om);
                     T = T * inv;
                     w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
                     e = cd.w - gt_px;
                     const float X = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2 + cd.w * dpix_depth + (e * e) * dpix_var;
-                    S = last_alpha * X_last + (1.f - last_alpha) * S;
+                    S = last_alpha * X_last + last_om * S;
                     X_last = X;
-                    float dL_dalpha = (X - S) * T;
                     last_alpha = alpha;
-                    dL_dalpha += (-T_final * inv) * bg_dot_dpixel;
-                    qq = q1[u].y * dL_dalpha * G;
+                    last_om = om;
+                    const float dL_dalpha = (X - S) * T + bg_term * inv;
+                    qq = oG * dL_dalpha;
                     if (DO_MAP && T > 0.5f && mid_once) {  // backward.cu:654-664: once per pixel, straight to LDS
                         const float* mg = a.means3D + 3 * (size_t)s.id[j];
                         const float mul3 = v2 * mg[0] + v6 * mg[1] + v10 * mg[2] + v14;
@@ -312,7 +316,7 @@ __global__ void __launch_bounds__(256, DGR_BWD_WAVES) render_bwd_light_kernel(Re
                     g[0] = w * dpix0;
                     g[1] = w * dpix1;
                     g[2] = w * dpix2;
-                    g[3] = wd + dpix_var * w * 2.f * e;
+                    g[3] = wd + (dvar2 * w) * e;
                     g[4] = qdx;        // sum q dx
                     g[5] = qdy;        // sum q dy
                     g[6] = qdx * dx;   // sum q dx^2
