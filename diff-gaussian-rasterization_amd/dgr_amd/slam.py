@@ -1,0 +1,122 @@
+"""The caller's side of the rasterizer: CG-SLAM's `render()` and the camera tensors a tracking or
+mapping step feeds it.
+
+The reference repository documents this call but does not contain it (README.md:33-47, 71-96: `render(viewpoint_cam,
+gaussians, pipe, background, viewmatrix=w2cT, fov=(tanfovx, tanfovy), HW=(H, W), gt_depth=..., track_off=...,
+map_off=...)` returning a dict); it lives in CG-SLAM and follows the 3DGS `gaussian_renderer.render`.  This module
+restates it over `dgr_amd.light` / `dgr_amd.full`, duck-typed on the 3DGS `GaussianModel` accessors, and adds the
+differentiable pose -> matrices helpers, so that a whole tracking iteration (pose parameters -> viewmatrix -> render ->
+loss -> backward -> pose update) can run without leaving the GPU.
+
+Matrix convention (cuda_rasterizer/auxiliary.h:58-77 reads 16 floats column-major): the rasterizer takes W2C^T,
+(Proj W2C)^T and Proj^T.  The analytic pose gradient is returned w.r.t. the `viewmatrix` tensor only; `projmatrix` and
+`campos` are recomputed from the same pose but enter as constants, exactly as in the reference (its backward adds their
+dependence inside the kernels: L/cuda_rasterizer/backward.cu:633-651, 683-751).
+"""
+import torch
+
+from . import full as _full
+from . import light as _light
+
+
+def projection_matrix(tanfovx, tanfovy, znear=0.01, zfar=100.0, device=None, dtype=torch.float32):
+    """Proj (row-major math, z forward, as 3DGS `getProjectionMatrix` with symmetric frustum)."""
+    P = torch.zeros((4, 4), dtype=dtype, device=device)
+    P[0, 0] = 1.0 / tanfovx
+    P[1, 1] = 1.0 / tanfovy
+    P[2, 2] = zfar / (zfar - znear)
+    P[2, 3] = -(zfar * znear) / (zfar - znear)
+    P[3, 2] = 1.0
+    return P
+
+
+def quat_to_rotmat(q):
+    """Unit quaternion (r, x, y, z) -> 3x3 rotation, differentiable (q is normalised here)."""
+    q = q / q.norm()
+    r, x, y, z = q[0], q[1], q[2], q[3]
+    return torch.stack([
+        torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)]),
+        torch.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)]),
+        torch.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]),
+    ])
+
+
+def w2c_from_quat_trans(q, t):
+    """World-to-camera 4x4 from a quaternion and a translation (both differentiable leaves of a tracking step)."""
+    top = torch.cat([quat_to_rotmat(q), t.reshape(3, 1)], dim=1)
+    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=top.dtype, device=top.device)
+    return torch.cat([top, bottom], dim=0)
+
+
+def camera_tensors(w2c, tanfovx, tanfovy, znear=0.01, zfar=100.0):
+    """(viewmatrix, projmatrix, perspec_matrix, campos) for the rasterizer from a world-to-camera matrix.
+    `viewmatrix` stays attached to `w2c`'s graph; the other three are detached (see the module docstring)."""
+    P = projection_matrix(tanfovx, tanfovy, znear, zfar, device=w2c.device, dtype=w2c.dtype)
+    viewmatrix = w2c.transpose(0, 1).contiguous()
+    with torch.no_grad():
+        perspec = P.transpose(0, 1).contiguous()
+        projmatrix = (w2c.transpose(0, 1) @ P.transpose(0, 1)).contiguous()
+        campos = (-(w2c[:3, :3].transpose(0, 1) @ w2c[:3, 3])).contiguous()
+    return viewmatrix, projmatrix, perspec, campos
+
+
+def _get(obj, name, default=None):
+    v = getattr(obj, name, default)
+    return v() if callable(v) and not isinstance(v, torch.Tensor) else v
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, viewmatrix=None, fov=None,
+           HW=None, gt_depth=None, track_off=False, map_off=False, variant="light"):
+    """CG-SLAM's `render()` (reference README.md:33,71).
+
+    `pc`: anything with the 3DGS GaussianModel accessors `get_xyz`, `get_opacity`, `get_scaling`, `get_rotation`,
+    `get_features` ([P, M, 3]) and `active_sh_degree`.  `viewmatrix` is W2C^T (differentiable for tracking); `fov` the
+    two half-angle tangents; `HW` = (H, W).  `viewpoint_camera` may carry `projection_matrix` (Proj^T), `znear`, `zfar`;
+    without it a symmetric frustum with znear 0.01 / zfar 100 is used.  `pipe.debug` is honoured.
+    Returns the reference's dict (light: render, depth, depth_median, opacity_map, depth_var, gau_uncertainty,
+    num_related_pixels; full: render, depth, opacity_map) plus the 3DGS bookkeeping entries viewspace_points,
+    visibility_filter, radii."""
+    if viewmatrix is None or fov is None or HW is None:
+        raise ValueError("render() needs viewmatrix=W2C^T, fov=(tanfovx, tanfovy) and HW=(H, W)")
+    mod = _light if variant == "light" else _full
+    H, W = int(HW[0]), int(HW[1])
+    tanfovx, tanfovy = float(fov[0]), float(fov[1])
+    dev = viewmatrix.device
+    znear = float(_get(viewpoint_camera, "znear", 0.01)) if viewpoint_camera is not None else 0.01
+    zfar = float(_get(viewpoint_camera, "zfar", 100.0)) if viewpoint_camera is not None else 100.0
+    with torch.no_grad():
+        perspec = _get(viewpoint_camera, "projection_matrix") if viewpoint_camera is not None else None
+        if perspec is None:
+            perspec = projection_matrix(tanfovx, tanfovy, znear, zfar, device=dev).transpose(0, 1).contiguous()
+        perspec = perspec.to(dev, torch.float32)
+        vm = viewmatrix.detach()
+        projmatrix = (vm @ perspec).contiguous()
+        w2c = vm.transpose(0, 1)
+        campos = (-(w2c[:3, :3].transpose(0, 1) @ w2c[:3, 3])).contiguous()
+
+    means3D = pc.get_xyz
+    # 3DGS keeps a zero tensor whose .grad receives the screen-space gradient (densification statistics)
+    screenspace_points = torch.zeros_like(means3D, requires_grad=True)
+    debug = bool(getattr(pipe, "debug", False)) if pipe is not None else False
+    common = dict(image_height=H, image_width=W, tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color,
+                  scale_modifier=scaling_modifier, viewmatrix=vm, projmatrix=projmatrix,
+                  sh_degree=int(pc.active_sh_degree), campos=campos, prefiltered=False)
+    if variant == "light":
+        settings = mod.GaussianRasterizationSettings(**common, debug=debug, perspec_matrix=perspec, track_off=track_off,
+                                                     map_off=map_off)
+    else:
+        settings = mod.GaussianRasterizationSettings(**common, perspec_matrix=perspec)
+    rasterizer = mod.GaussianRasterizer(raster_settings=settings)
+    shs, colors = (None, override_color) if override_color is not None else (pc.get_features, None)
+    out = rasterizer(means3D=means3D, means2D=screenspace_points, opacities=pc.get_opacity, shs=shs,
+                     colors_precomp=colors, scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None,
+                     viewmatrix=viewmatrix, gt_depth=gt_depth)
+    if variant == "light":
+        color, radii, depth, depth_median, depth_var, opacity_map, gau_uncertainty, gau_related_pixels = out
+        res = {"render": color, "depth": depth, "depth_median": depth_median, "opacity_map": opacity_map,
+               "depth_var": depth_var, "gau_uncertainty": gau_uncertainty, "num_related_pixels": gau_related_pixels}
+    else:
+        color, radii, depth, uncertainty = out
+        res = {"render": color, "depth": depth, "opacity_map": uncertainty}
+    res.update(viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii)
+    return res

@@ -1,0 +1,87 @@
+"""dgr_amd.slam: CG-SLAM's `render()` call (reference README.md:33,71) and the pose helpers.
+
+CPU: the camera tensors equal synth-v1's matrices.  GPU: a tracking step works end to end -- starting from a perturbed
+camera pose, gradient descent on (quaternion, translation) through the rasterizer's analytic viewmatrix gradient recovers
+the true pose.  This checks the pose gradient functionally, with no oracle involved."""
+import numpy as np
+import pytest
+import torch
+
+from dgr_amd import slam
+from dgr_amd.synth import camera, make_scene
+
+
+def rot_to_quat(R):
+    # (r, x, y, z) of a rotation matrix close to identity (trace > 0)
+    r = np.sqrt(1.0 + np.trace(R)) / 2.0
+    return np.array([r, (R[2, 1] - R[1, 2]) / (4 * r), (R[0, 2] - R[2, 0]) / (4 * r), (R[1, 0] - R[0, 1]) / (4 * r)])
+
+
+def test_camera_tensors_match_synth_v1():
+    W, H = 640, 480
+    tanfovx, tanfovy, Rm, t, view, proj, persp, campos = camera(W, H, 0.05)
+    q = torch.tensor(rot_to_quat(Rm), dtype=torch.float64)
+    w2c = slam.w2c_from_quat_trans(q, torch.tensor(t, dtype=torch.float64))
+    v, p, ps, c = slam.camera_tensors(w2c, tanfovx, tanfovy)
+    np.testing.assert_allclose(v.numpy(), view, atol=2e-7)
+    np.testing.assert_allclose(p.numpy(), proj, atol=2e-6)
+    np.testing.assert_allclose(ps.numpy(), persp, atol=2e-7)
+    np.testing.assert_allclose(c.numpy(), campos, atol=2e-7)
+
+
+class Model:
+    """The accessors of 3DGS's GaussianModel that render() uses."""
+
+    def __init__(self, s, dev):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.get_xyz, self.get_opacity, self.get_scaling = t(s.means), t(s.opac), t(s.scales)
+        self.get_rotation, self.get_features = t(s.rots), t(s.shs)
+        self.active_sh_degree = 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["light", "full"])
+def test_tracking_recovers_a_perturbed_pose(variant):
+    dev = torch.device("cuda:0")
+    W, H = 256, 192
+    s = make_scene(20000, W, H, 3)
+    pc = Model(s, dev)
+    tanfovx, tanfovy, Rm, t_true, *_ = camera(W, H, 0.05)
+    bg = torch.from_numpy(s.bg).to(dev)
+    gt_depth = torch.from_numpy(s.gt).to(dev)
+    kw = dict(fov=(tanfovx, tanfovy), HW=(H, W), gt_depth=gt_depth, variant=variant)
+    if variant == "light":
+        kw.update(track_off=False, map_off=True)  # tracking: pose gradient only (README.md:71)
+
+    def pose(q, t):
+        return slam.camera_tensors(slam.w2c_from_quat_trans(q, t), tanfovx, tanfovy)[0]
+
+    q_true = torch.tensor(rot_to_quat(Rm), dtype=torch.float32, device=dev)
+    t_true = torch.tensor(t_true, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        target = slam.render(None, pc, None, bg, viewmatrix=pose(q_true, t_true), **kw)
+    assert set(target) >= {"render", "depth", "opacity_map", "viewspace_points", "visibility_filter", "radii"}
+    if variant == "light":
+        assert set(target) >= {"depth_median", "depth_var", "gau_uncertainty", "num_related_pixels"}
+    tgt_c, tgt_d = target["render"].detach(), target["depth"].detach()
+
+    q = (q_true + torch.tensor([0.0, 0.004, -0.006, 0.003], device=dev)).requires_grad_()
+    t = (t_true + torch.tensor([0.012, -0.009, 0.015], device=dev)).requires_grad_()
+    opt = torch.optim.Adam([{"params": [q], "lr": 5e-4}, {"params": [t], "lr": 1.5e-3}])
+
+    def errors():
+        with torch.no_grad():
+            return float((q / q.norm() - q_true).norm()), float((t - t_true).norm())
+
+    e0 = errors()
+    losses = []
+    for it in range(150):
+        opt.zero_grad()
+        out = slam.render(None, pc, None, bg, viewmatrix=pose(q, t), **kw)
+        loss = (out["render"] - tgt_c).abs().mean() + 0.5 * (out["depth"] - tgt_d).abs().mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    e1 = errors()
+    assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
+    assert e1[0] < 0.3 * e0[0] and e1[1] < 0.3 * e0[1], (e0, e1)
