@@ -77,6 +77,9 @@ def main():
                     help="independent views (forward+backward each) issued round-robin on this many HIP streams: the "
                          "atomic- and latency-bound binning kernels of one view run under the VALU-bound blend kernels "
                          "of another; 1 = strictly one view at a time")
+    ap.add_argument("--tight-cull", action="store_true",
+                    help="opt-in alpha-aware tile rectangles (same images and gradients, NOT the reference's integer "
+                         "path: num_rendered and the tile lists shrink); off for the headline number")
     ap.add_argument("--allreduce", default="blocking", choices=["overlap", "blocking"],
                     help="N>1: blocking = the view's stream waits for its gradient all-reduce (with several views in "
                          "flight the other streams keep rendering under it); overlap = additionally defer the wait to "
@@ -114,6 +117,8 @@ def main():
         from dgr_amd import light as V
     GaussianRasterizer = V.GaussianRasterizer
 
+    if args.tight_cull:
+        _capi.set_option("tight_cull", 1)
     P, W, H, deg = WORKLOADS[args.workload]
     s = make_scene(P, W, H, seed=0, view_index=rank)  # rank r renders view r of the same Gaussians
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -258,7 +263,7 @@ def main():
             "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
                                    f"fwd+bwd incl. viewmatrix gradient, one view per step, {K} independent views in flight per GPU", "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
-                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms,
+                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "tight_cull": bool(args.tight_cull),
                        "gradient_allreduce": (None if world == 1 else
                                               f"{args.allreduce}: one fused RCCL sum of 248 B/Gaussian per view"),
                        "view_hbm_frac": 0.83e9 * (316 * P + 566 * V + 172 * R + 72 * N) / (316 * 5e5 + 566 * 425824 + 172 * 1654310 + 72 * 2073600)

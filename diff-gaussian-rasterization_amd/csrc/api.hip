@@ -15,6 +15,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <string>
 
 #include "../../include/dgr_hip.h"
@@ -53,6 +54,9 @@ StageProf g_prof[] = {{"preprocess_fwd"}, {"scan_blocks"}, {"count_rank"}, {"sca
 enum { ST_PRE_FWD, ST_SCAN_BLOCKS, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD, ST_ZERO, ST_RENDER_BWD, ST_PRE_BWD,
        ST_COUNT };
 std::mutex g_prof_mu;
+
+// dgr_set_option("tight_cull", 1): alpha-aware tile rectangles (preprocess.hip); process-wide, default off
+std::atomic<int> g_tight_cull{0};
 
 // A kernel stage hands its two events to the stage's first kernel launch (dgr::launch, kernels.h): they then hold
 // that kernel's start and end.  A stage without a kernel (the scratch memset) is bracketed with hipEventRecord.
@@ -124,6 +128,7 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
     a.focal_y = c.H / (2.0f * c.tan_fovy);  // rasterizer_impl.cu:228-229
     a.focal_x = c.W / (2.0f * c.tan_fovx);
     a.prefiltered = c.prefiltered;
+    a.tight_cull = g_tight_cull.load();
     a.sh_vec_ok = aligned16(c.shs);
     a.geom = geom; a.radii_out = c.radii;
     a.zero_words = img.tile_count; a.n_zero_words = (int)(((char*)img.ranges - (char*)img.tile_count) / 4);
@@ -503,6 +508,18 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
 int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4) {
     HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out4, comp16, comp4, (hipStream_t)stream));
     return DGR_OK;
+}
+
+int dgr_set_option(const char* name, int value) {
+    const std::string n(name ? name : "");
+    if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }
+    g_last_error = "unknown option: " + n;
+    return DGR_ERR_BAD_ARGUMENT;
+}
+int dgr_get_option(const char* name) {
+    const std::string n(name ? name : "");
+    if (n == "tight_cull") return g_tight_cull.load();
+    return DGR_ERR_BAD_ARGUMENT;
 }
 
 int dgr_profile_select(const char* stage) {

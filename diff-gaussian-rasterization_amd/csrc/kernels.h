@@ -43,6 +43,7 @@ struct PreprocessFwdArgs {
     const float* campos;
     float tan_fovx, tan_fovy, focal_x, focal_y;
     int prefiltered;
+    int tight_cull;        // dgr_set_option("tight_cull"): alpha-aware tile rectangles (changes the integer path)
     bool sh_vec_ok;
     GeometryView geom;
     int* radii_out;        // caller's radii tensor (may be NULL)

@@ -273,7 +273,29 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
                     rgb = make_float3(0.f, 0.f, 0.f);
                 }
                 radius = (int)my_radius;
-                rect = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+                int tx0 = x0, ty0 = y0, tx1 = x1, ty1 = y1;  // the rectangle that is binned (radii stay the reference's)
+                if (a.tight_cull) {
+                    // Optional (NOT the reference's integer path): shrink the tile rectangle to the box of
+                    // the region where alpha can reach 15/255, q(d) <= tau = 2 ln(255 o / 15): half extents sqrt(tau cov_xx),
+                    // sqrt(tau cov_yy) <= 2.38 sigma instead of the 3 sigma_max circle, with the same safety margin the
+                    // blend kernels' own culling uses.  Every dropped (tile, Gaussian) instance is one no pixel would blend,
+                    // so images and gradients are unchanged; num_rendered, the tile lists and n_contrib shrink.
+                    const float o = a.opacities[idx];
+                    const float tau = 2.0f * __logf(o * (255.0f / 15.0f));
+                    if (!(tau > 0.0f)) {
+                        tx1 = tx0;  // can never contribute
+                    } else {
+                        const float hx = sqrtf(tau * cx) * 1.001f + 0.05f, hy = sqrtf(tau * cz) * 1.001f + 0.05f;
+                        // tile t holds pixels 16 t .. 16 t + 15 (pixel centres at integer coordinates)
+                        tx0 = max(x0, (int)ceilf((pix - hx - 15.0f) / 16.0f));
+                        ty0 = max(y0, (int)ceilf((piy - hy - 15.0f) / 16.0f));
+                        tx1 = min(x1, (int)floorf((pix + hx) / 16.0f) + 1);
+                        ty1 = min(y1, (int)floorf((piy + hy) / 16.0f) + 1);
+                        if (tx1 < tx0) tx1 = tx0;
+                        if (ty1 < ty0) ty1 = ty0;
+                    }
+                }
+                rect = make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
                 a.geom.depths[idx] = p_view.z;
                 float4* rec = a.geom.rec + 3 * (size_t)idx;
                 rec[0] = make_float4(pix, piy, p_view.z, a.opacities[idx]);

@@ -27,6 +27,8 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # argument lists follow include/dgr_hip.h one to one
 _SIGS = {
     "dgr_last_error": (C.c_char_p, []),
+    "dgr_set_option": (_i, [C.c_char_p, _i]),
+    "dgr_get_option": (_i, [C.c_char_p]),
     "dgr_version": (C.c_char_p, []),
     "dgr_geometry_bytes": (_sz, [_i]),
     "dgr_image_bytes": (_sz, [_i, _i]),
@@ -101,6 +103,16 @@ def stream_handle(device_index=None):
         return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if device_index is None else device_index)
     except AttributeError:  # pragma: no cover -- other torch builds
         return torch.cuda.current_stream().cuda_stream
+
+
+def set_option(name, value):
+    """Process-wide library option (include/dgr_hip.h: dgr_set_option), e.g. set_option("tight_cull", 1)."""
+    if load().dgr_set_option(name.encode(), int(value)):
+        raise ValueError(last_error())
+
+
+def get_option(name):
+    return load().dgr_get_option(name.encode())
 
 
 def profile_select(stage=""):

@@ -116,6 +116,12 @@ def _check(rc):
     raise RuntimeError(f"dgr_hip: error {rc}: {msg}")
 
 
+def set_tight_culling(on=True):
+    """Opt in to alpha-aware tile rectangles (include/dgr_hip.h: dgr_set_option "tight_cull"): same images and gradients,
+    ~40 % fewer tile instances; `num_rendered` and the opaque state buffers are then not the reference's.  Process-wide."""
+    _capi.set_option("tight_cull", 1 if on else 0)
+
+
 class _C:
     """Functions with the signatures of the reference's pybind11 module `_C` (L/ext.cpp:15-19)."""
 

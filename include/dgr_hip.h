@@ -162,6 +162,14 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
                       int binning_capacity, const char* geom_buffer, const char* binning_buffer,
                       const char* image_buffer, void* dst_device);
 
+/* Process-wide options (default 0).
+ *  "tight_cull": 1 = alpha-aware tile rectangles.  The reference gives a Gaussian every tile its
+ *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle
+ *     is cut down to the box where alpha can reach 15/255.  Images and gradients are unchanged, but num_rendered, the
+ *     tile lists and n_contrib are NOT the reference's any more -- hence opt-in. */
+int dgr_set_option(const char* name, int value);
+int dgr_get_option(const char* name);
+
 /* Self-test of the wave64 multi-value butterfly reductions the backward blend relies on.  `in` holds 16
  * values per lane as in[c * 64 + lane]; out16[lane] / out4[lane] receive what each lane holds after the
  * 16-value / 4-value reduction, comp16[lane] / comp4[lane] the index of the value that lane's total belongs to. */

@@ -244,3 +244,28 @@ def test_views_in_flight_match_serial_views():
             assert np.array_equal(a, b)  # forward is deterministic
         for a, b in zip(g_s, g_p):
             assert_grad_close(b, a, "views in flight", rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-3)
+
+
+def test_tight_culling_changes_the_lists_but_not_the_results():
+    """dgr_set_option("tight_cull", 1): alpha-aware tile rectangles.  Every dropped instance is one no
+    pixel blends, so images are bit-identical and gradients equal up to atomic-order noise; radii (the caller's
+    visibility filter) are untouched; num_rendered shrinks."""
+    from dgr_amd import _capi
+    s = make_scene(20000, 320, 240, 9)
+    grads = tuple(g * (s.W * s.H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+    out0, d0 = hh.hip_forward(s, 3)
+    g0 = hh.hip_backward(s, 3, out0, grads=grads)
+    _capi.set_option("tight_cull", 1)
+    try:
+        assert _capi.get_option("tight_cull") == 1
+        out1, d1 = hh.hip_forward(s, 3)
+        g1 = hh.hip_backward(s, 3, out1, grads=grads)
+    finally:
+        _capi.set_option("tight_cull", 0)
+    assert d1["num_rendered"] < 0.8 * d0["num_rendered"]
+    assert np.array_equal(d0["radii"], d1["radii"])
+    for k in ("color", "depth", "depth_median", "opacity_map", "gau_related_pixels"):
+        assert np.array_equal(d0[k], d1[k]), k
+    assert_grad_close(d1["gau_uncertainty"], d0["gau_uncertainty"], "gau_uncertainty", rel_to_max=1e-6)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dview"):
+        assert_grad_close(g1[k], g0[k], k, rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
