@@ -354,7 +354,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    { ScopedStage t(ST_ZERO, st, false); HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
+    { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
 
     dgr::RenderBwdLightArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
@@ -481,7 +481,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    { ScopedStage t(ST_ZERO, st, false); HIP_TRY(hipMemsetAsync(sc.acc, 0, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
+    { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
 
     dgr::RenderBwdFullArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;

@@ -157,6 +157,9 @@ struct RenderBwdFullArgs {
 // ---- launchers (each enqueues on `stream` and returns the hipError_t of the launch) ----
 hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream);
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hipStream_t stream);
+// zero-fill of a 16-byte aligned buffer whose size is a multiple of 16 (a kernel rather than hipMemsetAsync: memset nodes of a
+// captured hipGraph were seen to re-execute with corrupted parameters on this ROCm)
+hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream);
 
 // binning: tile_count -> ranges (+ total in status[0], overflow in status[1]); emit keys; sort tiles

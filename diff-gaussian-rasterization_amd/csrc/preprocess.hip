@@ -13,6 +13,8 @@
 // arithmetic is written in the reference's association order with FMA contraction OFF: radii,
 // tile rects and depth bits -- the integer path -- then agree bit for bit with the CPU oracle.
 #include "dgr_common.h"
+#include <algorithm>
+
 #include "kernels.h"
 
 #pragma clang fp contract(off)
@@ -782,6 +784,19 @@ __global__ void __launch_bounds__(1024) pose_reduce_kernel(const double* __restr
 }  // namespace dgr
 
 namespace dgr {
+namespace {
+__global__ void __launch_bounds__(256) zero_fill_kernel(float4* dst, size_t n16) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace
+hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream) {
+    const size_t n16 = bytes / 16;
+    if (n16 == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<size_t>((n16 + 255) / 256, 256 * 16);
+    launch(zero_fill_kernel, dim3(blocks), dim3(256), stream, (float4*)dst, n16);
+    return hipGetLastError();
+}
 hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream) {
     if (a.P <= 0) return hipSuccess;
     launch(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), stream, a);

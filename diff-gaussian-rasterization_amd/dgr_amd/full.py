@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _capi
+from . import light as _light
 from .light import _capacity_cache, _check, _f32c, _grad_arena
 
 
@@ -76,6 +77,19 @@ class _C:
             status = torch.empty((4,), **i32)
             key = (dev.index, P, H, W)
             cap = _capacity_cache.get(key, 0)
+            if _light._sync_mode() == "lazy" and cap > 0:
+                # no host synchronisation (dgr_amd/light.py): the status word is checked one call late; the tuple's
+                # num_rendered / num_related members are the latest values read back for this shape
+                while len(_light._pending_status) > 1 and not torch.cuda.is_current_stream_capturing():
+                    _light._check_oldest()
+                cap = int(cap * 1.5) + 4096
+                binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)
+                _check(lib.dgr_full_forward_presized(st, p(geomBuffer), p(binningBuffer), cap, p(imgBuffer), p(status),
+                                                     *common))
+                _light._post_status(status, key)
+                related = _light._last_status.get(key, (0, 0, 0, 0))[3]
+                return (_capacity_cache[key], related, out_color, out_depth, out_unc, radii, geomBuffer, binningBuffer,
+                        imgBuffer)
             cap = int(cap * 1.25) + 4096 if cap else 4 * P + 4096
             while True:
                 binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)
@@ -86,6 +100,7 @@ class _C:
                     raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
                 rendered, related = s[0], s[3]
                 _capacity_cache[key] = max(_capacity_cache.get(key, 0), rendered)
+                _light._last_status[key] = s
                 if not s[1]:
                     break
                 cap = int(rendered * 1.1) + 4096

@@ -47,6 +47,7 @@ _capacity_cache = {}
 # `prefiltered` violation therefore raises one or two calls late.  Default ("strict"): one status read at the end of
 # every forward, like the reference's blocking copy of num_rendered (L/cuda_rasterizer/rasterizer_impl.cu:287).
 _pending_status = []   # [(pinned host int32[4], event, key)]
+_last_status = {}      # key -> the most recent status word read back for that shape
 _pinned_pool = []
 
 
@@ -54,7 +55,15 @@ def _sync_mode():
     return os.environ.get("DGR_SYNC_MODE", "strict")
 
 
+# Status words of forwards recorded into a hipGraph (torch.cuda.graph): nothing can be read back while capturing, so the
+# device tensors are kept and inspected on request after a replay (check_captured_status()).
+_captured_status = []
+
+
 def _post_status(status, key):
+    if torch.cuda.is_current_stream_capturing():
+        _captured_status.append(status)
+        return
     host = _pinned_pool.pop() if _pinned_pool else torch.empty((4,), dtype=torch.int32, pin_memory=True)
     host.copy_(status, non_blocking=True)
     ev = torch.cuda.Event()
@@ -68,11 +77,24 @@ def _check_oldest():
     s = host.tolist()
     _pinned_pool.append(host)
     _capacity_cache[key] = max(_capacity_cache.get(key, 0), s[0])
+    _last_status[key] = s
     if s[2]:
         raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
     if s[1]:
         raise RuntimeError(f"dgr_hip: binning buffer overflow in an earlier lazily-checked forward (needed {s[0]} "
                            f"instances); its outputs were invalid -- rerun that step")
+
+
+def check_captured_status():
+    """After replaying a graph that contains forwards: raises if one of them overflowed its binning buffer (the graph
+    was captured with a smaller scene than it is replayed on) or hit the prefiltered trap.  Blocks on the device."""
+    for st in _captured_status:
+        s = st.tolist()
+        if s[2]:
+            raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+        if s[1]:
+            raise RuntimeError(f"dgr_hip: binning buffer overflow in a graph-captured forward (needed {s[0]} instances): "
+                               f"re-capture after an eager warm-up on the larger scene")
 
 
 def check_async_errors():
@@ -185,7 +207,7 @@ class _C:
             lazy = _sync_mode() == "lazy" and cap > 0
             if lazy:
                 # status words of earlier calls have long completed: reading them does not stall the pipeline
-                while len(_pending_status) > 1:
+                while len(_pending_status) > 1 and not torch.cuda.is_current_stream_capturing():
                     _check_oldest()
                 cap = int(cap * 1.5) + 4096
                 binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)

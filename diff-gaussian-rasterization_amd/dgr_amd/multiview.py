@@ -69,6 +69,50 @@ class ViewStreams:
         self._fresh.clear()
 
 
+class CapturedStep:
+    """hipGraph capture of a fixed-shape step -- a forward + backward, a whole tracking iteration including the pose
+    optimiser (use `capturable=True` optimisers), ... -- so that replaying it costs one launch on the host.
+
+    The rasterizer's lazy forward and its backward perform no host synchronisation, launch kernels only (no memset
+    nodes: those were seen to re-execute with corrupted parameters from a captured graph on this ROCm) and allocate
+    only through torch's caching allocator, so `torch.cuda.graph` records them as they are.  Worth it when the step is
+    host-bound: config 2 (100 k Gaussians, 640x480) goes from 0.28-0.37 ms per view eager to 0.20 ms replayed; a
+    1080p / 500 k view is GPU-bound and gains nothing (and views on several streams inside ONE graph do not overlap
+    on this ROCm -- use ViewStreams eagerly for that).
+
+        step = CapturedStep(fn)      # runs fn() a few times eagerly first (sizes the binning buffer), then records it
+        out = step.replay()          # whatever fn returned at capture time: the same tensors, rewritten by every replay
+        step.check()                 # raises if a replayed forward overflowed its binning buffer
+
+    `fn` must read its inputs from fixed tensors (update them in place between replays) and should return every tensor
+    the caller wants to read afterwards (e.g. the leaves' `.grad`): after an eager step `.grad` no longer aliases the
+    captured buffers."""
+
+    def __init__(self, fn, warmup=3, device=None):
+        import os
+        if os.environ.get("DGR_SYNC_MODE", "strict") != "lazy":
+            raise RuntimeError("CapturedStep needs DGR_SYNC_MODE=lazy (a blocking status read cannot be captured)")
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                fn()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        light.check_async_errors()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.result = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.result
+
+    @staticmethod
+    def check():
+        light.check_captured_status()
+
+
 class GradientArena:
     """Sums the gradients of the Gaussian parameters over all ranks after a backward."""
 

@@ -269,3 +269,52 @@ def test_tight_culling_changes_the_lists_but_not_the_results():
     assert_grad_close(d1["gau_uncertainty"], d0["gau_uncertainty"], "gau_uncertainty", rel_to_max=1e-6)
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dview"):
         assert_grad_close(g1[k], g0[k], k, rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
+
+
+
+@pytest.mark.parametrize("variant", ["light", "full"])
+def test_captured_step_replays_forward_and_backward(monkeypatch, variant):
+    """dgr_amd.multiview.CapturedStep: one view recorded into a hipGraph; repeated replays reproduce the eager results,
+    also after the inputs were changed in place."""
+    monkeypatch.setenv("DGR_SYNC_MODE", "lazy")
+    from dgr_amd import full as F, light as D
+    from dgr_amd.multiview import CapturedStep, make_settings
+    dev = hh.dev()
+    s = make_scene(5000, 160, 120, 4)
+    if variant == "light":
+        rast = D.GaussianRasterizer(make_settings(s, 3, dev))
+    else:
+        rast = F.GaussianRasterizer(F.GaussianRasterizationSettings(
+            image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=hh.T(s.bg), scale_modifier=1.0,
+            viewmatrix=hh.T(s.view), projmatrix=hh.T(s.proj), sh_degree=3, campos=hh.T(s.campos), prefiltered=False,
+            perspec_matrix=hh.T(s.persp)))
+    means3D, shs, opac = hh.T(s.means).requires_grad_(), hh.T(s.shs).requires_grad_(), hh.T(s.opac).requires_grad_()
+    scales, rots, view = hh.T(s.scales).requires_grad_(), hh.T(s.rots).requires_grad_(), hh.T(s.view).requires_grad_()
+    means2D = torch.zeros((s.P, 3), device=dev, requires_grad=True)
+    gt, gC, gD = hh.T(s.gt), hh.T(s.gC), hh.T(s.gD[None])
+    leaves = [means3D, shs, opac, scales, rots, view]
+
+    def step():
+        for t in leaves + [means2D]:
+            t.grad = None
+        outs = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots,
+                    viewmatrix=view, gt_depth=gt)
+        torch.autograd.backward([outs[0], outs[2]], [gC, gD])
+        return [outs[0].detach()] + [t.grad for t in leaves]  # (the captured step's outputs live in these tensors)
+
+    def snapshot(tensors):
+        torch.cuda.synchronize()
+        return [t.cpu().numpy().copy() for t in tensors]
+
+    cap = CapturedStep(step)
+    for scale in (1.0, 0.7, 1.0):  # opacities changed in place between replays; every setting replayed twice
+        with torch.no_grad():
+            opac.copy_(hh.T(s.opac) * scale)
+        want = snapshot(step())
+        for _ in range(2):
+            got = snapshot(cap.replay())
+            cap.check()
+            assert np.array_equal(got[0], want[0])
+            for a, b in zip(got[1:], want[1:]):
+                assert_grad_close(a, b, "replay", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
+    D.check_async_errors()
