@@ -151,10 +151,8 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
     return DGR_OK;
 }
 
-int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, bool have_instances,
-                 hipStream_t st) {
+int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, hipStream_t st) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
-    (void)have_instances;
     dgr::RenderFwdLightArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
     r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background; r.gt_depth = c.gt_depth;
@@ -167,9 +165,8 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
 
 // ---- full variant: same front end, different blend
 int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryView geom, dgr::ImageView img,
-                      dgr::BinningView bin, bool have_instances, hipStream_t st) {
+                      dgr::BinningView bin, hipStream_t st) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
-    (void)have_instances;
     dgr::RenderFwdFullArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
     r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background;
@@ -282,7 +279,7 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
     if ((rc = forward_front(c, geom, img, st))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
-    if ((rc = forward_back(c, geom, img, bin, binning_capacity > 0, st))) return rc;
+    if ((rc = forward_back(c, geom, img, bin, st))) return rc;
     return DGR_OK;
 }
 
@@ -323,7 +320,7 @@ int dgr_light_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bi
     }
     dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
     if ((rc = binning_stages(c, geom, img, bin, R, st))) return rc;  // also with R == 0: it writes the (empty) range table
-    if ((rc = forward_back(c, geom, img, bin, R > 0, st))) return rc;
+    if ((rc = forward_back(c, geom, img, bin, st))) return rc;
     if (debug) HIP_TRY(hipStreamSynchronize(st));  // CHECK_CUDA(..., debug): L/cuda_rasterizer/auxiliary.h:166-173
     return R;
 }
@@ -404,7 +401,7 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
     if ((rc = forward_front(c, geom, img, st))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
-    if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, binning_capacity > 0, st))) return rc;
+    if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
     return DGR_OK;
 }
 
@@ -443,7 +440,7 @@ int dgr_full_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bin
     }
     dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
     if ((rc = binning_stages(c, geom, img, bin, R, st))) return rc;  // also with R == 0: it writes the (empty) range table
-    if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, R > 0, st))) return rc;
+    if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
     if (num_related_primitives) {  // second blocking read of the reference (:498)
         HIP_TRY(hipMemcpyAsync(status, img.status, sizeof(status), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

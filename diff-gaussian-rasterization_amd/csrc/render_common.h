@@ -47,7 +47,7 @@ using Staged = StagedT<DGR_TILE_PIX>;
 // iterations without a valid lane are finished pixels and sub-pixel splats -- and costs more VALU than it saves.)
 template <int NB>
 __device__ __forceinline__ unsigned stage_one(StagedT<NB>& s, int slot, uint32_t gid, const float4* __restrict__ rec,
-                                              float tile_x0, float tile_y0, float4* raw_conic) {
+                                              float tile_x0, float tile_y0) {
     const float4 q0 = rec[3 * (size_t)gid + 0];
     const float4 q1 = rec[3 * (size_t)gid + 1];
     const float4 q2 = rec[3 * (size_t)gid + 2];
@@ -60,7 +60,6 @@ __device__ __forceinline__ unsigned stage_one(StagedT<NB>& s, int slot, uint32_t
     s.rec[2 * slot + 1] = make_float4(-0.5f * LOG2E * q1.z, o, __int_as_float(slot), lthr);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
-    if (raw_conic) *raw_conic = make_float4(q1.x, q1.y, q1.z, 0.f);
     const float tau = 2.0f * 0.6931471805599453f * l2;
     const float det = q1.x * q1.z - q1.y * q1.y;
     if (!(tau > 0.0f)) return 0u;                                       // opacity below 15/255: can never contribute
@@ -126,7 +125,7 @@ __device__ __forceinline__ int build_lists(StagedT<NB>& s, unsigned code, int ti
     return n;
 }
 
-// two-entry form of load4 (fewer live registers: the backward trades a little load batching for occupancy)
+// two consecutive list entries: one 4-byte LDS read yields two record offsets
 template <int NB>
 __device__ __forceinline__ void load2(const StagedT<NB>& s, int wave, int k, float4 (&q0)[2], float4 (&q1)[2]) {
     const unsigned pk = *reinterpret_cast<const unsigned*>(&s.list[wave][k]);
@@ -134,18 +133,6 @@ __device__ __forceinline__ void load2(const StagedT<NB>& s, int wave, int k, flo
     const char* base = reinterpret_cast<const char*>(s.rec);
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        q0[u] = *reinterpret_cast<const float4*>(base + off[u]);
-        q1[u] = *reinterpret_cast<const float4*>(base + off[u] + 16);
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void load4(const StagedT<NB>& s, int wave, int k, float4 (&q0)[4], float4 (&q1)[4]) {
-    const uint2 pk = *reinterpret_cast<const uint2*>(&s.list[wave][k]);
-    const unsigned off[4] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16};
-    const char* base = reinterpret_cast<const char*>(s.rec);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
         q0[u] = *reinterpret_cast<const float4*>(base + off[u]);
         q1[u] = *reinterpret_cast<const float4*>(base + off[u] + 16);
     }

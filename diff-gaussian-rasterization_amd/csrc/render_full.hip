@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
         last_base = base;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
-        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0, nullptr);
+        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
         const int n = build_lists(s, code, tid, wave, lane);
 
         for (int k = 0; k < n; k += 2) {

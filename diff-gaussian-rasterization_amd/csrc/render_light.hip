@@ -31,10 +31,7 @@ namespace dgr {
 namespace {
 
 // ================================================================================ forward
-#ifndef DGR_FWD_UNROLL
-#define DGR_FWD_UNROLL 2
-#endif
-constexpr int FWD_UNROLL = DGR_FWD_UNROLL;
+constexpr int FWD_UNROLL = 2;  // list entries per loop iteration (4 was measured: no faster, more registers)
 
 struct StagedFwd {
     Staged f;
@@ -95,13 +92,12 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         have_flush = true;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
-        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0, nullptr);
+        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
         const int n = build_lists(s, code, tid, wave, lane);
 
         for (int k = 0; k < n; k += FWD_UNROLL) {
             float4 q0[FWD_UNROLL], q1[FWD_UNROLL];
-            if (FWD_UNROLL == 4) load4(s, wave, k, reinterpret_cast<float4(&)[4]>(q0), reinterpret_cast<float4(&)[4]>(q1));
-            else load2(s, wave, k, reinterpret_cast<float4(&)[2]>(q0), reinterpret_cast<float4(&)[2]>(q1));
+            load2(s, wave, k, q0, q1);
 #pragma unroll
             for (int u = 0; u < FWD_UNROLL; u++) {
                 const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
@@ -164,28 +160,17 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
 // Tracking mode (map_off) needs only the three sums the pose gradient is built from: a 4-value butterfly.
 constexpr int NACC_LIGHT = 14;
 
-#ifndef DGR_BWD_LDS_PAD
-#define DGR_BWD_LDS_PAD 0
-#endif
-#ifndef DGR_BWD_BATCH
-#define DGR_BWD_BATCH 128
-#endif
-constexpr int BWD_NB = DGR_BWD_BATCH;      // list positions staged per batch
+constexpr int BWD_NB = 128;                // list positions staged per batch (256: 5 workgroups per CU, 267 us; 128: 247 us)
 constexpr int BWD_LD = BWD_NB + 1;         // accumulator row length
 struct StagedBwd {
     StagedT<BWD_NB> f;
     float acc[NACC_LIGHT * BWD_LD];
     int max_last;
-#if DGR_BWD_LDS_PAD
-    char pad[DGR_BWD_LDS_PAD];  // occupancy experiment
-#endif
 };
 
-#ifndef DGR_BWD_WAVES
-#define DGR_BWD_WAVES 8  // waves per SIMD the register allocation must allow (measured: 4 -> 258 us, 8 -> 247 us)
-#endif
+// 8 waves per SIMD (63 VGPRs, no scratch): measured 258 us at the compiler's own choice of 7, 247 us at 8
 template <bool DO_MAP, bool DO_POSE>
-__global__ void __launch_bounds__(256, DGR_BWD_WAVES) render_bwd_light_kernel(RenderBwdLightArgs a) {
+__global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
     __shared__ StagedBwd sb;
     StagedT<BWD_NB>& s = sb.f;
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
@@ -204,9 +189,6 @@ __global__ void __launch_bounds__(256, DGR_BWD_WAVES) render_bwd_light_kernel(Re
     if (tid == 0) {
         sb.max_last = 0;
         write_sentinel(s);
-#if DGR_BWD_LDS_PAD
-        sb.pad[a.W & 7] = 1;
-#endif
     }
     __syncthreads();
     {
