@@ -37,6 +37,8 @@ WORKLOADS = {
     "config3": (500_000, 1920, 1080, 3),
     "config2": (100_000, 640, 480, 3),
     "config1": (10_000, 256, 256, 0),
+    "config4": (2_000_000, 1920, 1080, 3),   # per-GPU view of BASELINE config 4
+    "config5": (5_000_000, 3840, 2160, 3),   # per-GPU view of BASELINE config 5
 }
 
 
