@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--tight-cull", action="store_true",
                     help="opt-in alpha-aware tile rectangles (same images and gradients, NOT the reference's integer "
                          "path: num_rendered and the tile lists shrink); off for the headline number")
+    ap.add_argument("--views-per-allreduce", type=int, default=0,
+                    help="N>1: local views whose gradient arenas are summed before ONE all-reduce (global batch = this "
+                         "many views per GPU); 0 = --views-in-flight, 1 = an all-reduce after every view")
     ap.add_argument("--allreduce", default="blocking", choices=["overlap", "blocking"],
                     help="N>1: blocking = the view's stream waits for its gradient all-reduce (with several views in "
                          "flight the other streams keep rendering under it); overlap = additionally defer the wait to "
@@ -111,7 +114,7 @@ def main():
 
     os.environ["DGR_SYNC_MODE"] = args.sync_mode
     from dgr_amd import _capi, light
-    from dgr_amd.multiview import GradientArena, ViewStreams, make_settings
+    from dgr_amd.multiview import GradientArena, GroupedReduce, ViewStreams, make_settings
     from dgr_amd.synth import make_scene
     if args.variant == "full":
         from dgr_amd import full as V
@@ -146,6 +149,8 @@ def main():
     arena = GradientArena(params) if dist is not None else None
 
     pending = [None]
+    G = args.views_per_allreduce if args.views_per_allreduce > 0 else max(1, args.views_in_flight)
+    grouped = GroupedReduce(arena, dist, G) if (arena is not None and G > 1) else None
 
     def step():
         for p_ in params + [view]:
@@ -158,7 +163,9 @@ def main():
         else:
             color, radii, depth, median, var, alpha, unc, px = outs
             torch.autograd.backward([color, depth, median, var], [gC, gD, gM, gV])
-        if arena is not None:  # one fused RCCL all-reduce of the per-Gaussian gradients
+        if grouped is not None:  # sum over the group's local views, then one fused RCCL all-reduce
+            grouped.add_view()
+        elif arena is not None:  # one fused RCCL all-reduce of the per-Gaussian gradients after every view
             if args.allreduce == "blocking":
                 arena.all_reduce(dist)
             else:
@@ -168,6 +175,8 @@ def main():
         return radii
 
     def drain():
+        if grouped is not None:
+            grouped.flush()
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
@@ -266,8 +275,9 @@ def main():
                                    f"fwd+bwd incl. viewmatrix gradient, one view per step, {K} independent views in flight per GPU", "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
                        "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "tight_cull": bool(args.tight_cull),
-                       "gradient_allreduce": (None if world == 1 else
-                                              f"{args.allreduce}: one fused RCCL sum of 248 B/Gaussian per view"),
+                       "gradient_allreduce": (None if dist is None else
+                                              f"one fused RCCL sum of 248 B/Gaussian per {G} local view(s)"
+                                              + ("" if G > 1 else f" ({args.allreduce})")),
                        "view_hbm_frac": 0.83e9 * (316 * P + 566 * V + 172 * R + 72 * N) / (316 * 5e5 + 566 * 425824 + 172 * 1654310 + 72 * 2073600)
                                         * (views_per_s / world) / (HBM_PEAK_GBS * 1e9),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},

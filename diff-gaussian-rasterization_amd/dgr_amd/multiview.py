@@ -156,3 +156,46 @@ class PendingReduce:
         for w in self.works:
             w.wait()
         return self.tensors
+
+
+class GroupedReduce:
+    """One all-reduce per GROUP of local views instead of one per view (fewer, larger collectives: the global batch is
+    `group_size` views per GPU).  Call `add_view()` right after a view's backward, on that view's stream; when the
+    group is full its gradient arenas are summed into the first one (on the current stream, after the other views'
+    streams) and that sum is all-reduced.  `flush()` reduces an incomplete group.  Views whose gradients autograd
+    copied instead of aliasing (no fused span) are reduced immediately, one by one."""
+
+    def __init__(self, arena, dist, group_size, group=None):
+        self.arena, self.dist, self.n, self.group = arena, dist, max(1, int(group_size)), group
+        self.pending = []   # [(span, event recorded on the producing stream)]
+        self.collectives = 0
+        self.last_total = None
+
+    def add_view(self):
+        span = self.arena.fused_span()
+        if span is None:
+            self.collectives += self.arena.all_reduce(self.dist, self.group)
+            return
+        ev = torch.cuda.Event() if span.is_cuda else None
+        if ev is not None:
+            ev.record()
+        self.pending.append((span, ev))
+        if len(self.pending) >= self.n:
+            self.flush()
+
+    def flush(self):
+        if not self.pending:
+            return None
+        total = self.pending[0][0]
+        if total.is_cuda:
+            cur = torch.cuda.current_stream(total.device)
+            for span, ev in self.pending:
+                cur.wait_event(ev)
+                span.record_stream(cur)
+        for span, _ in self.pending[1:]:
+            total.add_(span)
+        self.dist.all_reduce(total, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.collectives += 1
+        self.pending = []
+        self.last_total = total
+        return total

@@ -99,3 +99,51 @@ def test_gradient_all_reduce_equals_serial_sum_over_views(oracle, fused, async_o
             want = serial[0][GKEY[n]].astype(np.float64) + serial[1][GKEY[n]]
             np.testing.assert_allclose(grads[n], want.reshape(grads[n].shape), rtol=1e-6, atol=1e-9)
         np.testing.assert_allclose(dview, serial[rank]["dL_dview"], rtol=1e-6)  # pose gradient is per view, not reduced
+
+
+def worker_grouped(rank, world, port, q):
+    for p in (ROOT, PKG):
+        sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dgr_amd import light
+    from dgr_amd.multiview import GradientArena, GroupedReduce
+    P, W, H, deg = 800, 48, 32, 2
+    f32 = dict(dtype=torch.float32, device="cpu")
+    params = [torch.zeros((P, 3), requires_grad=True) for _ in NAMES]  # shapes are irrelevant to the exchange
+    arena = GradientArena([])
+    grouped = GroupedReduce(arena, dist, group_size=2)
+    for local in range(2):  # two local views per rank: views 2*rank, 2*rank + 1
+        g = view_grads(P, W, H, deg, 2 * rank + local)
+        seg = light._grad_arena(P, 16, f32)  # (sets light._last_arena, as a backward does)
+        for n in NAMES:
+            seg[n].copy_(torch.from_numpy(g[GKEY[n]]))
+        grouped.add_view()
+        if local == 0:
+            first = seg
+            assert grouped.collectives == 0  # nothing reduced before the group is complete
+    assert grouped.collectives == 1 and not grouped.pending
+    q.put((rank, {n: first[n].numpy().copy() for n in NAMES}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grouped_reduce_sums_local_views_then_one_collective(oracle):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker_grouped, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sys.path[:0] = [ROOT, PKG]
+    serial = [view_grads(800, 48, 32, 2, k) for k in range(4)]
+    for rank, grads in res:
+        for n in NAMES:
+            want = sum(sv[GKEY[n]].astype(np.float64) for sv in serial)
+            np.testing.assert_allclose(grads[n], want.reshape(grads[n].shape), rtol=2e-5, atol=1e-8)  # float32 sums of four views
