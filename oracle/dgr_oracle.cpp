@@ -1116,10 +1116,12 @@ void renderBackwardFull(const State& st, const float* bg, const float* colors, c
 //  6 sum over quadrants of max over its four 4x4 blocks of [5]-type counts (iterations of a wave whose 16-lane rows
 //    walk one block's list each)               7 the same for [3]-type counts (backward)
 //  8 sum over tiles of max over 4 quadrants of [4]-type counts   9 the same for [2]
-void pairStats(const State& st, double* out) {
+void pairStats(const State& st, double* out, double* out2) {
     const int W = st.W, H = st.H;
     const int tiles = st.gx * st.gy;
     double acc[10] = {0};
+    double acc2[8] = {0};  // 0 valid (8x4, Gaussian) pairs, 1 tested, 2/3 wave iterations bwd/fwd with per-128-batch max over the
+                           // two halves, 4/5 the same for four 4x4 rows, 6/7 for the whole quadrant (one list per wave)
 #pragma omp parallel for schedule(dynamic, 4)
     for (int tile = 0; tile < tiles; tile++) {
         const uint32_t r0 = st.ranges[2 * tile], r1 = st.ranges[2 * tile + 1];
@@ -1133,8 +1135,30 @@ void pairStats(const State& st, double* out) {
             done[p] = !inside[p];
         }
         double loc[10] = {0};
+        double loc2[8] = {0};
+        int hb_valid[8] = {0}, hb_tested[8] = {0}, bb_valid[16] = {0}, bb_tested[16] = {0}, qb_valid[4] = {0}, qb_tested[4] = {0};
+        auto close_batch = [&]() {
+            for (int q = 0; q < 4; q++) {
+                const int qx = q & 1, qy = q >> 1;
+                const int h0 = qy * 4 + qx, h1 = h0 + 2;  // halves: index = (y / 4) * 2 + x / 8
+                loc2[2] += std::max(hb_valid[h0], hb_valid[h1]);
+                loc2[3] += std::max(hb_tested[h0], hb_tested[h1]);
+                int mv = 0, mt = 0;
+                for (int r = 0; r < 4; r++) {
+                    const int b = ((qy) * 2 + (r >> 1)) * 4 + qx * 2 + (r & 1);
+                    mv = std::max(mv, bb_valid[b]);
+                    mt = std::max(mt, bb_tested[b]);
+                }
+                loc2[4] += mv; loc2[5] += mt;
+                loc2[6] += qb_valid[q]; loc2[7] += qb_tested[q];
+            }
+            for (int i = 0; i < 8; i++) hb_valid[i] = hb_tested[i] = 0;
+            for (int i = 0; i < 16; i++) bb_valid[i] = bb_tested[i] = 0;
+            for (int i = 0; i < 4; i++) qb_valid[i] = qb_tested[i] = 0;
+        };
         int q_tested[4] = {0}, q_valid[4] = {0}, b_tested[16] = {0}, b_valid[16] = {0};
         for (uint32_t k = r0; k < r1; k++) {
+            if (k > r0 && ((k - r0) % 128) == 0) close_batch();
             bool all_done = true;
             for (int p = 0; p < 256; p++) all_done = all_done && done[p];
             if (all_done) break;
@@ -1176,8 +1200,8 @@ void pairStats(const State& st, double* out) {
                         alive = alive || !done[p] || blended[p];
                     }
                 const bool box = tau > 0 && lx + hx >= x0 && lx - hx <= x0 + 7 && ly + hy >= y0 && ly - hy <= y0 + 7;
-                if (v) { loc[2] += 1; q_valid[q]++; }
-                if (box && alive) { loc[4] += 1; q_tested[q]++; }
+                if (v) { loc[2] += 1; q_valid[q]++; qb_valid[q]++; }
+                if (box && alive) { loc[4] += 1; q_tested[q]++; qb_tested[q]++; }
             }
             for (int b = 0; b < 16; b++) {
                 const int x0 = (b & 3) * 4, y0 = (b >> 2) * 4;
@@ -1189,10 +1213,24 @@ void pairStats(const State& st, double* out) {
                         alive = alive || !done[p] || blended[p];
                     }
                 const bool box = tau > 0 && lx + hx >= x0 && lx - hx <= x0 + 3 && ly + hy >= y0 && ly - hy <= y0 + 3;
-                if (v) { loc[3] += 1; b_valid[b]++; }
-                if (box && alive) { loc[5] += 1; b_tested[b]++; }
+                if (v) { loc[3] += 1; b_valid[b]++; bb_valid[b]++; }
+                if (box && alive) { loc[5] += 1; b_tested[b]++; bb_tested[b]++; }
+            }
+            for (int hb = 0; hb < 8; hb++) {  // 8 wide x 4 high halves of the quadrants
+                const int x0 = (hb & 1) * 8, y0 = (hb >> 1) * 4;
+                bool v = false, alive = false;
+                for (int yy = 0; yy < 4; yy++)
+                    for (int xx = 0; xx < 8; xx++) {
+                        const int p = (y0 + yy) * 16 + x0 + xx;
+                        v = v || blended[p];
+                        alive = alive || !done[p] || blended[p];
+                    }
+                const bool box = tau > 0 && lx + hx >= x0 && lx - hx <= x0 + 7 && ly + hy >= y0 && ly - hy <= y0 + 3;
+                if (v) { loc2[0] += 1; hb_valid[hb]++; }
+                if (box && alive) { loc2[1] += 1; hb_tested[hb]++; }
             }
         }
+        close_batch();
         for (int q = 0; q < 4; q++) {
             int mt = 0, mv = 0;
             for (int r = 0; r < 4; r++) {
@@ -1206,13 +1244,18 @@ void pairStats(const State& st, double* out) {
         loc[8] += std::max(std::max(q_tested[0], q_tested[1]), std::max(q_tested[2], q_tested[3]));
         loc[9] += std::max(std::max(q_valid[0], q_valid[1]), std::max(q_valid[2], q_valid[3]));
 #pragma omp critical
-        for (int i = 0; i < 10; i++) acc[i] += loc[i];
+        {
+            for (int i = 0; i < 10; i++) acc[i] += loc[i];
+            for (int i = 0; i < 8; i++) acc2[i] += loc2[i];
+        }
     }
     for (int i = 0; i < 10; i++) out[i] = acc[i];
+    if (out2) for (int i = 0; i < 8; i++) out2[i] = acc2[i];
 }
 
 extern "C" {
-void dgro_pair_stats(void* st, double* out) { pairStats(*(State*)st, out); }
+void dgro_pair_stats(void* st, double* out) { pairStats(*(State*)st, out, nullptr); }
+void dgro_pair_stats2(void* st, double* out, double* out2) { pairStats(*(State*)st, out, out2); }
 
 
 void* dgro_state_new() { return new State(); }
