@@ -507,6 +507,17 @@ int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* ou
     return DGR_OK;
 }
 
+int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    const int* visible, float lr, float beta1, float beta2, float eps, int step) {
+    if (rows < 0 || k <= 0 || step < 1 || (rows > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) {
+        g_last_error = "dgr_sparse_adam: bad argument";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    HIP_TRY(dgr::launch_sparse_adam((size_t)rows, k, param, grad, exp_avg, exp_avg_sq, visible, lr, beta1, beta2, eps, step,
+                                    (hipStream_t)stream));
+    return DGR_OK;
+}
+
 int dgr_set_option(const char* name, int value) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }

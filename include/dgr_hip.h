@@ -162,6 +162,13 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
                       int binning_capacity, const char* geom_buffer, const char* binning_buffer,
                       const char* image_buffer, void* dst_device);
 
+/* Fused sparse Adam step on one per-Gaussian tensor [rows, k] (the reference leaves the optimiser
+ * to torch).  torch.optim.Adam's update (no weight decay, no amsgrad) with bias correction for the 1-based `step`;
+ * rows with visible[row] <= 0 are skipped -- parameter and both moments untouched, as in 3DGS's sparse Adam -- and
+ * `visible` == NULL updates every row.  `visible` is typically the forward's `radii`. */
+int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    const int* visible, float lr, float beta1, float beta2, float eps, int step);
+
 /* Process-wide options (default 0).
  *  "tight_cull": 1 = alpha-aware tile rectangles.  The reference gives a Gaussian every tile its
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle
