@@ -318,3 +318,60 @@ def test_captured_step_replays_forward_and_backward(monkeypatch, variant):
             for a, b in zip(got[1:], want[1:]):
                 assert_grad_close(a, b, "replay", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
     D.check_async_errors()
+
+
+@pytest.mark.parametrize("variant", ["light", "full"])
+def test_results_do_not_depend_on_stale_memory(variant):
+    """Every buffer the kernels read is written first: the same view rendered after filling the caching allocator's free
+    blocks with NaN bit patterns, with 0xFF bytes and with zeros gives identical images and gradients up to atomic order."""
+    from dgr_amd import full as F, light as D
+    from dgr_amd.multiview import make_settings
+    dev = hh.dev()
+    s = make_scene(6000, 200, 136, 12)
+    if variant == "light":
+        rast = D.GaussianRasterizer(make_settings(s, 3, dev))
+    else:
+        rast = F.GaussianRasterizer(F.GaussianRasterizationSettings(
+            image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=hh.T(s.bg), scale_modifier=1.0,
+            viewmatrix=hh.T(s.view), projmatrix=hh.T(s.proj), sh_degree=3, campos=hh.T(s.campos), prefiltered=False,
+            perspec_matrix=hh.T(s.persp)))
+    gt, gC, gD = hh.T(s.gt), hh.T(s.gC), hh.T(s.gD[None])
+
+    def poison(kind):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        blocks = []
+        for nbytes in (64 << 20, 16 << 20, 4 << 20, 1 << 20, 256 << 10, 64 << 10, 4 << 10, 512):
+            for _ in range(6):
+                t = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                if kind == "nan":
+                    t.view(torch.float32).fill_(float("nan"))
+                else:
+                    t.fill_(0xFF if kind == "ff" else 0)
+                blocks.append(t)
+        torch.cuda.synchronize()
+        del blocks  # back to the allocator's free lists, contents intact
+
+    def run():
+        leaves = [hh.T(a).requires_grad_() for a in (s.means, s.shs, s.opac, s.scales, s.rots, s.view)]
+        means3D, shs, opac, scales, rots, view = leaves
+        means2D = torch.zeros((s.P, 3), device=dev, requires_grad=True)
+        outs = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots,
+                    viewmatrix=view, gt_depth=gt)
+        torch.autograd.backward([outs[0], outs[2]], [gC, gD])
+        torch.cuda.synchronize()
+        return [o.detach().cpu().numpy() for o in outs if o.dtype == torch.float32], [t.grad.cpu().numpy() for t in leaves]
+
+    results = []
+    for kind in ("zero", "nan", "ff"):
+        poison(kind)
+        results.append(run())
+    for outs, grads in results[1:]:
+        for a, b in zip(outs, results[0][0]):
+            if a.ndim == 3:
+                assert np.array_equal(a, b)  # images are deterministic
+            else:
+                assert_grad_close(a, b, "gau_uncertainty", rel_to_max=2e-6)  # float atomics: order only
+        for a, b in zip(grads, results[0][1]):
+            assert np.isfinite(a).all()
+            assert_grad_close(a, b, "stale memory", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
