@@ -103,6 +103,8 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path")
+    if os.environ.get("DGR_BENCH_SHARE_GPU") == "1":
+        local_rank = 0  # test hook: every rank on GPU 0 (with DGR_BENCH_BACKEND=gloo, to exercise the N>1 logic on one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -110,7 +112,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("DGR_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for the test hook above
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     os.environ["DGR_SYNC_MODE"] = args.sync_mode
     from dgr_amd import _capi, light
