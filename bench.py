@@ -68,8 +68,8 @@ def algorithmic_bytes(stage, P, V, R, N, M):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="config3", choices=sorted(WORKLOADS))
     ap.add_argument("--variant", default="light", choices=["light", "full"],
                     help="light = the headline (config 3); full = the -full flavour (use with --workload config2)")
