@@ -106,7 +106,7 @@ __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
 // One 64-byte accumulator row per Gaussian so that every atomic of a (pixel, Gaussian) pair lands
 // in a single cache line:
 //  [0..2] dL/dcolour  [3] dL/ddepth (blend + variance terms)  [4..5] dL/dmean2D
-//  [6..8] dL/dconic (xx, xy, yy)  [9] dL/dopacity  [10..12] median-depth term of dL/dmean3D
+//  [6..8] dL/dconic (xx, xy, yy)  [9] dL/dopacity  [10] sum of dL/dmedian over the pixels whose median this is  [11..12] unused
 //  [13] sum of the blend-only depth term (pose gradient)  [14..15] unused
 // full variant: [0..9] as above ([3] = dL/dgau_depth incl. the uncertainty term), then the sums its pose gradient
 // (ComputePG, F/cuda_rasterizer/backward.cu:838-1338) is linear in:

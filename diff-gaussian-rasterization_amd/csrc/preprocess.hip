@@ -431,7 +431,14 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
 
         const bool full = a.full_variant != 0;
         // light: the blend kernel's median-depth term; full: computeCov2DCUDA ASSIGNS (F/cuda_rasterizer/backward.cu:383)
-        float3 dmean = full ? make_float3(0.f, 0.f, 0.f) : make_float3(acc[10], acc[11], acc[12]);
+        float3 dmean = make_float3(0.f, 0.f, 0.f);
+        if (!full) {
+            // light: the blend kernel's median-depth term (L/cuda_rasterizer/backward.cu:654-664), whose pixel sum of
+            // dL/dmedian arrives in acc[10]; the per-Gaussian factors are applied here
+            const float* v = a.view;
+            const float mul3 = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
+            dmean = make_float3((v[2] - v[3] * mul3) * acc[10], (v[6] - v[7] * mul3) * acc[10], (v[10] - v[11] * mul3) * acc[10]);
+        }
         float3 s_cam = make_float3(0.f, 0.f, 0.f);  // full: sum_ch dL_dcolor[ch] * d(rgb[ch])/d(campos.{x,y,z})
         float dcov[6] = {0, 0, 0, 0, 0, 0};
         float3 dscale = make_float3(0, 0, 0);

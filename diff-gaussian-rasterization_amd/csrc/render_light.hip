@@ -223,8 +223,6 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     //   X_j = <features_j, dL/dpixel>,   S <- alpha_last X_last + (1 - alpha_last) S,   dL/dalpha = X_j - S.
     float S = 0.f, X_last = 0.f, last_alpha = 0.f, last_om = 1.f;  // last_om = 1 - last_alpha
     bool mid_once = true;
-    const float v2 = a.view[2], v3 = a.view[3], v6 = a.view[6], v7 = a.view[7], v10 = a.view[10], v11 = a.view[11],
-                v14 = a.view[14];
     // which accumulator component this lane's quad delivers after the butterfly (-1: none)
     int my_comp;
     if (DO_MAP) {
@@ -279,12 +277,11 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     last_om = om;
                     const float dL_dalpha = (X - S) * T + bg_term * inv;
                     qq = oG * dL_dalpha;
-                    if (DO_MAP && T > 0.5f && mid_once) {  // backward.cu:654-664: once per pixel, straight to LDS
-                        const float* mg = a.means3D + 3 * (size_t)s.id[j];
-                        const float mul3 = v2 * mg[0] + v6 * mg[1] + v10 * mg[2] + v14;
-                        atomicAdd(&sb.acc[10 * BWD_LD + j], (v2 - v3 * mul3) * dpix_median);
-                        atomicAdd(&sb.acc[11 * BWD_LD + j], (v6 - v7 * mul3) * dpix_median);
-                        atomicAdd(&sb.acc[12 * BWD_LD + j], (v10 - v11 * mul3) * dpix_median);
+                    if (DO_MAP && T > 0.5f && mid_once) {
+                        // backward.cu:654-664, once per pixel: the median-depth term of dL/dmean3D is
+                        // (v_k - v_{k+1} mul3) * dL/dmedian with factors that depend on the Gaussian alone, so only
+                        // the pixel sum of dL/dmedian is formed here (one LDS atomic); preprocess_bwd applies them.
+                        atomicAdd(&sb.acc[10 * BWD_LD + j], dpix_median);
                         mid_once = false;
                     }
                 }
