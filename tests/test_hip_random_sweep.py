@@ -1,0 +1,48 @@
+"""Randomised sweep of scene shapes against the oracle (light variant): image sizes that are not multiples of the tile,
+images smaller than a tile, blown-up Gaussians (scale_modifier), translucent and opaque populations, every SH degree.
+The integer path must be bit-exact and images / stage-isolated gradients inside the usual bars for each draw."""
+import numpy as np
+import pytest
+
+from util import assert_grad_close, assert_image_close, make_scene
+import hip_helpers as hh
+
+pytestmark = pytest.mark.gpu
+
+rng = np.random.default_rng(2024)
+DRAWS = []
+for i in range(14):
+    W = int(rng.choice([7, 16, 33, 100, 129, 250, 321]))
+    H = int(rng.choice([5, 16, 47, 64, 97, 200]))
+    DRAWS.append(dict(P=int(rng.integers(50, 12000)), W=W, H=H, deg=int(rng.integers(0, 4)), seed=100 + i,
+                      scale_modifier=float(rng.choice([0.5, 1.0, 1.0, 2.5, 6.0])),
+                      opacity=str(rng.choice(["as drawn", "translucent", "opaque"]))))
+
+
+@pytest.mark.parametrize("draw", DRAWS, ids=lambda d: f"P{d['P']}_{d['W']}x{d['H']}_d{d['deg']}_s{d['scale_modifier']}_{d['opacity'][:5]}")
+def test_random_scene(oracle, draw):
+    s = make_scene(draw["P"], draw["W"], draw["H"], draw["seed"])
+    if draw["opacity"] == "translucent":
+        s = s._replace(opac=(s.opac * 0.12).astype(np.float32))  # many below the 15/255 threshold
+    elif draw["opacity"] == "opaque":
+        s = s._replace(opac=np.minimum(1.0, s.opac * 0.2 + 0.85).astype(np.float32))  # early termination everywhere
+    sm, deg = draw["scale_modifier"], draw["deg"]
+    out, d = hh.hip_forward(s, deg, scale_modifier=sm)
+    st, ref = hh.oracle_forward(oracle, s, deg, scale_modifier=sm)
+    assert d["num_rendered"] == ref["num_rendered"]
+    assert np.array_equal(d["radii"], ref["radii"])
+    assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    npx = s.W * s.H
+    for k in ("color", "depth", "depth_median", "opacity_map"):
+        assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx))  # small images: one flipped pixel
+    if not np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib")):
+        return  # a flipped termination: the backward would be compared on different lists
+    grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+    g = hh.hip_backward(s, deg, out, grads=grads, alphas=ref["opacity_map"], scale_modifier=sm)
+    gr = hh.oracle_backward(oracle, st, s, deg, ref["opacity_map"], grads=grads, scale_modifier=sm)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dview"):
+        # one pixel's median-depth term may land on the neighbouring Gaussian (the backward re-derives T by division; its
+        # T > 0.5 test is a hard threshold like the others): two rows of dL_dmeans3D, nothing else
+        rows = 2 if k == "dL_dmeans3D" else (1 if g[k].ndim > 1 and k != "dL_dview" else 0)
+        assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=rows)
