@@ -46,3 +46,31 @@ def test_random_scene(oracle, draw):
         # T > 0.5 test is a hard threshold like the others): two rows of dL_dmeans3D, nothing else
         rows = 2 if k == "dL_dmeans3D" else (1 if g[k].ndim > 1 and k != "dL_dview" else 0)
         assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=rows)
+
+
+FULL_DRAWS = [dict(P=int(rng.integers(200, 9000)), W=int(rng.choice([9, 48, 131, 200])), H=int(rng.choice([6, 33, 80, 144])),
+                   deg=int(rng.integers(0, 4)), seed=300 + i, opacity=str(rng.choice(["as drawn", "translucent", "opaque"])))
+              for i in range(8)]
+
+
+@pytest.mark.parametrize("draw", FULL_DRAWS, ids=lambda d: f"full_P{d['P']}_{d['W']}x{d['H']}_d{d['deg']}_{d['opacity'][:5]}")
+def test_random_scene_full_variant(oracle, draw):
+    s = make_scene(draw["P"], draw["W"], draw["H"], draw["seed"])
+    if draw["opacity"] == "translucent":
+        s = s._replace(opac=(s.opac * 0.12).astype(np.float32))
+    elif draw["opacity"] == "opaque":
+        s = s._replace(opac=np.minimum(1.0, s.opac * 0.2 + 0.85).astype(np.float32))
+    deg, npx = draw["deg"], draw["W"] * draw["H"]
+    grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gV))
+    out, d = hh.hip_full_forward(s, deg)
+    g = hh.hip_full_backward(s, deg, out, grads=grads)
+    st, ref, gr = hh.oracle_full(oracle, s, deg, grads=grads)
+    assert np.array_equal(d["radii"], ref["radii"]) and d["num_rendered"] == ref["num_rendered"]
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    for k in ("color", "depth", "uncertainty"):
+        assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx))
+    if not np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib")):
+        return
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=1)
+    assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=1e-4, elem_rtol=5e-3, elem_frac=0.1)
