@@ -1,14 +1,16 @@
 #!/bin/bash
-# Usage (on the GPU box, from the repo root): bash profiles/run_profile.sh <tag>
+# Usage (on the GPU box, from the repo root): bash profiles/run_profile.sh <tag> [extra bench.py arguments]
 # Writes gpurun_out/prof_<tag>/{stats, pmc*}; copy the summaries you want judged into profiles/.
 set -u
 TAG=${1:-r1}
+shift || true
+EXTRA="$*"
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # kernel trace of the default bench command (several views in flight: kernel durations include time-sharing), and of
 # the same workload one view at a time (isolated kernel durations); the counter passes use the isolated form
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline $EXTRA"
 rocprofv3 --kernel-trace --stats -d $OUT/stats_default -o trace -- $BENCH > $OUT/bench_stats_default.log 2>&1
 CMD="$BENCH --views-in-flight 1"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o trace -- $CMD > $OUT/bench_stats.log 2>&1
