@@ -253,6 +253,19 @@ def main():
         V = int((radii > 0).sum().item())
         R = int(_capi_last_num_rendered(P, H, W, dev))
         N = W * H
+        # secondary figure of SURVEY.md s8(d): (pixel, Gaussian) pairs evaluated = 2 x sum of n_contrib per view (fwd + bwd)
+        pair_evals = None
+        if args.variant == "light":
+            st_ = light._C.rasterize_gaussians(
+                settings.bg, means3D.detach(), torch.empty(0, device=dev), opac.detach(), scales.detach(), rots.detach(),
+                1.0, torch.empty(0, device=dev), settings.viewmatrix, gt, settings.projmatrix, settings.tanfovx,
+                settings.tanfovy, H, W, shs.detach(), deg, settings.campos, False, False)
+            nc = torch.zeros(N, dtype=torch.int32, device=dev)
+            lib_ = _capi.load()
+            cap_ = int(st_[0])  # n_contrib lives in the image buffer: any valid binning capacity will do for this export
+            if lib_.dgr_state_export(_capi.stream_handle(), b"n_contrib", P, W, H, int(st_[0]), cap_, st_[7].data_ptr(),
+                                     st_[8].data_ptr(), st_[9].data_ptr(), nc.data_ptr()) >= 0:
+                pair_evals = 2 * int(nc.to(torch.int64).sum().item())
         views_per_s = world * args.steps / elapsed
         dom_ms = dom_tot / max(dom_n, 1)
         abytes = algorithmic_bytes(dominant, P, V, R, N, 16)
@@ -280,7 +293,9 @@ def main():
             "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
                                    f"fwd+bwd incl. viewmatrix gradient, one view per step, {K} independent views in flight per GPU", "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
-                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "tight_cull": bool(args.tight_cull),
+                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms,
+                       "pair_evals_per_view": pair_evals,
+                       "pair_evals_per_s": None if pair_evals is None else pair_evals * views_per_s / world, "tight_cull": bool(args.tight_cull),
                        "gradient_allreduce": (None if dist is None else
                                               f"one fused RCCL sum of 248 B/Gaussian per {G} local view(s)"
                                               + ("" if G > 1 else f" ({args.allreduce})")),
