@@ -145,7 +145,7 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
                    hipStream_t st) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
     { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_rank(c.P, geom, img, bin, gx, capacity, st)); }
-    { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, capacity, st)); }
+    { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, gx, capacity, st)); }
     { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
     { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
     return DGR_OK;

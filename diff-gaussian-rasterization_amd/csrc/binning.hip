@@ -30,7 +30,13 @@ constexpr int SORT_THREADS = 256;
 constexpr int COUNT_STAGE = 4096;   // ranks staged per 256-Gaussian block in count_rank (16 KB)
 constexpr int SORT_LDS_MAX = 4096;  // keys per tile sorted in LDS (32 KB); larger tiles sort in global memory
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img, int tiles, int capacity) {
+__global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img, int tiles, int grid_x, int capacity) {
+    const int pairs_x = (grid_x + 1) >> 1;
+    // tile i = (ty, tx): half tx & 1 of the 64-bit pair counter (ty, tx / 2), one pair per cache line (count_rank)
+    auto count_of = [&](int i) {
+        const int ty = i / grid_x, tx = i - ty * grid_x;
+        return img.tile_count[((size_t)ty * pairs_x + (tx >> 1)) * DGR_COUNT_STRIDE + (tx & 1)];
+    };
     __shared__ uint32_t wsum[SCAN_THREADS / 64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (tiles + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -43,12 +49,12 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img,
     if (per <= REG) {
 #pragma unroll
         for (int k = 0; k < REG; k++) {
-            c[k] = (lo + k < hi) ? img.tile_count[(size_t)(lo + k) * DGR_COUNT_STRIDE] : 0u;
+            c[k] = (lo + k < hi) ? count_of(lo + k) : 0u;
         }
 #pragma unroll
         for (int k = 0; k < REG; k++) s += c[k];
     } else {
-        for (int i = lo; i < hi; i++) s += img.tile_count[(size_t)i * DGR_COUNT_STRIDE];
+        for (int i = lo; i < hi; i++) s += count_of(i);
     }
     // wave-level inclusive scan, then the 16 wave totals through LDS: one barrier
     uint32_t incl = s;
@@ -78,7 +84,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img,
         }
     } else {
         for (int i = lo; i < hi; i++) {
-            const uint32_t cc = img.tile_count[(size_t)i * DGR_COUNT_STRIDE];
+            const uint32_t cc = count_of(i);
             img.ranges[i] = overflow ? make_uint2(0u, 0u) : make_uint2(run, run + cc);
             run += cc;
         }
@@ -123,22 +129,64 @@ __global__ void __launch_bounds__(256) count_rank_kernel(int P, GeometryView geo
                                                         // scan_tiles sees the true total and flags the overflow
     const uint32_t loc = off0 - block_base;
     const uint32_t w = (uint32_t)(r.z - r.x);
+    // Horizontally adjacent tiles (2p, 2p + 1) share one 64-bit counter {count(2p), count(2p + 1) << 32}: an instance
+    // pair in the same row takes ONE returning atomic that bumps both halves (the stage is bound by the number of
+    // atomics the memory-side unit retires, not by their width).  Per rectangle row: an unpaired tile first if the row
+    // starts at an odd tile, then pairs, then an unpaired last tile.
+    const uint32_t lead = r.x & 1u;                       // row starts at an odd tile
+    const uint32_t rest = (w > lead) ? w - lead : 0u;
+    const uint32_t ops_row = (w ? (w >= lead ? lead : 0u) : 0u) + (rest >> 1) + (rest & 1u);
+    const uint32_t h = (uint32_t)(r.w - r.y);
+    const uint32_t n_ops = ops_row * h;
+    const int pairs_x = (grid_x + 1) >> 1;
+    unsigned long long* cnt64 = reinterpret_cast<unsigned long long*>(img.tile_count);
+    auto put = [&](uint32_t kk, uint32_t v) {
+        if (staged) stage[loc + kk] = v;
+        else if (store) bin.ranks[off0 + kk] = v;
+    };
     // four returning atomics in flight per thread
-    for (uint32_t k = 0; k < n; k += 4) {
-        uint32_t rank[4];
+    for (uint32_t q = 0; q < n_ops; q += 4) {
+        unsigned long long got[4];
+        uint32_t kk0[4];
+        int kind[4];  // 0: none, 1: low half only, 2: high half only, 3: both
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t kk = k + u;
-            if (kk < n) {
-                const uint32_t yy = kk / w, xx = kk - yy * w;  // row-major over the rect, as duplicateWithKeys enumerates
-                rank[u] = atomicAdd(&img.tile_count[(size_t)((r.y + yy) * grid_x + r.x + xx) * DGR_COUNT_STRIDE], 1u);
+            kind[u] = 0;
+            const uint32_t qq = q + u;
+            if (qq < n_ops) {
+                const uint32_t yy = qq / ops_row, o = qq - yy * ops_row;
+                uint32_t x;  // first tile of this op, relative to r.x
+                bool both = false;
+                if (lead && o == 0) {
+                    x = 0;
+                } else {
+                    x = lead + 2u * (o - lead);
+                    both = x + 1u < w;
+                }
+                const uint32_t tx = r.x + x;
+                unsigned long long* c = cnt64 + ((size_t)(r.y + yy) * pairs_x + (tx >> 1)) * (DGR_COUNT_STRIDE / 2);
+                kk0[u] = yy * w + x;
+                if (both) {
+                    kind[u] = 3;
+                    got[u] = atomicAdd(c, 0x0000000100000001ull);
+                } else if (tx & 1u) {
+                    kind[u] = 2;
+                    got[u] = (unsigned long long)atomicAdd(reinterpret_cast<uint32_t*>(c) + 1, 1u) << 32;
+                } else {
+                    kind[u] = 1;
+                    got[u] = atomicAdd(reinterpret_cast<uint32_t*>(c), 1u);
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            if (k + u < n) {
-                if (staged) stage[loc + k + u] = rank[u];
-                else if (store) bin.ranks[off0 + k + u] = rank[u];
+            if (kind[u] == 3) {
+                put(kk0[u], (uint32_t)got[u]);
+                put(kk0[u] + 1u, (uint32_t)(got[u] >> 32));
+            } else if (kind[u] == 2) {
+                put(kk0[u], (uint32_t)(got[u] >> 32));
+            } else if (kind[u] == 1) {
+                put(kk0[u], (uint32_t)got[u]);
             }
         }
     }
@@ -317,8 +365,8 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_tiles_kernel(ImageView img,
 
 }  // namespace
 
-hipError_t launch_scan_tiles(ImageView img, int tiles, int capacity, hipStream_t stream) {
-    launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, capacity);
+hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, hipStream_t stream) {
+    launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, grid_x, capacity);
     return hipGetLastError();
 }
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,

@@ -166,7 +166,7 @@ hipError_t launch_sparse_adam(size_t rows, int k, float* param, const float* gra
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream);
 
 // binning: tile_count -> ranges (+ total in status[0], overflow in status[1]); emit keys; sort tiles
-hipError_t launch_scan_tiles(ImageView img, int tiles, int capacity, hipStream_t stream);
+hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, hipStream_t stream);
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,
                              hipStream_t stream);
 hipError_t launch_scan_blocks(int P, GeometryView geom, ImageView img, hipStream_t stream);
