@@ -15,6 +15,7 @@
 #include <vector>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <string>
 
@@ -47,6 +48,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 struct StageProf {
     const char* name;
     bool on = false;
+    unsigned seen = 0;  // launches of this stage since it was selected
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
 StageProf g_prof[] = {{"preprocess_fwd"}, {"scan_blocks"}, {"count_rank"}, {"scan_tiles"}, {"emit_instances"}, {"sort_tiles"},
@@ -54,6 +56,7 @@ StageProf g_prof[] = {{"preprocess_fwd"}, {"scan_blocks"}, {"count_rank"}, {"sca
 enum { ST_PRE_FWD, ST_SCAN_BLOCKS, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD, ST_ZERO, ST_RENDER_BWD, ST_PRE_BWD,
        ST_COUNT };
 std::mutex g_prof_mu;
+std::atomic<int> g_profile_every{1};
 
 // dgr_set_option("tight_cull", 1): alpha-aware tile rectangles (preprocess.hip); process-wide, default off
 std::atomic<int> g_tight_cull{0};
@@ -67,6 +70,9 @@ struct ScopedStage {
     bool kernel_stage;
     ScopedStage(int id, hipStream_t s, bool is_kernel = true) : st(s), kernel_stage(is_kernel) {
         if (!g_prof[id].on) return;
+        // dgr_set_option("profile_every", n): bracket every n-th launch only (the events ride in the dispatch packet
+        // and cost a little overlap between streams; a sample keeps the timed region undisturbed)
+        if (g_prof[id].seen++ % (unsigned)std::max(1, g_profile_every.load()) != 0) return;
         p = &g_prof[id];
         if (hipEventCreate(&le.start) != hipSuccess || hipEventCreate(&le.stop) != hipSuccess) { p = nullptr; return; }
         le.used = false;
@@ -521,12 +527,14 @@ int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* g
 int dgr_set_option(const char* name, int value) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }
+    if (n == "profile_every") { g_profile_every.store(value > 0 ? value : 1); return DGR_OK; }
     g_last_error = "unknown option: " + n;
     return DGR_ERR_BAD_ARGUMENT;
 }
 int dgr_get_option(const char* name) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") return g_tight_cull.load();
+    if (n == "profile_every") return g_profile_every.load();
     return DGR_ERR_BAD_ARGUMENT;
 }
 
@@ -535,6 +543,7 @@ int dgr_profile_select(const char* stage) {
     const std::string n(stage ? stage : "");
     bool found = n.empty() || n == "all";
     for (auto& p : g_prof) {
+        p.seen = 0;
         p.on = (n == "all") || (n == p.name);
         found = found || p.on;
     }

@@ -173,7 +173,8 @@ int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* g
  *  "tight_cull": 1 = alpha-aware tile rectangles.  The reference gives a Gaussian every tile its
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle
  *     is cut down to the box where alpha can reach 15/255.  Images and gradients are unchanged, but num_rendered, the
- *     tile lists and n_contrib are NOT the reference's any more -- hence opt-in. */
+ *     tile lists and n_contrib are NOT the reference's any more -- hence opt-in.
+ *  "profile_every": n >= 1 = dgr_profile_* brackets every n-th launch of the selected stage only (default 1). */
 int dgr_set_option(const char* name, int value);
 int dgr_get_option(const char* name);
 
