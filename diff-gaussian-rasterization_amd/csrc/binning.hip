@@ -28,7 +28,8 @@ namespace {
 constexpr int SCAN_THREADS = 1024;
 constexpr int SORT_THREADS = 256;
 constexpr int COUNT_STAGE = 4096;   // ranks staged per 256-Gaussian block in count_rank (16 KB)
-constexpr int SORT_LDS_MAX = 4096;  // keys per tile sorted in LDS (32 KB); larger tiles sort in global memory
+constexpr int SORT_LDS_MAX = 2048;  // keys per tile sorted in LDS (16 KB: 8 workgroups per CU; with 4096 keys = 32 KB only
+                                    // 5 fit and the latency-bound sort took 37 us instead of 30); larger tiles sort in global memory
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img, int tiles, int grid_x, int capacity) {
     const int pairs_x = (grid_x + 1) >> 1;
