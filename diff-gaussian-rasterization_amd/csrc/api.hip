@@ -43,6 +43,29 @@ int hip_fail(hipError_t e, const char* what) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- early status (dgr_early_status_arm / _wait): num_rendered and the prefiltered flag are final after scan_blocks,
+// a tenth of the way into the forward; a caller that needs them on the host (the reference's blocking copy of
+// num_rendered) waits for a copy issued at that point instead of for the whole forward.
+struct EarlyStatus {
+    bool armed = false, pending = false;
+    hipEvent_t ev = nullptr;
+    int* pinned = nullptr;
+};
+thread_local EarlyStatus g_early;
+
+int early_status_post(const int* device_status, hipStream_t st) {
+    if (!g_early.armed) return DGR_OK;
+    g_early.armed = false;
+    if (!g_early.ev) {
+        HIP_TRY(hipEventCreateWithFlags(&g_early.ev, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void**)&g_early.pinned, 4 * sizeof(int), hipHostMallocDefault));
+    }
+    HIP_TRY(hipMemcpyAsync(g_early.pinned, device_status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(g_early.ev, st));
+    g_early.pending = true;
+    return DGR_OK;
+}
+
 // ---- optional per-stage timing with HIP events on the launching stream (dgr_profile_* in dgr_hip.h).
 // Disabled by default; when a stage is selected, two events bracket that stage's launch only.
 struct StageProf {
@@ -284,6 +307,7 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
     if ((rc = forward_front(c, geom, img, st))) return rc;
+    if ((rc = early_status_post(img.status, st))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
     if ((rc = forward_back(c, geom, img, bin, st))) return rc;
     return DGR_OK;
@@ -406,6 +430,7 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
     if ((rc = forward_front(c, geom, img, st))) return rc;
+    if ((rc = early_status_post(img.status, st))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
     return DGR_OK;
@@ -521,6 +546,24 @@ int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* g
     }
     HIP_TRY(dgr::launch_sparse_adam((size_t)rows, k, param, grad, exp_avg, exp_avg_sq, visible, lr, beta1, beta2, eps, step,
                                     (hipStream_t)stream));
+    return DGR_OK;
+}
+
+int dgr_early_status_arm(void) {
+    g_early.armed = true;
+    g_early.pending = false;
+    return DGR_OK;
+}
+int dgr_early_status_wait(int* host_status4) {
+    if (!host_status4) { g_last_error = "dgr_early_status_wait: NULL"; return DGR_ERR_BAD_ARGUMENT; }
+    if (!g_early.pending) {  // nothing was posted (P == 0, or no presized forward since arming)
+        g_early.armed = false;
+        host_status4[0] = host_status4[1] = host_status4[2] = host_status4[3] = 0;
+        return 1;
+    }
+    HIP_TRY(hipEventSynchronize(g_early.ev));
+    for (int i = 0; i < 4; i++) host_status4[i] = g_early.pinned[i];
+    g_early.pending = false;
     return DGR_OK;
 }
 

@@ -27,6 +27,8 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # argument lists follow include/dgr_hip.h one to one
 _SIGS = {
     "dgr_last_error": (C.c_char_p, []),
+    "dgr_early_status_arm": (_i, []),
+    "dgr_early_status_wait": (_i, [_vp]),
     "dgr_sparse_adam": (_i, [_vp, C.c_long, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i]),
     "dgr_set_option": (_i, [C.c_char_p, _i]),
     "dgr_get_option": (_i, [C.c_char_p]),

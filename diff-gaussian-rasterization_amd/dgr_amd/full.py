@@ -93,15 +93,20 @@ class _C:
             cap = int(cap * 1.25) + 4096 if cap else 4 * P + 4096
             while True:
                 binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)
+                lib.dgr_early_status_arm()
                 _check(lib.dgr_full_forward_presized(st, p(geomBuffer), p(binningBuffer), cap, p(imgBuffer), p(status),
                                                      *common))
-                s = status.tolist()  # one host read: num_rendered, overflow, prefiltered flag, num_related
+                s = _light._early_status(lib)  # waits until num_rendered is known, not for the whole forward
                 if s[2]:
                     raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
-                rendered, related = s[0], s[3]
+                rendered = s[0]
                 _capacity_cache[key] = max(_capacity_cache.get(key, 0), rendered)
-                _light._last_status[key] = s
-                if not s[1]:
+                if rendered <= cap:
+                    # num_related (the reference's NG) is produced by the forward blend: the second blocking read of
+                    # the reference (F/cuda_rasterizer/rasterizer_impl.cu:498); lazy mode reports it one call late instead
+                    s = status.tolist()
+                    related = s[3]
+                    _light._last_status[key] = s
                     break
                 cap = int(rendered * 1.1) + 4096
         return rendered, related, out_color, out_depth, out_unc, radii, geomBuffer, binningBuffer, imgBuffer

@@ -127,6 +127,15 @@ def _grad_arena(P, M, f32):
     return {name: arena[a:a + n].view(shp) for name, (a, n, shp) in offs.items()}
 
 
+_early_buf = (C.c_int * 4)()
+
+
+def _early_status(lib):
+    """{num_rendered, -, prefiltered violation, -} of the presized forward just issued (include/dgr_hip.h: early status)."""
+    _check(lib.dgr_early_status_wait(_early_buf))
+    return list(_early_buf)
+
+
 def _check(rc):
     if rc >= 0:
         return rc
@@ -220,14 +229,15 @@ class _C:
             cap = int(cap * 1.25) + 4096 if cap else 4 * P + 4096
             while True:
                 binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)
+                lib.dgr_early_status_arm()
                 _check(lib.dgr_light_forward_presized(st, p(geomBuffer), p(binningBuffer), cap, p(imgBuffer),
                                                       p(status), *common))
-                s = status.tolist()  # the one host read of this forward (also what returns num_rendered)
-                if s[2]:
+                s = _early_status(lib)  # the one host wait of this forward: until num_rendered is known, a tenth of the
+                if s[2]:                # way into the forward -- not until the forward has finished
                     raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
                 rendered = s[0]
                 _capacity_cache[key] = max(_capacity_cache.get(key, 0), rendered)
-                if not s[1]:
+                if rendered <= cap:
                     break
                 cap = int(rendered * 1.1) + 4096  # overflow: every tile list was left empty; run again
             if debug:

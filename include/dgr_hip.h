@@ -162,6 +162,15 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
                       int binning_capacity, const char* geom_buffer, const char* binning_buffer,
                       const char* image_buffer, void* dst_device);
 
+/* Early status.  The reference blocks the host once per forward to read num_rendered (L/cr/rasterizer_impl.cu:287).  That
+ * number and the prefiltered-violation flag are final after the per-block scan, about a tenth of the way into the forward:
+ * dgr_early_status_arm() makes the NEXT *_forward_presized call of this thread copy the status word to pinned host memory
+ * at that point, and dgr_early_status_wait() blocks until that copy -- not the rest of the forward -- has completed and
+ * returns {num_rendered, 0, prefiltered violation, 0} (the overflow flag is the caller's own num_rendered > capacity).
+ * Returns 1 when nothing was posted (P == 0). */
+int dgr_early_status_arm(void);
+int dgr_early_status_wait(int* host_status4);
+
 /* Fused sparse Adam step on one per-Gaussian tensor [rows, k] (the reference leaves the optimiser
  * to torch).  torch.optim.Adam's update (no weight decay, no amsgrad) with bias correction for the 1-based `step`;
  * rows with visible[row] <= 0 are skipped -- parameter and both moments untouched, as in 3DGS's sparse Adam -- and
