@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import pytest
+
 from dgr_amd import _capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,3 +39,25 @@ def test_state_sizes_scale_as_documented():
     assert 93 * 1000 <= g1 <= 93 * 1000 + 9 * 256 and g2 > g1
     assert lib.dgr_binning_bytes(1000, 64, 64) >= 12 * 1000
     assert lib.dgr_light_backward_scratch_bytes(1000, 64, 64) >= 64 * 1000
+
+
+def test_options_round_trip_and_reject_unknown_names():
+    lib = _capi.load()
+    assert lib.dgr_get_option(b"tight_cull") == 0
+    assert lib.dgr_set_option(b"tight_cull", 1) == 0 and lib.dgr_get_option(b"tight_cull") == 1
+    assert lib.dgr_set_option(b"tight_cull", 0) == 0
+    assert lib.dgr_set_option(b"profile_every", 8) == 0 and lib.dgr_get_option(b"profile_every") == 8
+    assert lib.dgr_set_option(b"profile_every", 1) == 0
+    assert lib.dgr_set_option(b"no_such_option", 1) == _capi.DGR_ERR_BAD_ARGUMENT
+    assert b"no_such_option" in lib.dgr_last_error()
+    with pytest.raises(ValueError):
+        _capi.set_option("no_such_option", 1)
+    assert lib.dgr_profile_select(b"no_such_stage") == _capi.DGR_ERR_BAD_ARGUMENT
+
+
+def test_early_status_without_a_forward_reports_nothing_posted():
+    import ctypes
+    lib = _capi.load()
+    buf = (ctypes.c_int * 4)(7, 7, 7, 7)
+    assert lib.dgr_early_status_arm() == 0
+    assert lib.dgr_early_status_wait(buf) == 1 and list(buf) == [0, 0, 0, 0]
