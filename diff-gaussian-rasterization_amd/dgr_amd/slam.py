@@ -120,3 +120,27 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         res = {"render": color, "depth": depth, "opacity_map": uncertainty}
     res.update(viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii)
     return res
+
+
+def render_batch(cameras, pc, pipe, bg_color, loss_fn, views_in_flight=3, **render_kwargs):
+    """One mapping step over a batch of keyframes: every camera is rendered, `loss_fn(out, k)`
+    is evaluated on its output dict and back-propagated, each view's forward + loss + backward on its own HIP stream
+    (`dgr_amd.multiview.ViewStreams`) so that the views overlap on the GPU; gradients accumulate in the `.grad` of the
+    Gaussian parameters as usual.  `cameras`: sequence of dicts with `viewmatrix` (W2C^T), `fov`, `HW` and optionally
+    `gt_depth`, `viewpoint_camera`.  Returns the list of detached loss values (device tensors); the caller's stream is
+    ordered after all views on return."""
+    from .multiview import ViewStreams
+    cameras = list(cameras)
+    if not cameras:
+        return []
+    views = ViewStreams(min(max(1, views_in_flight), len(cameras)), cameras[0]["viewmatrix"].device)
+    losses = []
+    for k, cam in enumerate(cameras):
+        with views.next():
+            out = render(cam.get("viewpoint_camera"), pc, pipe, bg_color, viewmatrix=cam["viewmatrix"], fov=cam["fov"],
+                         HW=cam["HW"], gt_depth=cam.get("gt_depth"), **render_kwargs)
+            loss = loss_fn(out, k)
+            loss.backward()
+            losses.append(loss.detach())
+    views.join()
+    return losses

@@ -85,3 +85,45 @@ def test_tracking_recovers_a_perturbed_pose(variant):
     e1 = errors()
     assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
     assert e1[0] < 0.3 * e0[0] and e1[1] < 0.3 * e0[1], (e0, e1)
+
+
+@pytest.mark.gpu
+def test_render_batch_accumulates_like_a_serial_loop():
+    """slam.render_batch: four keyframes on three streams give the gradient sum of rendering them one after the other."""
+    dev = torch.device("cuda:0")
+    W, H = 160, 120
+    scenes = [make_scene(6000, W, H, 3, view_index=k) for k in range(4)]
+    s = scenes[0]
+    bg = torch.from_numpy(s.bg).to(dev)
+    gt = torch.from_numpy(s.gt).to(dev)
+    targets = [torch.rand((3, H, W), device=dev) for _ in scenes]
+
+    def model():
+        m = Model(s, dev)
+        for name in ("get_xyz", "get_opacity", "get_scaling", "get_rotation", "get_features"):
+            setattr(m, name, getattr(m, name).clone().requires_grad_())
+        return m
+
+    def cams():
+        return [dict(viewmatrix=torch.from_numpy(sc.view).to(dev), fov=(sc.tanfovx, sc.tanfovy), HW=(H, W), gt_depth=gt)
+                for sc in scenes]
+
+    def loss_fn(out, k):
+        return (out["render"] - targets[k]).abs().mean() + 0.1 * out["depth"].mean()
+
+    a = model()
+    la = slam.render_batch(cams(), a, None, bg, loss_fn, views_in_flight=3)
+    b = model()
+    lb = []
+    for k, cam in enumerate(cams()):
+        out = slam.render(None, b, None, bg, viewmatrix=cam["viewmatrix"], fov=cam["fov"], HW=cam["HW"], gt_depth=gt)
+        loss = loss_fn(out, k)
+        loss.backward()
+        lb.append(loss.detach())
+    torch.cuda.synchronize()
+    for x, y in zip(la, lb):
+        assert abs(float(x) - float(y)) <= 1e-6 * abs(float(y))
+    for name in ("get_xyz", "get_opacity", "get_scaling", "get_rotation", "get_features"):
+        ga, gb = getattr(a, name).grad.cpu().numpy(), getattr(b, name).grad.cpu().numpy()
+        scale = np.abs(gb).max()
+        assert np.abs(ga - gb).max() <= 2e-5 * scale, name
