@@ -376,3 +376,41 @@ def test_results_do_not_depend_on_stale_memory(variant):
         for a, b in zip(grads, results[0][1]):
             assert np.isfinite(a).all()
             assert_grad_close(a, b, "stale memory", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
+
+
+def test_inputs_are_converted_like_the_reference_binding():
+    """The reference's binding calls .contiguous() on every input (L/rasterize_points.cu:101-125) and CG-SLAM may hand it
+    double tensors or views: float64, non-contiguous and fp32-contiguous inputs must render the same frame."""
+    from dgr_amd import light as D
+    from dgr_amd.multiview import make_settings
+    dev = hh.dev()
+    s = make_scene(3000, 96, 64, 13)
+    rast = D.GaussianRasterizer(make_settings(s, 3, dev))
+    gt = hh.T(s.gt)
+
+    def run(conv):
+        ts = [conv(hh.T(a)) for a in (s.means, s.shs, s.opac, s.scales, s.rots, s.view)]
+        for t in ts:
+            t.requires_grad_()
+        means3D, shs, opac, scales, rots, view = ts
+        means2D = torch.zeros((s.P, 3), device=dev, requires_grad=True)
+        outs = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots,
+                    viewmatrix=view, gt_depth=gt)
+        torch.autograd.backward([outs[0], outs[2]], [hh.T(s.gC), hh.T(s.gD[None])])
+        torch.cuda.synchronize()
+        return outs[0].detach().cpu().numpy(), [t.grad.float().cpu().numpy() for t in ts]
+
+    def strided(t):  # same values, memory with a gap after every row / element
+        if t.dim() == 1:
+            return torch.stack([t, t], 1)[:, 0]
+        big = torch.zeros(t.shape[:-1] + (t.shape[-1] + 1,), device=t.device, dtype=t.dtype)
+        big[..., :-1] = t
+        return big[..., :-1]
+
+    base_c, base_g = run(lambda t: t.clone())
+    for conv in (lambda t: t.double(), strided):
+        c, g = run(conv)
+        assert np.array_equal(c, base_c)
+        for a, b in zip(g, base_g):
+            assert a.shape == b.shape
+            assert_grad_close(a, b, "converted input", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)

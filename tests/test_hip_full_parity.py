@@ -75,3 +75,26 @@ def test_full_autograd_surface():
     torch.autograd.backward([color, depth, unc], [hh.T(s.gC), hh.T(s.gD[None]), hh.T(s.gV[None])])
     assert view.grad.shape == (4, 4) and means2D.grad.shape == (s.P, 3) and shs.grad.shape == (s.P, 16, 3)
     assert float(view.grad.abs().sum()) > 0 and float(means3D.grad.abs().sum()) > 0
+
+
+def test_full_precomputed_colors_and_covariances(oracle):
+    """colors_precomp skips SH (dL_dcolors is then returned and the colour -> campos part of the pose gradient vanishes);
+    cov3D_precomp skips scale/rotation (F/cuda_rasterizer/rasterizer_impl.cu)."""
+    s = make_scene(4000, 96, 80, 3)
+    st0, ref0, _ = hh.oracle_full(oracle, s, 3, backward=False)
+    colors = st0.get("rgb").reshape(-1, 3).copy()
+    cov3D = st0.get("cov3D").reshape(-1, 6).copy()
+    grads = tuple(g * (s.W * s.H) ** 0.5 for g in (s.gC, s.gD, s.gV))
+    for kw in (dict(colors_precomp=colors), dict(cov3D_precomp=cov3D), dict(colors_precomp=colors, cov3D_precomp=cov3D)):
+        out, d = hh.hip_full_forward(s, 3, **kw)
+        st, ref, gr = hh.oracle_full(oracle, s, 3, grads=grads, **kw)
+        assert np.array_equal(d["radii"], ref["radii"])
+        assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+        for k in ("color", "depth", "uncertainty"):
+            assert_image_close(d[k], ref[k], k)
+        g = hh.hip_full_backward(s, 3, out, grads=grads, **kw)
+        names = ["dL_dmeans3D", "dL_dopacity", "dL_dview"]
+        names += ["dL_dcolors"] if "colors_precomp" in kw else ["dL_dsh"]
+        names += ["dL_dcov3D"] if "cov3D_precomp" in kw else ["dL_dscales", "dL_drotations"]
+        for k in names:
+            assert_grad_close(g[k], gr[k], k, rel_to_max=1e-4 if k == "dL_dview" else 2e-5, elem_rtol=2e-3, elem_frac=0.1 if k == "dL_dview" else 2e-3)
