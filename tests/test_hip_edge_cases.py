@@ -414,3 +414,30 @@ def test_inputs_are_converted_like_the_reference_binding():
         for a, b in zip(g, base_g):
             assert a.shape == b.shape
             assert_grad_close(a, b, "converted input", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
+
+
+def test_debug_mode_dumps_a_snapshot_on_failure(tmp_path, monkeypatch):
+    """`debug=True` (L/diff_gaussian_rasterization/__init__.py:75-84): a failing forward leaves snapshot_fw.dump with the
+    CPU copies of its arguments, and a passing one synchronises and leaves nothing."""
+    from dgr_amd import light as D
+    from dgr_amd.multiview import make_settings
+    monkeypatch.chdir(tmp_path)
+    dev = hh.dev()
+    s = make_scene(500, 64, 48, 2)
+    far = s.means.copy()
+    far[:, 2] = -50.0  # behind the camera: culled
+    bad = s._replace(means=np.concatenate([s.means[:-5], far[-5:]]).astype(np.float32))
+
+    def call(scene, prefiltered):
+        rast = D.GaussianRasterizer(make_settings(scene, 3, dev, debug=True, prefiltered=prefiltered))
+        return rast(means3D=hh.T(scene.means), means2D=torch.zeros((scene.P, 3), device=dev), opacities=hh.T(scene.opac),
+                    shs=hh.T(scene.shs), scales=hh.T(scene.scales), rotations=hh.T(scene.rots), viewmatrix=hh.T(scene.view),
+                    gt_depth=hh.T(scene.gt))
+
+    call(s, False)
+    assert not (tmp_path / "snapshot_fw.dump").exists()
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        call(bad, True)
+    dump = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)
+    assert isinstance(dump, (tuple, list)) and len(dump) == 20  # the 20 arguments of rasterize_gaussians
+    assert all(not (isinstance(t, torch.Tensor) and t.is_cuda) for t in dump)
