@@ -4,13 +4,17 @@
 One "step" = one view: GaussianRasterizer.forward + backward through the reference-shaped autograd
 surface (light variant, SH degree 3, all four pixel-gradient images non-zero, track_off = map_off =
 False) on the synth-v1 scene of BASELINE config 3, inputs resident in HBM before the timed region.
+By default three independent views are in flight on three HIP streams (--views-in-flight; every view is
+a complete forward + backward with its own state) and the forward checks its status word lazily
+(--sync-mode); `config.ms_per_view_one_stream` is the strictly serial figure.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, rank r renders view r of the same Gaussians (weak scaling) and the
-per-Gaussian gradients are all-reduced (RCCL, one fused buffer) inside the timed region, as a mapping
-step over N views needs; pose gradients stay per view.  value = views of all ranks / max-over-ranks time.
+per-Gaussian gradients are all-reduced (RCCL, one fused buffer per group of --views-per-allreduce local
+views) inside the timed region, as a mapping step over a keyframe batch needs; pose gradients stay per
+view.  value = views of all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line; `roofline` describes the dominant kernel, `cpu_baseline` the CPU oracle
 timed on this host (oracle/ is used here only as the reported baseline, never inside the timed path).
