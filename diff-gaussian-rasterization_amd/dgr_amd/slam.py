@@ -19,14 +19,23 @@ from . import full as _full
 from . import light as _light
 
 
+_proj_cache = {}
+
+
 def projection_matrix(tanfovx, tanfovy, znear=0.01, zfar=100.0, device=None, dtype=torch.float32):
-    """Proj (row-major math, z forward, as 3DGS `getProjectionMatrix` with symmetric frustum)."""
-    P = torch.zeros((4, 4), dtype=dtype, device=device)
-    P[0, 0] = 1.0 / tanfovx
-    P[1, 1] = 1.0 / tanfovy
-    P[2, 2] = zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
-    P[3, 2] = 1.0
+    """Proj (row-major math, z forward, as 3DGS `getProjectionMatrix` with symmetric frustum).  Cached per argument set
+    (treat the result as read-only): building it copies host scalars to the device, which a hipGraph capture forbids,
+    so a captured step finds the matrix its eager warm-up made."""
+    key = (float(tanfovx), float(tanfovy), float(znear), float(zfar), str(device), dtype)
+    P = _proj_cache.get(key)
+    if P is None:
+        P = torch.zeros((4, 4), dtype=dtype)
+        P[0, 0] = 1.0 / tanfovx
+        P[1, 1] = 1.0 / tanfovy
+        P[2, 2] = zfar / (zfar - znear)
+        P[2, 3] = -(zfar * znear) / (zfar - znear)
+        P[3, 2] = 1.0
+        P = _proj_cache[key] = P.to(device) if device is not None else P
     return P
 
 
@@ -44,7 +53,9 @@ def quat_to_rotmat(q):
 def w2c_from_quat_trans(q, t):
     """World-to-camera 4x4 from a quaternion and a translation (both differentiable leaves of a tracking step)."""
     top = torch.cat([quat_to_rotmat(q), t.reshape(3, 1)], dim=1)
-    bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=top.dtype, device=top.device)
+    # (built on the device: a host-to-device copy would not be capturable into a hipGraph)
+    bottom = torch.cat([torch.zeros((1, 3), dtype=top.dtype, device=top.device),
+                        torch.ones((1, 1), dtype=top.dtype, device=top.device)], dim=1)
     return torch.cat([top, bottom], dim=0)
 
 

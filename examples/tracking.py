@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Camera tracking against a fixed Gaussian map (CG-SLAM's tracking loop in miniature).
+
+A synthetic map is rendered from the true pose to get the "observed" frame; the pose estimate starts perturbed and is
+refined by Adam on (quaternion, translation) through the rasterizer's analytic viewmatrix gradient (tracking mode:
+map_off=True, no Gaussian gradients).  With --graph the whole iteration -- pose -> matrices -> render -> loss -> backward ->
+Adam step -- is recorded once into a hipGraph and replayed (dgr_amd.multiview.CapturedStep), which removes the host
+from the loop.
+
+  python examples/tracking.py [--graph] [--iters 150] [--width 640 --height 480 --gaussians 100000]
+"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-gaussian-rasterization_amd"), os.path.join(ROOT, "tests")]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--iters", type=int, default=150)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--gaussians", type=int, default=100000)
+    args = ap.parse_args()
+    if args.graph:
+        os.environ["DGR_SYNC_MODE"] = "lazy"  # a blocking status read cannot be captured
+    from dgr_amd import slam
+    from dgr_amd.multiview import CapturedStep
+    from dgr_amd.synth import camera, make_scene
+    from test_slam_render import Model, rot_to_quat
+
+    dev = torch.device("cuda:0")
+    W, H = args.width, args.height
+    s = make_scene(args.gaussians, W, H, 3)
+    pc = Model(s, dev)
+    tanfovx, tanfovy, Rm, t_true, *_ = camera(W, H, 0.05)
+    bg, gt_depth = torch.from_numpy(s.bg).to(dev), torch.from_numpy(s.gt).to(dev)
+    kw = dict(fov=(tanfovx, tanfovy), HW=(H, W), gt_depth=gt_depth, track_off=False, map_off=True)
+
+    def pose(q, t):
+        return slam.camera_tensors(slam.w2c_from_quat_trans(q, t), tanfovx, tanfovy)[0]
+
+    q_true = torch.tensor(rot_to_quat(Rm), dtype=torch.float32, device=dev)
+    t_true = torch.tensor(t_true, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        obs = slam.render(None, pc, None, bg, viewmatrix=pose(q_true, t_true), **kw)
+    obs_c, obs_d = obs["render"].detach(), obs["depth"].detach()
+
+    q = (q_true + torch.tensor([0.0, 0.004, -0.006, 0.003], device=dev)).requires_grad_()
+    t = (t_true + torch.tensor([0.012, -0.009, 0.015], device=dev)).requires_grad_()
+    opt = torch.optim.Adam([{"params": [q], "lr": 5e-4}, {"params": [t], "lr": 1.5e-3}], capturable=args.graph)
+
+    def iteration():
+        opt.zero_grad(set_to_none=True)
+        out = slam.render(None, pc, None, bg, viewmatrix=pose(q, t), **kw)
+        loss = (out["render"] - obs_c).abs().mean() + 0.5 * (out["depth"] - obs_d).abs().mean()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    def err():
+        with torch.no_grad():
+            return float((q / q.norm() - q_true).norm()), float((t - t_true).norm())
+
+    print(f"start : rotation error {err()[0]:.2e}, translation error {err()[1]:.2e}")
+    if args.graph:
+        step = CapturedStep(iteration, warmup=3)  # (three eager iterations first)
+        run = step.replay
+    else:
+        run = iteration
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.iters):
+        loss = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if args.graph:
+        step.check()
+    print(f"finish: rotation error {err()[0]:.2e}, translation error {err()[1]:.2e}, loss {float(loss):.3e}")
+    print(f"{args.iters} iterations in {dt * 1e3:.1f} ms = {dt / args.iters * 1e3:.3f} ms per tracking iteration"
+          f" ({'hipGraph replay' if args.graph else 'eager'})")
+
+
+if __name__ == "__main__":
+    main()

@@ -127,3 +127,52 @@ def test_render_batch_accumulates_like_a_serial_loop():
         ga, gb = getattr(a, name).grad.cpu().numpy(), getattr(b, name).grad.cpu().numpy()
         scale = np.abs(gb).max()
         assert np.abs(ga - gb).max() <= 2e-5 * scale, name
+
+
+@pytest.mark.gpu
+def test_tracking_iteration_replayed_from_a_hipgraph(monkeypatch):
+    """The whole tracking iteration -- pose -> camera matrices -> render -> loss -> backward -> Adam step -- recorded once
+    (dgr_amd.multiview.CapturedStep) and replayed: the pose converges as in the eager loop (examples/tracking.py)."""
+    monkeypatch.setenv("DGR_SYNC_MODE", "lazy")
+    from dgr_amd.multiview import CapturedStep
+    dev = torch.device("cuda:0")
+    W, H = 256, 192
+    s = make_scene(20000, W, H, 3)
+    pc = Model(s, dev)
+    tanfovx, tanfovy, Rm, t_true, *_ = camera(W, H, 0.05)
+    bg, gt_depth = torch.from_numpy(s.bg).to(dev), torch.from_numpy(s.gt).to(dev)
+    kw = dict(fov=(tanfovx, tanfovy), HW=(H, W), gt_depth=gt_depth, track_off=False, map_off=True)
+
+    def pose(q, t):
+        return slam.camera_tensors(slam.w2c_from_quat_trans(q, t), tanfovx, tanfovy)[0]
+
+    q_true = torch.tensor(rot_to_quat(Rm), dtype=torch.float32, device=dev)
+    t_true = torch.tensor(t_true, dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        obs = slam.render(None, pc, None, bg, viewmatrix=pose(q_true, t_true), **kw)
+    obs_c, obs_d = obs["render"].detach(), obs["depth"].detach()
+    q = (q_true + torch.tensor([0.0, 0.004, -0.006, 0.003], device=dev)).requires_grad_()
+    t = (t_true + torch.tensor([0.012, -0.009, 0.015], device=dev)).requires_grad_()
+    opt = torch.optim.Adam([{"params": [q], "lr": 5e-4}, {"params": [t], "lr": 1.5e-3}], capturable=True)
+
+    def iteration():
+        opt.zero_grad(set_to_none=True)
+        out = slam.render(None, pc, None, bg, viewmatrix=pose(q, t), **kw)
+        loss = (out["render"] - obs_c).abs().mean() + 0.5 * (out["depth"] - obs_d).abs().mean()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    def errors():
+        with torch.no_grad():
+            return float((q / q.norm() - q_true).norm()), float((t - t_true).norm())
+
+    e0 = errors()
+    step = CapturedStep(iteration, warmup=3)
+    first = float(step.replay())
+    for _ in range(150):
+        last = step.replay()
+    step.check()
+    e1 = errors()
+    assert float(last) < 0.3 * first
+    assert e1[0] < 0.3 * e0[0] and e1[1] < 0.3 * e0[1], (e0, e1)
