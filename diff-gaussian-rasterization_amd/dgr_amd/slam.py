@@ -59,6 +59,12 @@ def w2c_from_quat_trans(q, t):
     return torch.cat([top, bottom], dim=0)
 
 
+def _small_matmul(a, b):
+    """a @ b for 3x3 / 4x4 operands as one broadcast multiply and one sum: a BLAS call for sixteen numbers costs more
+    host time on ROCm (≈1.5 ms: handle and heuristics) than the whole render."""
+    return (a.unsqueeze(-1) * b.unsqueeze(-3)).sum(-2)
+
+
 def camera_tensors(w2c, tanfovx, tanfovy, znear=0.01, zfar=100.0):
     """(viewmatrix, projmatrix, perspec_matrix, campos) for the rasterizer from a world-to-camera matrix.
     `viewmatrix` stays attached to `w2c`'s graph; the other three are detached (see the module docstring)."""
@@ -66,8 +72,8 @@ def camera_tensors(w2c, tanfovx, tanfovy, znear=0.01, zfar=100.0):
     viewmatrix = w2c.transpose(0, 1).contiguous()
     with torch.no_grad():
         perspec = P.transpose(0, 1).contiguous()
-        projmatrix = (w2c.transpose(0, 1) @ P.transpose(0, 1)).contiguous()
-        campos = (-(w2c[:3, :3].transpose(0, 1) @ w2c[:3, 3])).contiguous()
+        projmatrix = _small_matmul(w2c.transpose(0, 1), P.transpose(0, 1)).contiguous()
+        campos = (-(w2c[:3, :3] * w2c[:3, 3:4]).sum(0)).contiguous()  # -(R^T t)
     return viewmatrix, projmatrix, perspec, campos
 
 
@@ -101,9 +107,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
             perspec = projection_matrix(tanfovx, tanfovy, znear, zfar, device=dev).transpose(0, 1).contiguous()
         perspec = perspec.to(dev, torch.float32)
         vm = viewmatrix.detach()
-        projmatrix = (vm @ perspec).contiguous()
+        projmatrix = _small_matmul(vm, perspec).contiguous()
         w2c = vm.transpose(0, 1)
-        campos = (-(w2c[:3, :3].transpose(0, 1) @ w2c[:3, 3])).contiguous()
+        campos = (-(w2c[:3, :3] * w2c[:3, 3:4]).sum(0)).contiguous()  # -(R^T t)
 
     means3D = pc.get_xyz
     # 3DGS keeps a zero tensor whose .grad receives the screen-space gradient (densification statistics)
