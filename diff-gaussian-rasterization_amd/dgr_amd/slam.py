@@ -39,24 +39,36 @@ def projection_matrix(tanfovx, tanfovy, znear=0.01, zfar=100.0, device=None, dty
     return P
 
 
+_const_cache = {}
+
+
+def _constants(device, dtype):
+    """(identity, Levi-Civita tensor, bottom row) on `device`, built once (host -> device copies are not capturable)."""
+    key = (str(device), dtype)
+    c = _const_cache.get(key)
+    if c is None:
+        eps = torch.zeros((3, 3, 3), dtype=dtype)
+        for i, j, k in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
+            eps[i, j, k], eps[i, k, j] = 1.0, -1.0
+        c = _const_cache[key] = (torch.eye(3, dtype=dtype).to(device), eps.to(device),
+                                 torch.tensor([[0.0, 0.0, 0.0, 1.0]], dtype=dtype).to(device))
+    return c
+
+
 def quat_to_rotmat(q):
-    """Unit quaternion (r, x, y, z) -> 3x3 rotation, differentiable (q is normalised here)."""
+    """Unit quaternion (r, x, y, z) -> 3x3 rotation, differentiable (q is normalised here).
+    R = (r^2 - |v|^2) I + 2 v v^T + 2 r [v]x in a dozen tensor operations (a tracking loop is launch-bound)."""
+    eye, eps, _ = _constants(q.device, q.dtype)
     q = q / q.norm()
-    r, x, y, z = q[0], q[1], q[2], q[3]
-    return torch.stack([
-        torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)]),
-        torch.stack([2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)]),
-        torch.stack([2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]),
-    ])
+    r, v = q[0], q[1:]
+    cross = -(eps * v).sum(-1)  # [v]x: cross[i][j] = -eps[i][j][k] v[k]
+    return (r * r - (v * v).sum()) * eye + 2.0 * v.unsqueeze(1) * v.unsqueeze(0) + (2.0 * r) * cross
 
 
 def w2c_from_quat_trans(q, t):
     """World-to-camera 4x4 from a quaternion and a translation (both differentiable leaves of a tracking step)."""
     top = torch.cat([quat_to_rotmat(q), t.reshape(3, 1)], dim=1)
-    # (built on the device: a host-to-device copy would not be capturable into a hipGraph)
-    bottom = torch.cat([torch.zeros((1, 3), dtype=top.dtype, device=top.device),
-                        torch.ones((1, 1), dtype=top.dtype, device=top.device)], dim=1)
-    return torch.cat([top, bottom], dim=0)
+    return torch.cat([top, _constants(q.device, q.dtype)[2]], dim=0)
 
 
 def _small_matmul(a, b):

@@ -31,3 +31,23 @@ for it in range(60):
     opt.step(); t0 = tick("adam", t0)
 for k, v in T.items():
     print(f"{k:16s} {v / 50 * 1e3:7.3f} ms")
+
+# kernel stages of the rasterizer inside one tracking iteration (tracking mode: map_off)
+from dgr_amd import _capi
+_capi.set_option("profile_every", 1)
+_capi.profile_select("all")
+for it in range(20):
+    opt.zero_grad(set_to_none=True)
+    vm = slam.camera_tensors(slam.w2c_from_quat_trans(q, t), tanfovx, tanfovy)[0]
+    out = slam.render(None, pc, None, bg, viewmatrix=vm, **kw)
+    loss = (out["render"] - obs_c).abs().mean() + 0.5 * (out["depth"] - obs_d).abs().mean()
+    loss.backward()
+torch.cuda.synchronize()
+tot = 0.0
+for name in _capi.profile_stages():
+    ms, n = _capi.profile_read(name)
+    if n:
+        print(f"  stage {name:16s} {1e3 * ms / n:7.1f} us")
+        tot += ms / n
+print(f"  rasterizer kernels per iteration: {1e3 * tot:.1f} us")
+_capi.profile_select("")
