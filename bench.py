@@ -83,6 +83,9 @@ def main():
                     help="independent views (forward+backward each) issued round-robin on this many HIP streams: the "
                          "atomic- and latency-bound binning kernels of one view run under the VALU-bound blend kernels "
                          "of another; 1 = strictly one view at a time")
+    ap.add_argument("--graph", action="store_true",
+                    help="N=1: record one view per stream into a hipGraph (dgr_amd.multiview.CapturedStep) and replay the "
+                         "graphs round-robin instead of issuing the views from Python; pays for host-bound sizes (config 2)")
     ap.add_argument("--tight-cull", action="store_true",
                     help="opt-in alpha-aware tile rectangles (same images and gradients, NOT the reference's integer "
                          "path: num_rendered and the tile lists shrink); off for the headline number")
@@ -199,8 +202,14 @@ def main():
     K = max(1, args.views_in_flight)
     views = ViewStreams(K, dev) if K > 1 else None  # dgr_amd.multiview: independent views on K HIP streams
 
+    captured = []
+
     def run(n):
         r = None
+        if captured:
+            for i in range(n):
+                captured[i % len(captured)].replay()
+            return radii
         for i in range(n):
             if views is None:
                 r = step()
@@ -228,6 +237,11 @@ def main():
     _capi.profile_select(dominant)
     _capi.set_option("profile_every", 8)
 
+    if args.graph:
+        if dist is not None:
+            raise SystemExit("--graph is a single-GPU mode")
+        from dgr_amd.multiview import CapturedStep
+        captured.extend(CapturedStep(step, stream=torch.cuda.Stream(device=dev)) for _ in range(K))
     # one view at a time, for reference (short, untimed by the contract)
     serial_ms = None
     if K > 1:
@@ -276,6 +290,9 @@ def main():
                 pair_evals = 2 * int(nc.to(torch.int64).sum().item())
         views_per_s = world * args.steps / elapsed
         dom_ms = dom_tot / max(dom_n, 1)
+        live = dom_n > 0
+        if not live:  # hipGraph replay: the launches are inside the graphs, nothing is bracketed live
+            dom_ms = stage_ms[dominant]
         abytes = algorithmic_bytes(dominant, P, V, R, N, 16)
         achieved = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
@@ -301,7 +318,7 @@ def main():
             "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
                                    f"fwd+bwd incl. viewmatrix gradient, one view per step, {K} independent views in flight per GPU", "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
-                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms,
+                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "hipgraph_replay": bool(args.graph),
                        "pair_evals_per_view": pair_evals,
                        "pair_evals_per_s": None if pair_evals is None else pair_evals * views_per_s / world, "tight_cull": bool(args.tight_cull),
                        "gradient_allreduce": (None if dist is None else
@@ -312,7 +329,7 @@ def main():
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": abytes,
-                         "avg_ms": dom_ms, "launches": dom_n,
+                         "avg_ms": dom_ms, "launches": dom_n, "measured_in_timed_region": live,
                          # the same kernel with nothing else on the GPU (calibration pass, one view at a time)
                          "isolated_avg_ms": stage_ms[dominant],
                          "isolated_frac": abytes / (stage_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS},

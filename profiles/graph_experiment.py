@@ -94,3 +94,23 @@ for K in (2, 3):
         gk.replay()
     torch.cuda.synchronize()
     print(f"graph of {K} views on {K} streams  {1e3 * (time.perf_counter() - t0) / (n // K * K):.4f} ms/view")
+
+# K separately captured views, each replayed on its own stream (graphs on different streams may overlap each other)
+for K in (2, 3):
+    streams = [torch.cuda.Stream() for _ in range(K)]
+    graphs = []
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+        g_ = torch.cuda.CUDAGraph()
+        for p_ in params:
+            p_.grad = None
+        with torch.cuda.graph(g_, stream=st):
+            step()
+        graphs.append(g_)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        with torch.cuda.stream(streams[i % K]):
+            graphs[i % K].replay()
+    torch.cuda.synchronize()
+    print(f"{K} graphs replayed round-robin on {K} streams  {1e3 * (time.perf_counter() - t0) / n:.4f} ms/view")

@@ -441,3 +441,49 @@ def test_debug_mode_dumps_a_snapshot_on_failure(tmp_path, monkeypatch):
     dump = torch.load(tmp_path / "snapshot_fw.dump", weights_only=False)
     assert isinstance(dump, (tuple, list)) and len(dump) == 20  # the 20 arguments of rasterize_gaussians
     assert all(not (isinstance(t, torch.Tensor) and t.is_cuda) for t in dump)
+
+
+def test_captured_steps_on_their_own_streams(monkeypatch):
+    """Three views, each recorded into its own hipGraph on its own stream and replayed round-robin: every replay gives
+    that view's eager result (the graphs overlap on the GPU)."""
+    monkeypatch.setenv("DGR_SYNC_MODE", "lazy")
+    from dgr_amd import light as D
+    from dgr_amd.multiview import CapturedStep, make_settings
+    dev = hh.dev()
+    scenes = [make_scene(5000, 160, 120, 4, view_index=k) for k in range(3)]
+    s0 = scenes[0]
+    gt, gC, gD = hh.T(s0.gt), hh.T(s0.gC), hh.T(s0.gD[None])
+    shared = [hh.T(a) for a in (s0.means, s0.shs, s0.opac, s0.scales, s0.rots)]
+
+    def make_step(k):
+        rast = D.GaussianRasterizer(make_settings(scenes[k], 3, dev))
+        leaves = [t.clone().requires_grad_() for t in shared] + [hh.T(scenes[k].view).requires_grad_()]
+        means3D, shs, opac, scales, rots, view = leaves
+        means2D = torch.zeros((s0.P, 3), device=dev, requires_grad=True)
+
+        def step():
+            for t in leaves + [means2D]:
+                t.grad = None
+            outs = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots,
+                        viewmatrix=view, gt_depth=gt)
+            torch.autograd.backward([outs[0], outs[2]], [gC, gD])
+            return [outs[0].detach()] + [t.grad for t in leaves]
+        return step
+
+    steps = [make_step(k) for k in range(3)]
+    want = []
+    for st in steps:
+        res = st()
+        torch.cuda.synchronize()
+        want.append([t.cpu().numpy().copy() for t in res])
+    caps = [CapturedStep(st, stream=torch.cuda.Stream()) for st in steps]
+    for rnd in range(4):
+        for c in caps:
+            c.replay()
+    torch.cuda.synchronize()
+    for c, w in zip(caps, want):
+        got = [t.cpu().numpy() for t in c.result]
+        assert np.array_equal(got[0], w[0])
+        for a, b in zip(got[1:], w[1:]):
+            assert_grad_close(a, b, "replay on a stream", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
+    caps[0].check()
