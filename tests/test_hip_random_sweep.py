@@ -74,3 +74,20 @@ def test_random_scene_full_variant(oracle, draw):
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
         assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=1)
     assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=1e-4, elem_rtol=5e-3, elem_frac=0.1)
+
+
+@pytest.mark.parametrize("P", [1, 2, 63, 257])
+def test_tiny_populations(oracle, P):
+    """Fewer Gaussians than a wave / a workgroup, and one more than a workgroup."""
+    s = make_scene(P, 40, 24, 500 + P)
+    out, d = hh.hip_forward(s, 2)
+    st, ref = hh.oracle_forward(oracle, s, 2)
+    assert d["num_rendered"] == ref["num_rendered"] and np.array_equal(d["radii"], ref["radii"])
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    for k in ("color", "depth", "opacity_map"):
+        assert_image_close(d[k], ref[k], k, max_outliers=2.0 / (s.W * s.H))
+    grads = tuple(g * (s.W * s.H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+    g = hh.hip_backward(s, 2, out, grads=grads, alphas=ref["opacity_map"])
+    gr = hh.oracle_backward(oracle, st, s, 2, ref["opacity_map"], grads=grads)
+    for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dview"):
+        assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=0.05)
