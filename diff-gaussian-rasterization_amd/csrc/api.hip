@@ -549,6 +549,16 @@ int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* g
     return DGR_OK;
 }
 
+int dgr_densification_stats(void* stream, long rows, const float* dmeans2D, const int* radii, float* grad_accum, float* denom,
+                            float* max_radii2D) {
+    if (rows < 0 || rows > 0x7fffffffL || (rows > 0 && (!radii || (grad_accum && !dmeans2D)))) {
+        g_last_error = "dgr_densification_stats: bad argument";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    HIP_TRY(dgr::launch_densification_stats((int)rows, dmeans2D, radii, grad_accum, denom, max_radii2D, (hipStream_t)stream));
+    return DGR_OK;
+}
+
 int dgr_early_status_arm(void) {
     g_early.armed = true;
     g_early.pending = false;

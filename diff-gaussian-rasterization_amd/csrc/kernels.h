@@ -161,6 +161,8 @@ hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hi
 // captured hipGraph were seen to re-execute with corrupted parameters on this ROCm)
 hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream);
 // fused sparse Adam (optim.hip): rows with visible[row] <= 0 are skipped entirely; visible == NULL updates every row
+hipError_t launch_densification_stats(int rows, const float* dmeans2D, const int* radii, float* grad_accum, float* denom,
+                                      float* max_radii2D, hipStream_t stream);
 hipError_t launch_sparse_adam(size_t rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                               const int* visible, float lr, float beta1, float beta2, float eps, int step, hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream);

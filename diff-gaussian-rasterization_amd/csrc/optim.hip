@@ -33,7 +33,33 @@ __global__ void __launch_bounds__(256) sparse_adam_kernel(size_t n, int k, float
     }
 }
 
+// 3DGS's densification bookkeeping after a view's backward (GaussianModel.add_densification_stats and the
+// max_radii2D update of the training loop), for the rows the view saw: one pass instead of five indexed torch ops.
+__global__ void __launch_bounds__(256) densification_stats_kernel(int rows, const float* __restrict__ dmeans2D,
+                                                                  const int* __restrict__ radii,
+                                                                  float* __restrict__ grad_accum, float* __restrict__ denom,
+                                                                  float* __restrict__ max_radii2D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    if (grad_accum) {
+        const float gx = dmeans2D[3 * (size_t)i], gy = dmeans2D[3 * (size_t)i + 1];
+        grad_accum[i] += sqrtf(gx * gx + gy * gy);
+    }
+    if (denom) denom[i] += 1.0f;
+    if (max_radii2D) max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+}
+
 }  // namespace
+
+hipError_t launch_densification_stats(int rows, const float* dmeans2D, const int* radii, float* grad_accum, float* denom,
+                                      float* max_radii2D, hipStream_t stream) {
+    if (rows == 0) return hipSuccess;
+    launch(densification_stats_kernel, dim3((rows + 255) / 256), dim3(256), stream, rows, dmeans2D, radii, grad_accum, denom,
+           max_radii2D);
+    return hipGetLastError();
+}
 
 hipError_t launch_sparse_adam(size_t rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                               const int* visible, float lr, float beta1, float beta2, float eps, int step,

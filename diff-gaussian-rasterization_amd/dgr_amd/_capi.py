@@ -29,6 +29,7 @@ _SIGS = {
     "dgr_last_error": (C.c_char_p, []),
     "dgr_early_status_arm": (_i, []),
     "dgr_early_status_wait": (_i, [_vp]),
+    "dgr_densification_stats": (_i, [_vp, C.c_long, _vp, _vp, _vp, _vp, _vp]),
     "dgr_sparse_adam": (_i, [_vp, C.c_long, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i]),
     "dgr_set_option": (_i, [C.c_char_p, _i]),
     "dgr_get_option": (_i, [C.c_char_p]),

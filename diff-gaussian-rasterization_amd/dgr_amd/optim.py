@@ -9,6 +9,26 @@ import torch
 from . import _capi
 
 
+@torch.no_grad()
+def add_densification_stats(dmeans2D, radii, xyz_gradient_accum=None, denom=None, max_radii2D=None):
+    """3DGS's per-view densification bookkeeping in one launch (`dgr_densification_stats`): for rows with radii > 0,
+    `xyz_gradient_accum += |dmeans2D[:, :2]|`, `denom += 1`, `max_radii2D = max(max_radii2D, radii)`.
+    `dmeans2D`: the `.grad` of the `means2D` tensor handed to the rasterizer ([P, 3]); the three accumulators are float32
+    tensors with P elements ([P] or [P, 1]), updated in place; pass None to skip one."""
+    P = radii.numel()
+    for t in (xyz_gradient_accum, denom, max_radii2D):
+        if t is not None and (t.numel() != P or t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda):
+            raise RuntimeError("add_densification_stats: accumulators must be contiguous float32 GPU tensors with P elements")
+    if radii.dtype != torch.int32 or not radii.is_cuda or dmeans2D.shape != (P, 3) or dmeans2D.dtype != torch.float32:
+        raise RuntimeError("add_densification_stats: radii must be int32 [P] and dmeans2D float32 [P, 3] on the GPU")
+    ptr = lambda t: None if t is None else t.data_ptr()
+    rc = _capi.load().dgr_densification_stats(_capi.stream_handle(), P, dmeans2D.contiguous().data_ptr(),
+                                              radii.contiguous().data_ptr(), ptr(xyz_gradient_accum), ptr(denom),
+                                              ptr(max_radii2D))
+    if rc:
+        raise RuntimeError(_capi.last_error())
+
+
 class SparseAdam:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         """`params`: tensors [P, ...] or torch-style groups `{"params": [...], "lr": ...}`."""

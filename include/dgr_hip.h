@@ -178,6 +178,14 @@ int dgr_early_status_wait(int* host_status4);
 int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                     const int* visible, float lr, float beta1, float beta2, float eps, int step);
 
+/* Densification bookkeeping for the rows one view saw (radii[row] > 0), as 3DGS's GaussianModel.add_densification_stats
+ * and the training loop's max_radii2D update do with indexed torch ops (the reference's caller; the rasterizer only
+ * hands back dL_dmeans2D for this purpose, diff_gaussian_rasterization/__init__.py L:164-176):
+ *   grad_accum[row] += |dmeans2D[row, 0:2]|;  denom[row] += 1;  max_radii2D[row] = max(max_radii2D[row], radii[row]).
+ * dmeans2D is [rows, 3]; each of the three outputs ([rows] floats) may be NULL to skip it. */
+int dgr_densification_stats(void* stream, long rows, const float* dmeans2D, const int* radii, float* grad_accum, float* denom,
+                            float* max_radii2D);
+
 /* Process-wide options (default 0).
  *  "tight_cull": 1 = alpha-aware tile rectangles.  The reference gives a Gaussian every tile its
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle

@@ -59,3 +59,28 @@ def test_invisible_rows_are_left_alone():
         ref.step()
     for p, q in zip(params, ref_p):
         np.testing.assert_allclose(p.detach().cpu().numpy()[~unseen], q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_densification_stats_match_the_indexed_torch_ops():
+    """3DGS's add_densification_stats + max_radii2D update, one launch, three views in a row."""
+    from dgr_amd.optim import add_densification_stats
+    dev = torch.device("cuda:0")
+    P = 5001
+    g = torch.Generator(device="cpu").manual_seed(3)
+    accum, denom, maxr = (torch.zeros((P, 1), device=dev), torch.zeros((P, 1), device=dev), torch.zeros(P, device=dev))
+    accum_ref, denom_ref, maxr_ref = accum.clone(), denom.clone(), maxr.clone()
+    for view in range(3):
+        dmeans2D = torch.randn((P, 3), generator=g).to(dev)
+        radii = torch.randint(-1, 40, (P,), generator=g).to(torch.int32).to(dev)
+        radii[torch.rand(P, generator=g).to(dev) < 0.3] = 0
+        add_densification_stats(dmeans2D, radii, accum, denom, maxr)
+        seen = radii > 0
+        accum_ref[seen] += torch.norm(dmeans2D[seen, :2], dim=-1, keepdim=True)
+        denom_ref[seen] += 1
+        maxr_ref[seen] = torch.max(maxr_ref[seen], radii[seen].float())
+    np.testing.assert_allclose(accum.cpu().numpy(), accum_ref.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    assert torch.equal(denom, denom_ref) and torch.equal(maxr, maxr_ref)
+    # optional outputs
+    before = accum.clone()
+    add_densification_stats(dmeans2D, radii, None, denom, None)
+    assert torch.equal(accum, before) and torch.equal(denom, denom_ref + (radii > 0).float().unsqueeze(1))

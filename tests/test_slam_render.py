@@ -176,3 +176,20 @@ def test_tracking_iteration_replayed_from_a_hipgraph(monkeypatch):
     e1 = errors()
     assert float(last) < 0.3 * first
     assert e1[0] < 0.3 * e0[0] and e1[1] < 0.3 * e0[1], (e0, e1)
+
+
+@pytest.mark.gpu
+def test_mapping_loop_reduces_the_loss():
+    """examples/mapping.py: keyframe batch on several streams + densification statistics + fused sparse Adam refine a
+    degraded map; the statistics count each (Gaussian, view) a keyframe saw."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from mapping import mapping_loop
+    iters, keyframes = 40, 3
+    (l0, l1), pc, _ = mapping_loop(torch.device("cuda:0"), 8000, 192, 144, keyframes, iters)
+    assert l1 < 0.6 * l0, (l0, l1)
+    denom = pc.denom.cpu().numpy()
+    assert denom.max() == iters * keyframes and (denom > 0).mean() > 0.5
+    assert float(pc.xyz_gradient_accum.sum()) > 0 and float(pc.max_radii2D.max()) >= 1
+    assert np.all((pc.xyz_gradient_accum.cpu().numpy() > 0) <= (denom > 0))
