@@ -30,8 +30,8 @@ struct StagedT {
     static constexpr int SLOTS = NB;
     static constexpr int SENTINEL = NB;       // record slot that can never contribute (opacity 0)
     static constexpr int LIST_LD = NB + 8;    // list row: NB entries + sentinel padding, 8-byte aligned rows
-    float4 rec[2 * (NB + 1)];  // [2*slot] = {x, y, a2, b2}, [2*slot+1] = {c2, opacity, slot (int bits), lthr}
-                               //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power
+    float4 rec[2 * (NB + 1)];  // [2*slot] = {x, y, a2, c2}, [2*slot+1] = {b2, opacity, slot (int bits), lthr}
+                               //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power (pair_p2)
     float4 rgbd[NB];           // {r, g, b, depth}
     uint32_t id[NB];
     unsigned short list[4][LIST_LD];  // per consumer wave: byte offsets (slot * 32) into rec, tile-list order
@@ -56,8 +56,8 @@ __device__ __forceinline__ unsigned stage_one(StagedT<NB>& s, int slot, uint32_t
     // value and re-tests alpha itself on the rare path, so decisions are those of the linear-domain test.
     const float l2 = __log2f(o * (255.0f / 15.0f));  // = tau / (2 ln 2)
     const float lthr = (o > 0.f) ? (-l2 - 1.0e-4f) : 3.0e38f;
-    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -LOG2E * q1.y);
-    s.rec[2 * slot + 1] = make_float4(-0.5f * LOG2E * q1.z, o, __int_as_float(slot), lthr);
+    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -0.5f * LOG2E * q1.z);
+    s.rec[2 * slot + 1] = make_float4(-LOG2E * q1.y, o, __int_as_float(slot), lthr);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
     const float tau = 2.0f * 0.6931471805599453f * l2;
@@ -89,8 +89,8 @@ __device__ __forceinline__ unsigned stage_tagged(StagedT<NB>& s, int slot, uint3
     const float4 q0 = rec[3 * (size_t)gid + 0];
     const float4 q1 = rec[3 * (size_t)gid + 1];
     const float4 q2 = rec[3 * (size_t)gid + 2];
-    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -LOG2E * q1.y);
-    s.rec[2 * slot + 1] = make_float4(-0.5f * LOG2E * q1.z, q0.w, __int_as_float(slot), 0.f);
+    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -0.5f * LOG2E * q1.z);
+    s.rec[2 * slot + 1] = make_float4(-LOG2E * q1.y, q0.w, __int_as_float(slot), 0.f);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
     return code;
@@ -123,6 +123,20 @@ __device__ __forceinline__ int build_lists(StagedT<NB>& s, unsigned code, int ti
     __syncthreads();
     if (lane < 4) s.list[wave][n + lane] = (unsigned short)(StagedT<NB>::SENTINEL * 32);  // own list, own wave: program order suffices
     return n;
+}
+
+// v_pk_*_f32 operands: gfx950 issues two fp32 operations per lane with one packed instruction
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// log2(e) * power of one (pixel, Gaussian) pair from a staged record, and the offsets d = centre - pixel.
+// Forward and backward must agree on every decision, so both evaluate exactly this sequence: a packed subtract, a
+// packed multiply, two fused multiply-adds and one multiply (explicit fma: nothing is left to contraction).
+__device__ __forceinline__ float pair_p2(const float4& q0, const float4& q1, f2 pxy, f2& dxy) {
+    const f2 g = {q0.x, q0.y}, ac = {q0.z, q0.w};
+    dxy = g - pxy;
+    const f2 m = ac * dxy;                                      // a2 dx, c2 dy
+    const float t = __builtin_fmaf(q1.x, dxy.y, m.x);           // a2 dx + b2 dy
+    return __builtin_fmaf(dxy.x, t, m.y * dxy.y);
 }
 
 // two consecutive list entries: one 4-byte LDS read yields two record offsets

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     const int py = ty * DGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const size_t pix_id = (size_t)a.W * py + px;
-    const float pxf = (float)px, pyf = (float)py;
+    const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
 
     const uint2 range = a.ranges[tile];
@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
             load2(s, wave, k, q0, q1);
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
-                const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
+                f2 dxy;
+                const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
                 if ((p2 <= ub) & (p2 >= q1[u].w)) {
                   const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
                   if (alpha >= ALPHA_MIN) {
@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
     const bool inside = px < a.W && py < a.H;
     const size_t pix_id = (size_t)a.W * py + px;
     const size_t N = (size_t)a.W * a.H;
-    const float pxf = (float)px, pyf = (float)py;
+    const f2 pxy = {(float)px, (float)py};
 
     const uint2 range = a.ranges[tile];
     const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
@@ -204,8 +204,8 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
             load2(s, wave, k, q0, q1);
 #pragma unroll
             for (int u = 1; u >= 0; u--) {
-                const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
-                const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
+                f2 dxy;
+                const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
                 const float oG = q1[u].y * __builtin_amdgcn_exp2f(p2);  // o G: alpha before the 0.99 clamp
@@ -240,6 +240,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
                         fq = oG * (dL_depth * (T * (Xd - Sd)));  // dL_depth * ddepth_dalpha * o * G
                     }
                 }
+                const float dx = dxy.x, dy = dxy.y;
                 const float qdx = qq * dx, qdy = qq * dy;
                 float g[16];
                 g[0] = w * dpix0;
@@ -267,7 +268,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
         if (code != 0u) {
             constexpr float LN2 = 0.6931471805599453f;
             const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
-            const float ca = r0.z * (-2.f * LN2), cb = r0.w * (-LN2), cc = r1.x * (-2.f * LN2);
+            const float ca = r0.z * (-2.f * LN2), cb = r1.x * (-LN2), cc = r0.w * (-2.f * LN2);
 #pragma unroll
             for (int p = 0; p < 3; p++) {
                 const int cx = (p == 0) ? 4 : (p == 1) ? 10 : 13, cy = cx + 1;

@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
     const int py = ty * DGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
     const size_t pix_id = (size_t)a.W * py + px;
-    const float pxf = (float)px, pyf = (float)py;
+    const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
 
     const uint2 range = a.ranges[tile];
@@ -100,8 +100,8 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
             load2(s, wave, k, q0, q1);
 #pragma unroll
             for (int u = 0; u < FWD_UNROLL; u++) {
-                const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
-                const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
+                f2 dxy;
+                const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
                 if ((p2 <= ub) & (p2 >= q1[u].w)) {  // cheap log-domain pre-test: v_exp stays off the common path
                   const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
                   if (alpha >= ALPHA_MIN) {
@@ -182,6 +182,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     const size_t pix_id = (size_t)a.W * py + px;
     const size_t N = (size_t)a.W * a.H;
     const float pxf = (float)px, pyf = (float)py;
+    const f2 pxy = {pxf, pyf};
 
     const uint2 range = a.ranges[tile];
     const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
@@ -252,8 +253,9 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
             load2(s, wave, k, q0, q1);
 #pragma unroll
             for (int u = 1; u >= 0; u--) {
-                const float dx = q0[u].x - pxf, dy = q0[u].y - pyf;
-                const float p2 = dx * (q0[u].z * dx + q0[u].w * dy) + q1[u].x * dy * dy;
+                f2 dxy;
+                const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
+                const float dx = dxy.x, dy = dxy.y;
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
                 const float oG = q1[u].y * __builtin_amdgcn_exp2f(p2);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         if (code != 0u) {
             constexpr float LN2 = 0.6931471805599453f;
             const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
-            const float ca = r0.z * (-2.f * LN2), cb = r0.w * (-LN2), cc = r1.x * (-2.f * LN2);  // unscaled conic
+            const float ca = r0.z * (-2.f * LN2), cb = r1.x * (-LN2), cc = r0.w * (-2.f * LN2);  // unscaled conic
             const float Sx = sb.acc[4 * BWD_LD + tid], Sy = sb.acc[5 * BWD_LD + tid];
             sb.acc[4 * BWD_LD + tid] = -(ca * Sx + cb * Sy) * ddelx_dx;
             sb.acc[5 * BWD_LD + tid] = -(cc * Sy + cb * Sx) * ddely_dy;
