@@ -1,7 +1,7 @@
 // wave_reduce.h -- multi-value wave64 reductions for gfx950.
 //
 // Reducing V values across 64 lanes one at a time costs 6 cross-lane steps each.  The butterfly below
-// reduces up to 16 values TOGETHER in 33 instructions: every stage halves the lane span of each value and
+// reduces up to 16 values TOGETHER in 30 instructions: every stage halves the lane span of each value and
 // packs two registers into one (v_permlane32_swap / v_permlane16_swap move half a register in one
 // instruction; the narrower stages use DPP row_mirror / row_half_mirror / quad_perm).  Afterwards each
 // 4-lane quad holds the grand total of ONE input value:
@@ -46,20 +46,30 @@ __device__ __forceinline__ float wave_reduce16(float (&x)[16], int lane) {
     asm volatile("s_nop 1\n\t" DGR_SWAP16(0, 1) DGR_SWAP16(2, 3) DGR_SWAP16(4, 5) DGR_SWAP16(6, 7)
                  : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7));
     const float z0 = y0 + y1, z1 = y2 + y3, z2 = y4 + y5, z3 = y6 + y7;
-    // stage C: span 16 -> 8, 4 -> 2
-    const float a0 = z0 + dpp_mov<DPP_ROW_MIRROR>(z0), b0 = z1 + dpp_mov<DPP_ROW_MIRROR>(z1);
-    const float a1 = z2 + dpp_mov<DPP_ROW_MIRROR>(z2), b1 = z3 + dpp_mov<DPP_ROW_MIRROR>(z3);
-    const float t0 = (lane & 8) ? b0 : a0, t1 = (lane & 8) ? b1 : a1;
-    // stage D: span 8 -> 4, 2 -> 1
-    const float c0 = t0 + dpp_mov<DPP_ROW_HALF_MIRROR>(t0), c1 = t1 + dpp_mov<DPP_ROW_HALF_MIRROR>(t1);
-    float u = (lane & 4) ? c1 : c0;
+    // stage C: span 16 -> 8, 4 -> 2.  The DPP adds write through bank masks (a bank = 4 lanes of a row): lanes 0-7 of
+    // every row take the first source, lanes 8-15 the second -- a merge costs two instructions, no v_cndmask.
+    float t0, t1;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %1, %4, %4 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                 "v_add_f32_dpp %1, %5, %5 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                 : "=&v"(t0), "=&v"(t1)
+                 : "v"(z0), "v"(z1), "v"(z2), "v"(z3));
+    // stage D: span 8 -> 4, 2 -> 1: lanes 0-3 of every 8 take t0, lanes 4-7 take t1
+    float u;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                 : "=&v"(u)
+                 : "v"(t0), "v"(t1));
     // stage E: span 4 -> 1
     u += dpp_mov<DPP_QUAD_XOR1>(u);
     u += dpp_mov<DPP_QUAD_XOR2>(u);
     return u;
 }
 
-// Same network for 12 values (x[0..11]): 27 instructions.  Lane quads whose wave_reduce16_comp() is >= 12 hold garbage.
+// Same network for 12 values (x[0..11]): 25 instructions.  Lane quads whose wave_reduce16_comp() is >= 12 hold garbage.
 __device__ __forceinline__ float wave_reduce12(float (&x)[12], int lane) {
     asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) DGR_SWAP32(2, 3) DGR_SWAP32(4, 5) DGR_SWAP32(6, 7) DGR_SWAP32(8, 9)
                  DGR_SWAP32(10, 11)
@@ -69,11 +79,19 @@ __device__ __forceinline__ float wave_reduce12(float (&x)[12], int lane) {
     asm volatile("s_nop 1\n\t" DGR_SWAP16(0, 1) DGR_SWAP16(2, 3) DGR_SWAP16(4, 5)
                  : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5));
     const float z0 = y0 + y1, z1 = y2 + y3, z2 = y4 + y5;
-    const float a0 = z0 + dpp_mov<DPP_ROW_MIRROR>(z0), b0 = z1 + dpp_mov<DPP_ROW_MIRROR>(z1);
-    const float t1 = z2 + dpp_mov<DPP_ROW_MIRROR>(z2);  // upper half rows would carry values 12..15: unused
-    const float t0 = (lane & 8) ? b0 : a0;
-    const float c0 = t0 + dpp_mov<DPP_ROW_HALF_MIRROR>(t0), c1 = t1 + dpp_mov<DPP_ROW_HALF_MIRROR>(t1);
-    float u = (lane & 4) ? c1 : c0;
+    float t0, t1;  // (upper half rows of t1 would carry values 12..15: unused)
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %1, %4, %4 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+                 : "=&v"(t0), "=&v"(t1)
+                 : "v"(z0), "v"(z1), "v"(z2));
+    float u;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+                 : "=&v"(u)
+                 : "v"(t0), "v"(t1));
     u += dpp_mov<DPP_QUAD_XOR1>(u);
     u += dpp_mov<DPP_QUAD_XOR2>(u);
     return u;
