@@ -91,3 +91,65 @@ def test_tiny_populations(oracle, P):
     gr = hh.oracle_backward(oracle, st, s, 2, ref["opacity_map"], grads=grads)
     for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dview"):
         assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=0.05)
+
+
+def degenerate(s):
+    """A scene with the inputs the reference handles by construction rather than by care: Gaussians behind the camera
+    and outside the frustum, zero and enormous scales (determinant 0 / a rectangle larger than the frame), opacity exactly
+    0 and exactly 1, un-normalised and zero quaternions (the reference does not normalise: forward.cu:127)."""
+    P = s.means.shape[0]
+    means, scales, rots, opac = s.means.copy(), s.scales.copy(), s.rots.copy(), s.opac.copy()
+    k = np.arange(P)
+    means[k % 11 == 0, 2] *= -1.0                       # behind the camera
+    means[k % 13 == 1, 0] += 40.0                       # far outside the frustum
+    scales[k % 7 == 2] = 0.0                            # a point: covariance determinant 0
+    scales[k % 17 == 3] *= 60.0                         # covers the whole frame
+    scales[k % 19 == 4, 1:] = 0.0                       # a needle
+    opac[k % 5 == 0] = 0.0
+    opac[k % 5 == 1] = 1.0
+    rots[k % 23 == 5] *= 3.0                            # not unit length
+    rots[k % 29 == 6] = 0.0                             # zero quaternion: zero rotation matrix
+    return s._replace(means=means, scales=scales, rots=rots, opac=opac)
+
+
+def test_degenerate_inputs_light(oracle):
+    s = degenerate(make_scene(3000, 100, 70, 900))
+    out, d = hh.hip_forward(s, 3)
+    st, ref = hh.oracle_forward(oracle, s, 3)
+    assert d["num_rendered"] == ref["num_rendered"] and np.array_equal(d["radii"], ref["radii"])
+    assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    npx = s.W * s.H
+    for k in ("color", "depth", "depth_median", "opacity_map"):
+        assert np.all(np.isfinite(d[k]))
+        assert_image_close(d[k], ref[k], k, max_outliers=2.0 / npx)
+    assert np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
+    grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+    g = hh.hip_backward(s, 3, out, grads=grads, alphas=ref["opacity_map"])
+    gr = hh.oracle_backward(oracle, st, s, 3, ref["opacity_map"], grads=grads)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dview"):
+        assert np.array_equal(np.isfinite(g[k]), np.isfinite(gr[k])), k  # (a zero quaternion may give the reference NaN too)
+        ok = np.isfinite(gr[k])
+        assert_grad_close(np.where(ok, g[k], 0), np.where(ok, gr[k], 0), k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3,
+                          outlier_rows=2 if k == "dL_dmeans3D" else 1 if k != "dL_dview" else 0)
+
+
+def test_degenerate_inputs_full(oracle):
+    s = degenerate(make_scene(2500, 96, 64, 901))
+    npx = s.W * s.H
+    grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gV))
+    out, d = hh.hip_full_forward(s, 2)
+    g = hh.hip_full_backward(s, 2, out, grads=grads)
+    st, ref, gr = hh.oracle_full(oracle, s, 2, grads=grads)
+    assert np.array_equal(d["radii"], ref["radii"]) and d["num_rendered"] == ref["num_rendered"]
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    for k in ("color", "depth", "uncertainty"):
+        assert np.all(np.isfinite(d[k]))
+        assert_image_close(d[k], ref[k], k, max_outliers=2.0 / npx)
+    if not np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib")):
+        return
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        assert np.array_equal(np.isfinite(g[k]), np.isfinite(gr[k])), k
+        ok = np.isfinite(gr[k])
+        assert_grad_close(np.where(ok, g[k], 0), np.where(ok, gr[k], 0), k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3,
+                          outlier_rows=1)
