@@ -91,7 +91,8 @@ def main():
                          "path: num_rendered and the tile lists shrink); off for the headline number")
     ap.add_argument("--views-per-allreduce", type=int, default=0,
                     help="N>1: local views whose gradient arenas are summed before ONE all-reduce (global batch = this "
-                         "many views per GPU); 0 = --views-in-flight, 1 = an all-reduce after every view")
+                         "many views per GPU); 0 = 4 (BASELINE config 5: 32 views over 8 GPUs), 1 = an all-reduce after "
+                         "every view (config 4)")
     ap.add_argument("--allreduce", default="blocking", choices=["overlap", "blocking"],
                     help="N>1: blocking = the view's stream waits for its gradient all-reduce (with several views in "
                          "flight the other streams keep rendering under it); overlap = additionally defer the wait to "
@@ -162,7 +163,7 @@ def main():
     arena = GradientArena(params) if dist is not None else None
 
     pending = [None]
-    G = args.views_per_allreduce if args.views_per_allreduce > 0 else max(1, args.views_in_flight)
+    G = args.views_per_allreduce if args.views_per_allreduce > 0 else 4  # BASELINE config 5: 4 views per GPU and step
     grouped = GroupedReduce(arena, dist, G) if (arena is not None and G > 1) else None
 
     def step():
