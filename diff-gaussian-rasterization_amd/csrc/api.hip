@@ -559,6 +559,48 @@ int dgr_densification_stats(void* stream, long rows, const float* dmeans2D, cons
     return DGR_OK;
 }
 
+int dgr_pose_forward(void* stream, const float* quat, const float* trans, const float* perspec_matrix, float* viewmatrix,
+                     float* projmatrix, float* campos) {
+    if (!quat || !trans || !perspec_matrix || !viewmatrix || !projmatrix || !campos) {
+        g_last_error = "dgr_pose_forward: NULL argument";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    HIP_TRY(dgr::launch_pose_forward(quat, trans, perspec_matrix, viewmatrix, projmatrix, campos, (hipStream_t)stream));
+    return DGR_OK;
+}
+int dgr_pose_backward(void* stream, const float* quat, const float* dL_dviewmatrix, float* dL_dquat, float* dL_dtrans) {
+    if (!quat || !dL_dviewmatrix || !dL_dquat || !dL_dtrans) {
+        g_last_error = "dgr_pose_backward: NULL argument";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    HIP_TRY(dgr::launch_pose_backward(quat, dL_dviewmatrix, dL_dquat, dL_dtrans, (hipStream_t)stream));
+    return DGR_OK;
+}
+int dgr_l1_loss_scratch_floats(void) { return dgr::l1_loss_partials(); }
+int dgr_l1_loss_forward(void* stream, long n_color, const float* color, const float* color_obs, long n_depth, const float* depth,
+                        const float* depth_obs, float w_color, float w_depth, float* scratch, float* loss) {
+    if (n_color < 0 || n_depth < 0 || !scratch || !loss || (n_color > 0 && (!color || !color_obs)) ||
+        (n_depth > 0 && (!depth || !depth_obs))) {
+        g_last_error = "dgr_l1_loss_forward: bad argument";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    HIP_TRY(dgr::launch_l1_loss_forward(n_color, color, color_obs, n_depth, depth, depth_obs, w_color, w_depth, scratch, loss,
+                                        (hipStream_t)stream));
+    return DGR_OK;
+}
+int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const float* color_obs, long n_depth, const float* depth,
+                         const float* depth_obs, float w_color, float w_depth, const float* upstream, float* dL_dcolor,
+                         float* dL_ddepth) {
+    if (n_color < 0 || n_depth < 0 || (n_color > 0 && (!color || !color_obs || !dL_dcolor)) ||
+        (n_depth > 0 && (!depth || !depth_obs || !dL_ddepth))) {
+        g_last_error = "dgr_l1_loss_backward: bad argument";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    HIP_TRY(dgr::launch_l1_loss_backward(n_color, color, color_obs, n_depth, depth, depth_obs, w_color, w_depth, upstream,
+                                         dL_dcolor, dL_ddepth, (hipStream_t)stream));
+    return DGR_OK;
+}
+
 int dgr_early_status_arm(void) {
     g_early.armed = true;
     g_early.pending = false;

@@ -161,6 +161,15 @@ hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hi
 // captured hipGraph were seen to re-execute with corrupted parameters on this ROCm)
 hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream);
 // fused sparse Adam (optim.hip): rows with visible[row] <= 0 are skipped entirely; visible == NULL updates every row
+// slam.hip
+hipError_t launch_pose_forward(const float* q, const float* t, const float* perspec, float* view, float* proj, float* campos,
+                               hipStream_t stream);
+hipError_t launch_pose_backward(const float* q, const float* dview, float* dq, float* dt, hipStream_t stream);
+int l1_loss_partials();
+hipError_t launch_l1_loss_forward(long n_c, const float* c, const float* c_obs, long n_d, const float* d, const float* d_obs,
+                                  float w_c, float w_d, float* partial, float* loss, hipStream_t stream);
+hipError_t launch_l1_loss_backward(long n_c, const float* c, const float* c_obs, long n_d, const float* d, const float* d_obs,
+                                   float w_c, float w_d, const float* upstream, float* dc, float* dd, hipStream_t stream);
 hipError_t launch_densification_stats(int rows, const float* dmeans2D, const int* radii, float* grad_accum, float* denom,
                                       float* max_radii2D, hipStream_t stream);
 hipError_t launch_sparse_adam(size_t rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,

@@ -29,6 +29,11 @@ _SIGS = {
     "dgr_last_error": (C.c_char_p, []),
     "dgr_early_status_arm": (_i, []),
     "dgr_early_status_wait": (_i, [_vp]),
+    "dgr_pose_forward": (_i, [_vp] * 7),
+    "dgr_pose_backward": (_i, [_vp] * 5),
+    "dgr_l1_loss_scratch_floats": (_i, []),
+    "dgr_l1_loss_forward": (_i, [_vp, C.c_long, _vp, _vp, C.c_long, _vp, _vp, _f, _f, _vp, _vp]),
+    "dgr_l1_loss_backward": (_i, [_vp, C.c_long, _vp, _vp, C.c_long, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "dgr_densification_stats": (_i, [_vp, C.c_long, _vp, _vp, _vp, _vp, _vp]),
     "dgr_sparse_adam": (_i, [_vp, C.c_long, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i]),
     "dgr_set_option": (_i, [C.c_char_p, _i]),

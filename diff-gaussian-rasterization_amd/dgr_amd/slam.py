@@ -89,6 +89,82 @@ def camera_tensors(w2c, tanfovx, tanfovy, znear=0.01, zfar=100.0):
     return viewmatrix, projmatrix, perspec, campos
 
 
+class _PoseToCamera(torch.autograd.Function):
+    """(quaternion, translation) -> (viewmatrix, projmatrix, campos) in one launch, dL/dviewmatrix -> (dL/dq, dL/dt) in
+    another (C ABI: dgr_pose_forward / dgr_pose_backward).  Same function as
+    `camera_tensors(w2c_from_quat_trans(q, t), ...)`: only `viewmatrix` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, q, t, perspec):
+        from . import _capi
+        lib = _capi.load()
+        q, t, perspec = q.contiguous(), t.contiguous(), perspec.contiguous()
+        out = torch.empty((35,), dtype=torch.float32, device=q.device)
+        view, proj, campos = out[:16].view(4, 4), out[16:32].view(4, 4), out[32:35]
+        if lib.dgr_pose_forward(_capi.stream_handle(), q.data_ptr(), t.data_ptr(), perspec.data_ptr(), view.data_ptr(),
+                                proj.data_ptr(), campos.data_ptr()):
+            raise RuntimeError(_capi.last_error())
+        ctx.save_for_backward(q)
+        ctx.mark_non_differentiable(proj, campos)
+        return view, proj, campos
+
+    @staticmethod
+    def backward(ctx, dview, _dproj, _dcampos):
+        from . import _capi
+        lib = _capi.load()
+        (q,) = ctx.saved_tensors
+        grads = torch.empty((7,), dtype=torch.float32, device=q.device)
+        dview = dview.contiguous()
+        if lib.dgr_pose_backward(_capi.stream_handle(), q.data_ptr(), dview.data_ptr(), grads.data_ptr(),
+                                 grads[4:].data_ptr()):
+            raise RuntimeError(_capi.last_error())
+        return grads[:4], grads[4:], None
+
+
+def pose_to_camera(q, t, tanfovx, tanfovy, znear=0.01, zfar=100.0):
+    """(viewmatrix, projmatrix, perspec_matrix, campos) from a quaternion (r, x, y, z) and a translation, float32 GPU
+    tensors: the fused form of `camera_tensors(w2c_from_quat_trans(q, t), tanfovx, tanfovy)` (2 launches for forward +
+    backward instead of ~40 elementwise torch kernels)."""
+    perspec = projection_matrix(tanfovx, tanfovy, znear, zfar, device=q.device).transpose(0, 1).contiguous()
+    view, proj, campos = _PoseToCamera.apply(q, t, perspec)
+    return view, proj, perspec, campos
+
+
+class _L1Loss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, depth, color_obs, depth_obs, w_color, w_depth):
+        from . import _capi
+        lib = _capi.load()
+        color, depth, color_obs, depth_obs = (x.contiguous() for x in (color, depth, color_obs, depth_obs))
+        buf = torch.empty((lib.dgr_l1_loss_scratch_floats() + 1,), dtype=torch.float32, device=color.device)
+        if lib.dgr_l1_loss_forward(_capi.stream_handle(), color.numel(), color.data_ptr(), color_obs.data_ptr(), depth.numel(),
+                                   depth.data_ptr(), depth_obs.data_ptr(), float(w_color), float(w_depth), buf[1:].data_ptr(),
+                                   buf.data_ptr()):
+            raise RuntimeError(_capi.last_error())
+        ctx.save_for_backward(color, depth, color_obs, depth_obs)
+        ctx.weights = (float(w_color), float(w_depth))
+        return buf[0]
+
+    @staticmethod
+    def backward(ctx, upstream):
+        from . import _capi
+        lib = _capi.load()
+        color, depth, color_obs, depth_obs = ctx.saved_tensors
+        dc, dd = torch.empty_like(color), torch.empty_like(depth)
+        upstream = upstream.contiguous()
+        if lib.dgr_l1_loss_backward(_capi.stream_handle(), color.numel(), color.data_ptr(), color_obs.data_ptr(), depth.numel(),
+                                    depth.data_ptr(), depth_obs.data_ptr(), ctx.weights[0], ctx.weights[1],
+                                    upstream.data_ptr(), dc.data_ptr(), dd.data_ptr()):
+            raise RuntimeError(_capi.last_error())
+        return dc, dd, None, None, None, None
+
+
+def l1_loss(color, depth, color_obs, depth_obs, w_color=1.0, w_depth=0.5):
+    """w_color * mean|color - color_obs| + w_depth * mean|depth - depth_obs| as one fused reduction, with both gradient
+    images written by one launch in the backward (float32 GPU tensors; the observations carry no gradient)."""
+    return _L1Loss.apply(color, depth, color_obs, depth_obs, w_color, w_depth)
+
+
 def _get(obj, name, default=None):
     v = getattr(obj, name, default)
     return v() if callable(v) and not isinstance(v, torch.Tensor) else v

@@ -7,7 +7,7 @@ map_off=True, no Gaussian gradients).  With --graph the whole iteration -- pose 
 Adam step -- is recorded once into a hipGraph and replayed (dgr_amd.multiview.CapturedStep), which removes the host
 from the loop.
 
-  python examples/tracking.py [--graph] [--iters 150] [--width 640 --height 480 --gaussians 100000]
+  python examples/tracking.py [--graph] [--fused] [--iters 150] [--width 640 --height 480 --gaussians 100000]
 """
 import argparse
 import os
@@ -24,6 +24,8 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--fused", action="store_true",
+                    help="pose -> camera tensors and the L1 loss as single launches (slam.pose_to_camera, slam.l1_loss)")
     ap.add_argument("--iters", type=int, default=150)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -45,6 +47,8 @@ def main():
     kw = dict(fov=(tanfovx, tanfovy), HW=(H, W), gt_depth=gt_depth, track_off=False, map_off=True)
 
     def pose(q, t):
+        if args.fused:
+            return slam.pose_to_camera(q, t, tanfovx, tanfovy)[0]
         return slam.camera_tensors(slam.w2c_from_quat_trans(q, t), tanfovx, tanfovy)[0]
 
     q_true = torch.tensor(rot_to_quat(Rm), dtype=torch.float32, device=dev)
@@ -60,7 +64,10 @@ def main():
     def iteration():
         opt.zero_grad(set_to_none=True)
         out = slam.render(None, pc, None, bg, viewmatrix=pose(q, t), **kw)
-        loss = (out["render"] - obs_c).abs().mean() + 0.5 * (out["depth"] - obs_d).abs().mean()
+        if args.fused:
+            loss = slam.l1_loss(out["render"], out["depth"], obs_c, obs_d, 1.0, 0.5)
+        else:
+            loss = (out["render"] - obs_c).abs().mean() + 0.5 * (out["depth"] - obs_d).abs().mean()
         loss.backward()
         opt.step()
         return loss.detach()
@@ -87,7 +94,7 @@ def main():
         step.check()
     print(f"finish: rotation error {err()[0]:.2e}, translation error {err()[1]:.2e}, loss {float(loss):.3e}")
     print(f"{args.iters} iterations in {dt * 1e3:.1f} ms = {dt / args.iters * 1e3:.3f} ms per tracking iteration"
-          f" ({'hipGraph replay' if args.graph else 'eager'})")
+          f" ({'hipGraph replay' if args.graph else 'eager'}{', fused pose and loss' if args.fused else ''})")
 
 
 if __name__ == "__main__":

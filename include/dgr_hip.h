@@ -186,6 +186,27 @@ int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* g
 int dgr_densification_stats(void* stream, long rows, const float* dmeans2D, const int* radii, float* grad_accum, float* denom,
                             float* max_radii2D);
 
+/* ---- the small pieces of a tracking iteration around the rasterizer, one launch each (the reference's
+ * caller, CG-SLAM, does these with a dozen elementwise torch kernels each -- a 640x480 tracking step is launch-bound) ----
+ * dgr_pose_forward: (quat = (r, x, y, z), not necessarily unit; trans) -> the three camera tensors the rasterizer takes,
+ *   in its convention (cuda_rasterizer/auxiliary.h:58-77): viewmatrix = W2C^T, projmatrix = W2C^T * perspec_matrix with
+ *   perspec_matrix = Proj^T, campos = -R^T t.  16 + 16 + 3 floats.
+ * dgr_pose_backward: dL/dviewmatrix[16] (the rasterizer's pose gradient) -> dL/dquat[4], dL/dtrans[3], through the
+ *   normalisation of quat.  projmatrix and campos are constants of the rasterizer call, as in the reference
+ *   (diff_gaussian_rasterization/__init__.py L:164-176 returns a gradient for `viewmatrix` only). */
+int dgr_pose_forward(void* stream, const float* quat, const float* trans, const float* perspec_matrix, float* viewmatrix,
+                     float* projmatrix, float* campos);
+int dgr_pose_backward(void* stream, const float* quat, const float* dL_dviewmatrix, float* dL_dquat, float* dL_dtrans);
+/* loss = w_color * mean|color - color_obs| + w_depth * mean|depth - depth_obs| (two launches, fixed summation order);
+ * `scratch` holds dgr_l1_loss_scratch_floats() floats.  The backward writes both gradient images in one launch:
+ * w / n * sign(difference) * (*upstream), `upstream` == NULL meaning 1. */
+int dgr_l1_loss_scratch_floats(void);
+int dgr_l1_loss_forward(void* stream, long n_color, const float* color, const float* color_obs, long n_depth, const float* depth,
+                        const float* depth_obs, float w_color, float w_depth, float* scratch, float* loss);
+int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const float* color_obs, long n_depth, const float* depth,
+                         const float* depth_obs, float w_color, float w_depth, const float* upstream, float* dL_dcolor,
+                         float* dL_ddepth);
+
 /* Process-wide options (default 0).
  *  "tight_cull": 1 = alpha-aware tile rectangles.  The reference gives a Gaussian every tile its
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle

@@ -193,3 +193,40 @@ def test_mapping_loop_reduces_the_loss():
     assert denom.max() == iters * keyframes and (denom > 0).mean() > 0.5
     assert float(pc.xyz_gradient_accum.sum()) > 0 and float(pc.max_radii2D.max()) >= 1
     assert np.all((pc.xyz_gradient_accum.cpu().numpy() > 0) <= (denom > 0))
+
+
+@pytest.mark.gpu
+def test_fused_pose_and_loss_match_the_torch_ops():
+    """slam.pose_to_camera and slam.l1_loss (one launch each way) against the differentiable torch formulation."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    tanfovx, tanfovy = 0.6, 0.45
+    for trial in range(4):
+        q0 = (torch.randn(4, generator=g) * (0.3 if trial else 1.0) + torch.tensor([1.0, 0, 0, 0])).to(dev)
+        t0 = torch.randn(3, generator=g).to(dev)
+        qa, ta = q0.clone().requires_grad_(), t0.clone().requires_grad_()
+        qb, tb = q0.clone().requires_grad_(), t0.clone().requires_grad_()
+        va, pa, psa, ca = slam.pose_to_camera(qa, ta, tanfovx, tanfovy)
+        vb, pb, psb, cb = slam.camera_tensors(slam.w2c_from_quat_trans(qb, tb), tanfovx, tanfovy)
+        for x, y in ((va, vb), (pa, pb), (psa, psb), (ca, cb)):
+            np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-6, atol=2e-6)
+        assert va.requires_grad and not pa.requires_grad and not ca.requires_grad
+        w = torch.randn((4, 4), generator=g).to(dev)
+        (va * w).sum().backward()
+        (vb * w).sum().backward()
+        np.testing.assert_allclose(qa.grad.cpu().numpy(), qb.grad.cpu().numpy(), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(ta.grad.cpu().numpy(), tb.grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    H, W = 37, 53
+    c = torch.rand((3, H, W), generator=g).to(dev).requires_grad_()
+    d = torch.rand((1, H, W), generator=g).to(dev).requires_grad_()
+    co, do = torch.rand((3, H, W), generator=g).to(dev), torch.rand((1, H, W), generator=g).to(dev)
+    co[0, 0, :5] = c.detach()[0, 0, :5]  # exact ties: sign(0) = 0 on both sides
+    la = slam.l1_loss(c, d, co, do, 1.0, 0.5)
+    (3.0 * la).backward()
+    ga_c, ga_d = c.grad.clone(), d.grad.clone()
+    c.grad = d.grad = None
+    lb = (c - co).abs().mean() + 0.5 * (d - do).abs().mean()
+    (3.0 * lb).backward()
+    assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb))
+    np.testing.assert_allclose(ga_c.cpu().numpy(), c.grad.cpu().numpy(), rtol=1e-6, atol=0)
+    np.testing.assert_allclose(ga_d.cpu().numpy(), d.grad.cpu().numpy(), rtol=1e-6, atol=0)
