@@ -545,7 +545,18 @@ int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* g
         return DGR_ERR_BAD_ARGUMENT;
     }
     HIP_TRY(dgr::launch_sparse_adam((size_t)rows, k, param, grad, exp_avg, exp_avg_sq, visible, lr, beta1, beta2, eps, step,
-                                    (hipStream_t)stream));
+                                    nullptr, (hipStream_t)stream));
+    return DGR_OK;
+}
+int dgr_sparse_adam_capturable(void* stream, long rows, int k, float* param, const float* grad, float* exp_avg,
+                               float* exp_avg_sq, const int* visible, float lr, float beta1, float beta2, float eps,
+                               const int* step_device) {
+    if (rows < 0 || k <= 0 || !step_device || (rows > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) {
+        g_last_error = "dgr_sparse_adam_capturable: bad argument";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    HIP_TRY(dgr::launch_sparse_adam((size_t)rows, k, param, grad, exp_avg, exp_avg_sq, visible, lr, beta1, beta2, eps, 1,
+                                    step_device, (hipStream_t)stream));
     return DGR_OK;
 }
 

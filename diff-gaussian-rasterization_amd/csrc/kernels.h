@@ -173,7 +173,8 @@ hipError_t launch_l1_loss_backward(long n_c, const float* c, const float* c_obs,
 hipError_t launch_densification_stats(int rows, const float* dmeans2D, const int* radii, float* grad_accum, float* denom,
                                       float* max_radii2D, hipStream_t stream);
 hipError_t launch_sparse_adam(size_t rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
-                              const int* visible, float lr, float beta1, float beta2, float eps, int step, hipStream_t stream);
+                              const int* visible, float lr, float beta1, float beta2, float eps, int step,
+                              const int* step_dev, hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream);
 
 // binning: tile_count -> ranges (+ total in status[0], overflow in status[1]); emit keys; sort tiles

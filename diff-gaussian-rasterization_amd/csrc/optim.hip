@@ -19,7 +19,12 @@ __global__ void __launch_bounds__(256) sparse_adam_kernel(size_t n, int k, float
                                                           const float* __restrict__ grad, float* __restrict__ exp_avg,
                                                           float* __restrict__ exp_avg_sq, const int* __restrict__ visible,
                                                           float step_size, float beta1, float beta2, float eps,
-                                                          float inv_sqrt_bias2) {
+                                                          float inv_sqrt_bias2, float lr, const int* __restrict__ step_dev) {
+    if (step_dev) {  // capturable form: the step count lives on the device, the bias corrections are formed here
+        const float st = (float)*step_dev;
+        step_size = lr / (1.0f - powf(beta1, st));
+        inv_sqrt_bias2 = 1.0f / sqrtf(1.0f - powf(beta2, st));
+    }
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {
         if (visible && visible[e / (size_t)k] <= 0) continue;
@@ -63,13 +68,14 @@ hipError_t launch_densification_stats(int rows, const float* dmeans2D, const int
 
 hipError_t launch_sparse_adam(size_t rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                               const int* visible, float lr, float beta1, float beta2, float eps, int step,
-                              hipStream_t stream) {
+                              const int* step_dev, hipStream_t stream) {
     const size_t n = rows * (size_t)k;
     if (n == 0) return hipSuccess;
+    if (step < 1) step = 1;  // (unused with step_dev)
     const double bias1 = 1.0 - pow((double)beta1, (double)step), bias2 = 1.0 - pow((double)beta2, (double)step);
     const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
     launch(sparse_adam_kernel, dim3(blocks), dim3(256), stream, n, k, param, grad, exp_avg, exp_avg_sq, visible,
-           (float)((double)lr / bias1), beta1, beta2, eps, (float)(1.0 / sqrt(bias2)));
+           (float)((double)lr / bias1), beta1, beta2, eps, (float)(1.0 / sqrt(bias2)), lr, step_dev);
     return hipGetLastError();
 }
 

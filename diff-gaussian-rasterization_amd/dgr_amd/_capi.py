@@ -36,6 +36,7 @@ _SIGS = {
     "dgr_l1_loss_backward": (_i, [_vp, C.c_long, _vp, _vp, C.c_long, _vp, _vp, _f, _f, _vp, _vp, _vp]),
     "dgr_densification_stats": (_i, [_vp, C.c_long, _vp, _vp, _vp, _vp, _vp]),
     "dgr_sparse_adam": (_i, [_vp, C.c_long, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i]),
+    "dgr_sparse_adam_capturable": (_i, [_vp, C.c_long, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp]),
     "dgr_set_option": (_i, [C.c_char_p, _i]),
     "dgr_get_option": (_i, [C.c_char_p]),
     "dgr_version": (C.c_char_p, []),

@@ -30,8 +30,9 @@ def add_densification_stats(dmeans2D, radii, xyz_gradient_accum=None, denom=None
 
 
 class SparseAdam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        """`params`: tensors [P, ...] or torch-style groups `{"params": [...], "lr": ...}`."""
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        """`params`: tensors [P, ...] or torch-style groups `{"params": [...], "lr": ...}`.  `capturable=True` keeps the
+        step count on the device (one extra tiny launch per step) so that `step()` can be recorded into a hipGraph."""
         groups = list(params)
         if groups and isinstance(groups[0], torch.Tensor):
             groups = [{"params": groups}]
@@ -45,6 +46,8 @@ class SparseAdam:
             self.param_groups.append(g)
         self.state = {}
         self.steps = 0
+        self.capturable = bool(capturable)
+        self._step_dev = None
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
@@ -59,6 +62,11 @@ class SparseAdam:
         """visible: int32 [P] (e.g. the forward's radii; a row is updated where > 0) or None for every row."""
         lib = _capi.load()
         self.steps += 1
+        if self.capturable:
+            if self._step_dev is None:
+                dev = self.param_groups[0]["params"][0].device
+                self._step_dev = torch.full((1,), self.steps - 1, dtype=torch.int32, device=dev)
+            self._step_dev.add_(1)
         if visible is not None:
             if visible.dtype == torch.bool:
                 visible = visible.to(torch.int32)
@@ -79,8 +87,13 @@ class SparseAdam:
                 k = p.numel() // max(rows, 1)
                 if visible is not None and visible.numel() != rows:
                     raise RuntimeError("SparseAdam: `visible` must have one entry per row")
-                rc = lib.dgr_sparse_adam(st, rows, k, p.data_ptr(), grad.data_ptr(), s[0].data_ptr(), s[1].data_ptr(),
-                                         None if visible is None else visible.data_ptr(), float(g["lr"]), float(b1),
-                                         float(b2), float(g["eps"]), self.steps)
+                vis = None if visible is None else visible.data_ptr()
+                if self.capturable:
+                    rc = lib.dgr_sparse_adam_capturable(st, rows, k, p.data_ptr(), grad.data_ptr(), s[0].data_ptr(),
+                                                        s[1].data_ptr(), vis, float(g["lr"]), float(b1), float(b2),
+                                                        float(g["eps"]), self._step_dev.data_ptr())
+                else:
+                    rc = lib.dgr_sparse_adam(st, rows, k, p.data_ptr(), grad.data_ptr(), s[0].data_ptr(), s[1].data_ptr(),
+                                             vis, float(g["lr"]), float(b1), float(b2), float(g["eps"]), self.steps)
                 if rc:
                     raise RuntimeError(_capi.last_error())

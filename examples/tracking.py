@@ -25,7 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--fused", action="store_true",
-                    help="pose -> camera tensors and the L1 loss as single launches (slam.pose_to_camera, slam.l1_loss)")
+                    help="pose -> camera tensors, the L1 loss and the Adam step as single launches (slam.pose_to_camera, "
+                         "slam.l1_loss, optim.SparseAdam)")
     ap.add_argument("--iters", type=int, default=150)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -59,7 +60,12 @@ def main():
 
     q = (q_true + torch.tensor([0.0, 0.004, -0.006, 0.003], device=dev)).requires_grad_()
     t = (t_true + torch.tensor([0.012, -0.009, 0.015], device=dev)).requires_grad_()
-    opt = torch.optim.Adam([{"params": [q], "lr": 5e-4}, {"params": [t], "lr": 1.5e-3}], capturable=args.graph)
+    groups = [{"params": [q], "lr": 5e-4}, {"params": [t], "lr": 1.5e-3}]
+    if args.fused:  # one launch per tensor, step count on the device when the iteration is recorded into a graph
+        from dgr_amd.optim import SparseAdam
+        opt = SparseAdam(groups, capturable=args.graph)
+    else:
+        opt = torch.optim.Adam(groups, capturable=args.graph)
 
     def iteration():
         opt.zero_grad(set_to_none=True)

@@ -177,6 +177,11 @@ int dgr_early_status_wait(int* host_status4);
  * `visible` == NULL updates every row.  `visible` is typically the forward's `radii`. */
 int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                     const int* visible, float lr, float beta1, float beta2, float eps, int step);
+/* The same with the 1-based step count read from device memory when the kernel runs, so that a step recorded into a
+ * hipGraph keeps its bias correction right on every replay (the caller increments *step_device before, on the stream). */
+int dgr_sparse_adam_capturable(void* stream, long rows, int k, float* param, const float* grad, float* exp_avg,
+                               float* exp_avg_sq, const int* visible, float lr, float beta1, float beta2, float eps,
+                               const int* step_device);
 
 /* Densification bookkeeping for the rows one view saw (radii[row] > 0), as 3DGS's GaussianModel.add_densification_stats
  * and the training loop's max_radii2D update do with indexed torch ops (the reference's caller; the rasterizer only

@@ -84,3 +84,33 @@ def test_densification_stats_match_the_indexed_torch_ops():
     before = accum.clone()
     add_densification_stats(dmeans2D, radii, None, denom, None)
     assert torch.equal(accum, before) and torch.equal(denom, denom_ref + (radii > 0).float().unsqueeze(1))
+
+
+def test_capturable_steps_match_and_replay_from_a_graph():
+    """capturable=True reads the step count from device memory: same updates as torch Adam, also when the step is recorded
+    into a hipGraph once and replayed (the bias correction must follow the replays)."""
+    dev = torch.device("cuda:0")
+    P = 700
+    a = [t.clone().requires_grad_() for t in make(P, dev, 7)]
+    b = [t.clone().requires_grad_() for t in make(P, dev, 7)]
+    ours = SparseAdam(a, lr=2e-3, capturable=True)
+    ref = torch.optim.Adam(b, lr=2e-3)
+    grads = make(P, dev, 8)
+    for p, q, g in zip(a, b, grads):
+        p.grad, q.grad = g.clone(), g.clone()
+    for _ in range(3):  # eager steps (they also create the optimiser state before the capture)
+        ours.step()
+        ref.step()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            ours.step()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    for _ in range(5):  # (recording a graph executes nothing)
+        graph.replay()
+        ref.step()
+    torch.cuda.synchronize()
+    for p, q in zip(a, b):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=5e-6, atol=2e-7)
