@@ -9,7 +9,7 @@ A synthetic map rendered from K poses gives the keyframes' observed colour and d
   SparseAdam.step        fused Adam over the rows some keyframe saw, one launch per tensor
 all on the GPU, no host synchronisation inside the loop.
 
-  python examples/mapping.py [--iters 100] [--keyframes 4] [--width 640 --height 480 --gaussians 100000]
+  python examples/mapping.py [--graph] [--iters 100] [--keyframes 4] [--width 640 --height 480 --gaussians 100000]
 """
 import argparse
 import os
@@ -58,8 +58,9 @@ class MapModel:
                 {"params": [self._rotation], "lr": 1e-3}]
 
 
-def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None):
-    """Returns (losses of the first and last iteration, model, seconds per iteration)."""
+def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None, graph=False):
+    """Returns (losses of the first and last iteration, model, seconds per iteration).  graph=True records the whole
+    iteration (renders, losses, backward passes, statistics, Adam) into one hipGraph after three eager iterations."""
     from dgr_amd import slam
     from dgr_amd.optim import SparseAdam, add_densification_stats
     from dgr_amd.synth import make_scene
@@ -76,18 +77,29 @@ def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None):
                for c in cams]
     obs = [(o["render"].detach(), o["depth"].detach()) for o in obs]
 
+    if graph:
+        views_in_flight = 1  # (branches of one graph do not overlap on this ROCm, and the leaves' gradient accumulation
+                             #  belongs to the stream they were created on: keep the recorded iteration on one stream)
     pc = MapModel(s, dev, degrade=7)
-    opt = SparseAdam(pc.groups(), eps=1e-15)
+    opt = SparseAdam(pc.groups(), eps=1e-15, capturable=graph)
     seen = torch.zeros(P, dtype=torch.int32, device=dev)
     outs = [None] * keyframes
 
     def loss_fn(out, k):
         outs[k] = out
-        return (out["render"] - obs[k][0]).abs().mean() + 0.5 * (out["depth"] - obs[k][1]).abs().mean()
+        return slam.l1_loss(out["render"], out["depth"], obs[k][0], obs[k][1], 1.0, 0.5)  # one fused reduction
 
     def iteration():
         opt.zero_grad(set_to_none=True)
-        losses = slam.render_batch(cams, pc, None, bg, loss_fn, views_in_flight=views_in_flight, **kw)
+        if views_in_flight > 1:
+            losses = slam.render_batch(cams, pc, None, bg, loss_fn, views_in_flight=views_in_flight, **kw)
+        else:  # one keyframe after the other on the caller's stream
+            losses = []
+            for k, c in enumerate(cams):
+                loss = loss_fn(slam.render(None, pc, None, bg, viewmatrix=c["viewmatrix"], fov=c["fov"], HW=c["HW"],
+                                           gt_depth=gt, **kw), k)
+                loss.backward()
+                losses.append(loss.detach())
         seen.zero_()
         for out in outs:
             add_densification_stats(out["viewspace_points"].grad, out["radii"], pc.xyz_gradient_accum, pc.denom,
@@ -96,17 +108,29 @@ def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None):
         opt.step(visible=seen)
         return torch.stack(losses).mean()
 
-    first = float(iteration())
-    for _ in range(2):
-        iteration()
+    run = iteration
+    if graph:  # (the three eager iterations run inside CapturedStep, on the stream the graph is recorded on)
+        from dgr_amd.multiview import CapturedStep
+        with torch.no_grad():
+            first = float(torch.stack([slam.l1_loss(*(slam.render(None, pc, None, bg, viewmatrix=c["viewmatrix"], fov=c["fov"],
+                                                                  HW=c["HW"], gt_depth=gt, **kw)[k_] for k_ in ("render", "depth")),
+                                                    obs[i][0], obs[i][1], 1.0, 0.5) for i, c in enumerate(cams)]).mean())
+        step = CapturedStep(iteration, warmup=3)
+        run = step.replay
+    else:
+        first = float(iteration())
+        for _ in range(2):
+            iteration()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(iters - 3):
-        loss = iteration()
+        loss = run()
         if log and (i + 3) % 20 == 0:
             log(f"iteration {i + 3:4d}: loss {float(loss):.4e}")
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / max(iters - 3, 1)
+    if graph:
+        step.check()
     return (first, float(loss)), pc, dt
 
 
@@ -115,13 +139,16 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--keyframes", type=int, default=4)
     ap.add_argument("--views-in-flight", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="record the iteration into a hipGraph and replay it")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--gaussians", type=int, default=100000)
     args = ap.parse_args()
+    if args.graph:
+        os.environ["DGR_SYNC_MODE"] = "lazy"  # a blocking status read cannot be captured
     dev = torch.device("cuda:0")
     (l0, l1), pc, dt = mapping_loop(dev, args.gaussians, args.width, args.height, args.keyframes, args.iters,
-                                    args.views_in_flight, log=print)
+                                    args.views_in_flight, log=None if args.graph else print, graph=args.graph)
     n = float(pc.denom.sum())
     print(f"loss {l0:.4e} -> {l1:.4e}; {dt * 1e3:.3f} ms per mapping iteration over {args.keyframes} keyframes"
           f" ({dt / args.keyframes * 1e3:.3f} ms per keyframe); {int((pc.denom > 0).sum())} Gaussians seen,"
