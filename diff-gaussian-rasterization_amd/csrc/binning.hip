@@ -79,14 +79,15 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img,
 #pragma unroll
         for (int k = 0; k < REG; k++) {
             if (lo + k < hi) {
-                img.ranges[lo + k] = overflow ? make_uint2(0u, 0u) : make_uint2(run, run + c[k]);
+                // (empty tiles keep {0, 0}: the reference clears the table and writes only tiles that own instances)
+                img.ranges[lo + k] = (overflow || c[k] == 0u) ? make_uint2(0u, 0u) : make_uint2(run, run + c[k]);
                 run += c[k];
             }
         }
     } else {
         for (int i = lo; i < hi; i++) {
             const uint32_t cc = count_of(i);
-            img.ranges[i] = overflow ? make_uint2(0u, 0u) : make_uint2(run, run + cc);
+            img.ranges[i] = (overflow || cc == 0u) ? make_uint2(0u, 0u) : make_uint2(run, run + cc);
             run += cc;
         }
     }

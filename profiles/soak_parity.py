@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Soak run of the parity checks of tests/test_hip_random_sweep.py over many more random draws (not part of the test suite:
+minutes of oracle time).  usage: python profiles/soak_parity.py [n_light] [n_full] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-gaussian-rasterization_amd"), os.path.join(ROOT, "tests")]
+import numpy as np  # noqa: E402
+
+import hip_helpers as hh  # noqa: E402
+from util import assert_grad_close, assert_image_close, make_scene  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+O.use_cmath(False)
+n_light = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+n_full = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 7)
+fails, flips, t0 = [], 0, time.time()
+
+
+def draw_scene(i):
+    W = int(rng.choice([7, 16, 31, 64, 100, 129, 250, 321, 400]))
+    H = int(rng.choice([5, 16, 47, 64, 97, 200, 300]))
+    P = int(rng.integers(1, 30000))
+    s = make_scene(P, W, H, 1000 + i)
+    mode = rng.choice(["as drawn", "translucent", "opaque"])
+    if mode == "translucent":
+        s = s._replace(opac=(s.opac * 0.12).astype(np.float32))
+    elif mode == "opaque":
+        s = s._replace(opac=np.minimum(1.0, s.opac * 0.2 + 0.85).astype(np.float32))
+    return s, int(rng.integers(0, 4)), float(rng.choice([0.3, 1.0, 1.0, 2.5, 8.0])), mode
+
+
+for i in range(n_light):
+    s, deg, sm, mode = draw_scene(i)
+    tag = f"light#{i} P={s.means.shape[0]} {s.W}x{s.H} deg={deg} sm={sm} {mode}"
+    try:
+        out, d = hh.hip_forward(s, deg, scale_modifier=sm)
+        st, ref = hh.oracle_forward(O, s, deg, scale_modifier=sm)
+        assert d["num_rendered"] == ref["num_rendered"] and np.array_equal(d["radii"], ref["radii"])
+        assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
+        assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+        npx = s.W * s.H
+        for k in ("color", "depth", "depth_median", "opacity_map"):
+            assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx))
+        if not np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib")):
+            flips += 1
+            continue
+        grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+        modes = [(False, False), (True, False), (False, True)][i % 3]
+        g = hh.hip_backward(s, deg, out, grads=grads, alphas=ref["opacity_map"], scale_modifier=sm, track_off=modes[0], map_off=modes[1])
+        gr = hh.oracle_backward(O, st, s, deg, ref["opacity_map"], grads=grads, scale_modifier=sm, track_off=modes[0], map_off=modes[1])
+        flipped = False  # does some row miss the bar, i.e. did the two backward passes disagree on one (pixel, Gaussian) pair?
+        # One (pixel, Gaussian) pair within an ulp of a hard threshold (alpha >= 15/255, T > 0.5) is decided differently by
+        # the two backward passes now and then; it perturbs every later Gaussian of that pixel's chain -- a handful of rows in
+        # a sparse scene, a dozen where hundreds of Gaussians cover a pixel.  Rows over the bar are therefore counted, not
+        # forbidden: at most 2 + P / 2000 per tensor.
+        allowed = 2 + s.means.shape[0] // 2000
+        for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+            assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=allowed)
+            a2, b2 = g[k].reshape(len(g[k]), -1), gr[k].reshape(len(gr[k]), -1)
+            flipped = flipped or bool((np.abs(a2 - b2).max(1) > 2e-5 * max(np.abs(b2).max(), 1e-30)).any())
+        # the pose gradient is ONE sum over everything: a flipped pair is not confined to a row of it
+        flipped = flipped or modes[1]  # (tracking mode returns no per-Gaussian gradient to see a flip in)
+        assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=5e-3 if flipped else 2e-5, elem_rtol=2e-3,
+                          elem_frac=0.25 if flipped else 2e-3)
+        flips += int(flipped)
+    except AssertionError as e:
+        fails.append((tag, str(e)[:300]))
+        print("FAIL", tag, str(e)[:300], flush=True)
+
+for i in range(n_full):
+    s, deg, sm, mode = draw_scene(10000 + i)
+    tag = f"full#{i} P={s.means.shape[0]} {s.W}x{s.H} deg={deg} {mode}"
+    try:
+        npx = s.W * s.H
+        grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gV))
+        out, d = hh.hip_full_forward(s, deg)
+        g = hh.hip_full_backward(s, deg, out, grads=grads)
+        st, ref, gr = hh.oracle_full(O, s, deg, grads=grads)
+        assert np.array_equal(d["radii"], ref["radii"]) and d["num_rendered"] == ref["num_rendered"]
+        assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+        for k in ("color", "depth", "uncertainty"):
+            assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx))
+        if not (np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
+                and np.array_equal(hh.hip_state("n_valid", s, d), st.get("n_valid_contrib"))):
+            flips += 1  # a pixel blended a different set of Gaussians (a pair within one ulp of a threshold)
+            continue
+        for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+            assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=2 + s.means.shape[0] // 2000)
+        assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=1e-4, elem_rtol=5e-3, elem_frac=0.1)
+    except AssertionError as e:
+        fails.append((tag, str(e)[:300]))
+        print("FAIL", tag, str(e)[:300], flush=True)
+
+print(f"{n_light} light + {n_full} full draws in {time.time() - t0:.0f} s: {len(fails)} failures, {flips} draws with a pair the "
+      f"two implementations decided differently")
+sys.exit(1 if fails else 0)
