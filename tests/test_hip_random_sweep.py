@@ -84,6 +84,7 @@ def test_tiny_populations(oracle, P):
     st, ref = hh.oracle_forward(oracle, s, 2)
     assert d["num_rendered"] == ref["num_rendered"] and np.array_equal(d["radii"], ref["radii"])
     assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))  # empty tiles: {0, 0}, as the reference leaves them
     for k in ("color", "depth", "opacity_map"):
         assert_image_close(d[k], ref[k], k, max_outliers=2.0 / (s.W * s.H))
     grads = tuple(g * (s.W * s.H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
