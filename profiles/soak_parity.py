@@ -21,9 +21,9 @@ fails, flips, t0 = [], 0, time.time()
 
 
 def draw_scene(i):
-    W = int(rng.choice([7, 16, 31, 64, 100, 129, 250, 321, 400]))
-    H = int(rng.choice([5, 16, 47, 64, 97, 200, 300]))
-    P = int(rng.integers(1, 30000))
+    W = int(rng.choice([7, 16, 31, 64, 100, 129, 250, 321, 400, 803]))
+    H = int(rng.choice([5, 16, 47, 64, 97, 200, 300, 611]))
+    P = int(rng.integers(1, 30000)) if rng.random() < 0.9 else int(rng.integers(30000, 200000))
     s = make_scene(P, W, H, 1000 + i)
     mode = rng.choice(["as drawn", "translucent", "opaque"])
     if mode == "translucent":
@@ -37,8 +37,17 @@ for i in range(n_light):
     s, deg, sm, mode = draw_scene(i)
     tag = f"light#{i} P={s.means.shape[0]} {s.W}x{s.H} deg={deg} sm={sm} {mode}"
     try:
-        out, d = hh.hip_forward(s, deg, scale_modifier=sm)
-        st, ref = hh.oracle_forward(O, s, deg, scale_modifier=sm)
+        kw = {}
+        pre = int(rng.integers(0, 6))  # every third draw hands precomputed colours and / or covariances in
+        if pre in (1, 3, 5):
+            st0, _ = hh.oracle_forward(O, s, deg, scale_modifier=sm)
+            if pre in (1, 5):
+                kw["colors_precomp"] = st0.get("rgb").reshape(-1, 3).copy()
+            if pre in (3, 5):
+                kw["cov3D_precomp"] = st0.get("cov3D").reshape(-1, 6).copy()
+            tag += f" precomp={sorted(kw)}"
+        out, d = hh.hip_forward(s, deg, scale_modifier=sm, **kw)
+        st, ref = hh.oracle_forward(O, s, deg, scale_modifier=sm, **kw)
         assert d["num_rendered"] == ref["num_rendered"] and np.array_equal(d["radii"], ref["radii"])
         assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
         assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
@@ -50,15 +59,18 @@ for i in range(n_light):
             continue
         grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
         modes = [(False, False), (True, False), (False, True)][i % 3]
-        g = hh.hip_backward(s, deg, out, grads=grads, alphas=ref["opacity_map"], scale_modifier=sm, track_off=modes[0], map_off=modes[1])
-        gr = hh.oracle_backward(O, st, s, deg, ref["opacity_map"], grads=grads, scale_modifier=sm, track_off=modes[0], map_off=modes[1])
+        g = hh.hip_backward(s, deg, out, grads=grads, alphas=ref["opacity_map"], scale_modifier=sm, track_off=modes[0], map_off=modes[1], **kw)
+        gr = hh.oracle_backward(O, st, s, deg, ref["opacity_map"], grads=grads, scale_modifier=sm, track_off=modes[0], map_off=modes[1], **kw)
         flipped = False  # does some row miss the bar, i.e. did the two backward passes disagree on one (pixel, Gaussian) pair?
         # One (pixel, Gaussian) pair within an ulp of a hard threshold (alpha >= 15/255, T > 0.5) is decided differently by
         # the two backward passes now and then; it perturbs every later Gaussian of that pixel's chain -- a handful of rows in
         # a sparse scene, a dozen where hundreds of Gaussians cover a pixel.  Rows over the bar are therefore counted, not
         # forbidden: at most 2 + P / 2000 per tensor.
         allowed = 2 + s.means.shape[0] // 2000
-        for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        names = ["dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D"]
+        names += ["dL_dcolors"] if "colors_precomp" in kw else ["dL_dsh"]
+        names += [] if "cov3D_precomp" in kw else ["dL_dscales", "dL_drotations"]
+        for k in names:
             assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=allowed)
             a2, b2 = g[k].reshape(len(g[k]), -1), gr[k].reshape(len(gr[k]), -1)
             flipped = flipped or bool((np.abs(a2 - b2).max(1) > 2e-5 * max(np.abs(b2).max(), 1e-30)).any())
