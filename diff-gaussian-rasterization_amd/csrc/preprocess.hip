@@ -414,10 +414,13 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
         // ---- outputs that are plain copies of the blend kernel's sums
         // (with map_off the blend kernel still sums acc[4], acc[5] for the pose gradient, but the
         //  reference leaves every per-Gaussian gradient at zero: L/cuda_rasterizer/backward.cu:666)
-        a.dL_dmean2D[3 * (size_t)idx + 0] = a.map_off ? 0.0f : acc[4];
-        a.dL_dmean2D[3 * (size_t)idx + 1] = a.map_off ? 0.0f : acc[5];
-        a.dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
-        a.dL_dopacity[idx] = acc[9];
+        // (every dense output may be NULL: a tracking step needs the pose gradient only, dgr_hip.h)
+        if (a.dL_dmean2D) {
+            a.dL_dmean2D[3 * (size_t)idx + 0] = a.map_off ? 0.0f : acc[4];
+            a.dL_dmean2D[3 * (size_t)idx + 1] = a.map_off ? 0.0f : acc[5];
+            a.dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
+        }
+        if (a.dL_dopacity) a.dL_dopacity[idx] = acc[9];
         if (a.dL_dcolor) {
             a.dL_dcolor[3 * (size_t)idx + 0] = acc[0];
             a.dL_dcolor[3 * (size_t)idx + 1] = acc[1];
@@ -684,15 +687,21 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
             drot.w = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
         }
 
-        a.dL_dmean3D[3 * (size_t)idx + 0] = dmean.x;
-        a.dL_dmean3D[3 * (size_t)idx + 1] = dmean.y;
-        a.dL_dmean3D[3 * (size_t)idx + 2] = dmean.z;
+        if (a.dL_dmean3D) {
+            a.dL_dmean3D[3 * (size_t)idx + 0] = dmean.x;
+            a.dL_dmean3D[3 * (size_t)idx + 1] = dmean.y;
+            a.dL_dmean3D[3 * (size_t)idx + 2] = dmean.z;
+        }
+        if (a.dL_dcov3D) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
-        a.dL_dscale[3 * (size_t)idx + 0] = dscale.x;
-        a.dL_dscale[3 * (size_t)idx + 1] = dscale.y;
-        a.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
-        reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
+            for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+        }
+        if (a.dL_dscale) {
+            a.dL_dscale[3 * (size_t)idx + 0] = dscale.x;
+            a.dL_dscale[3 * (size_t)idx + 1] = dscale.y;
+            a.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
+        }
+        if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
 
         // ---------------- pose gradient: sum over Gaussians of Jacobian x (sum over pixels)
         // L/cuda_rasterizer/backward.cu:633-651 accumulates J_k(g) * {nx, ny, dL_ddepth} per pixel; J_k

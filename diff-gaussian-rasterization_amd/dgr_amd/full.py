@@ -115,8 +115,9 @@ class _C:
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, viewmatrix, gt_depth, projmatrix, tan_fovx, tan_fovy,
                                      dL_dout_color, dL_dout_depth, dL_dout_uncertainty, sh, degree, campos, geomBuffer,
-                                     R, binningBuffer, imageBuffer, NG, perspec_matrix):
-        # F/rasterize_points.cu:122-239
+                                     R, binningBuffer, imageBuffer, NG, perspec_matrix, need_gaussian_grads=True):
+        # F/rasterize_points.cu:122-239.  need_gaussian_grads=False (tracking: no Gaussian input requires a gradient) returns
+        # None for the eight per-Gaussian gradients and skips their dense rows; the pose gradient is the same.
         lib = _capi.load()
         dev = means3D.device
         P = means3D.size(0)
@@ -129,10 +130,11 @@ class _C:
         gt_depth, sh, perspec_matrix = _f32c(gt_depth, dev), _f32c(sh, dev), _f32c(perspec_matrix, dev)
         gC, gD, gU = _f32c(dL_dout_color, dev), _f32c(dL_dout_depth, dev), _f32c(dL_dout_uncertainty, dev)
         M = sh.size(1) if sh.numel() != 0 else 0
-        seg = _grad_arena(P, M, f32)
+        names = ("means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations")
+        seg = _grad_arena(P, M, f32) if need_gaussian_grads else dict.fromkeys(names)
         dL_dview = torch.empty((4, 4), **f32)
         scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes(P, W, H), 1),), dtype=torch.uint8, device=dev)
-        p = _capi.ptr
+        p = lambda t: None if t is None else _capi.ptr(t)  # noqa: E731
         _check(lib.dgr_full_backward(
             _capi.stream_handle(), P, int(degree), M, int(R), p(background), W, H, p(means3D), p(sh), p(colors),
             p(scales), float(scale_modifier), p(rotations), p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos),
@@ -232,7 +234,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 num_related_gaussians,
                 raster_settings.perspec_matrix)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations, grad_viewmatrix) = _C.rasterize_gaussians_backward(*args)
+         grad_rotations, grad_viewmatrix) = _C.rasterize_gaussians_backward(*args, need_gaussian_grads=any(ctx.needs_input_grad[:8]))
         grads = (
             grad_means3D,
             grad_means2D,

@@ -250,8 +250,10 @@ class _C:
                                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                      dL_dout_depth, dL_dout_median_depth, dL_dout_depth_var, gt_depth, sh, degree,
                                      campos, geomBuffer, R, binningBuffer, imageBuffer, alphas, debug,
-                                     perspec_matrix, track_off, map_off):
-        # L/rasterize_points.cu:131-236
+                                     perspec_matrix, track_off, map_off, need_gaussian_grads=True):
+        # L/rasterize_points.cu:131-236.  `need_gaussian_grads=False` (an extension: the autograd Function passes it when
+        # no Gaussian input requires a gradient, i.e. tracking) returns None for the eight per-Gaussian gradients and lets
+        # the library skip their dense rows; the pose gradient is the same.
         lib = _capi.load()
         dev = means3D.device
         P = means3D.size(0)
@@ -266,18 +268,23 @@ class _C:
         gC, gD = _f32c(dL_dout_color, dev), _f32c(dL_dout_depth, dev)
         gM, gV = _f32c(dL_dout_median_depth, dev), _f32c(dL_dout_depth_var, dev)
         M = sh.size(1) if sh.numel() != 0 else 0
-        seg = _grad_arena(P, M, f32)
-        dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dopacity = seg["means3D"], seg["means2D"], seg["sh"], seg["opacity"]
-        dL_dscales, dL_drotations, dL_dcov3D, dL_dcolors = seg["scales"], seg["rotations"], seg["cov3D"], seg["colors"]
+        if need_gaussian_grads:
+            seg = _grad_arena(P, M, f32)
+            dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dopacity = seg["means3D"], seg["means2D"], seg["sh"], seg["opacity"]
+            dL_dscales, dL_drotations, dL_dcov3D, dL_dcolors = seg["scales"], seg["rotations"], seg["cov3D"], seg["colors"]
+        else:
+            dL_dmeans3D = dL_dmeans2D = dL_dsh = dL_dopacity = dL_dscales = dL_drotations = dL_dcov3D = dL_dcolors = None
+            map_off = True  # nobody reads the per-Gaussian sums: the blend kernel forms the three pose sums only
         dL_dview = torch.empty((4, 4), **f32)
         scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes(P, W, H), 1),), dtype=torch.uint8, device=dev)
         p = _capi.ptr
+        q = lambda t: None if t is None else p(t)  # noqa: E731
         _check(lib.dgr_light_backward(
             _capi.stream_handle(), P, int(degree), M, int(R), p(background), W, H, p(means3D), p(sh), p(colors),
             p(alphas), p(scales), float(scale_modifier), p(rotations), p(cov3D_precomp), p(viewmatrix),
             p(projmatrix), p(campos), float(tan_fovx), float(tan_fovy), p(radii), p(geomBuffer), p(binningBuffer),
-            p(imageBuffer), p(gC), p(gD), p(gM), p(gV), p(dL_dmeans2D), None, p(dL_dopacity), p(dL_dcolors), None,
-            p(dL_dmeans3D), p(dL_dcov3D), p(dL_dsh), p(dL_dscales), p(dL_drotations), int(bool(debug)), None,
+            p(imageBuffer), p(gC), p(gD), p(gM), p(gV), q(dL_dmeans2D), None, q(dL_dopacity), q(dL_dcolors), None,
+            q(dL_dmeans3D), q(dL_dcov3D), q(dL_dsh), q(dL_dscales), q(dL_drotations), int(bool(debug)), None,
             p(perspec_matrix), p(dL_dview), None, p(gt_depth), int(bool(track_off)), int(bool(map_off)),
             p(scratch), scratch.numel()))
         return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
@@ -431,7 +438,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
         else:
-            out = _C.rasterize_gaussians_backward(*args)
+            # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp): tracking needs none
+            out = _C.rasterize_gaussians_backward(*args, need_gaussian_grads=any(ctx.needs_input_grad[:8]))
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_viewmatrix) = out
         # reference: torch.sum(grad_viewmatrix, dim=0) over a [H*W,4,4] buffer (__init__.py:160-161);

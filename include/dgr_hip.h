@@ -94,7 +94,10 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
  *    are not materialised and may be NULL;
  *  - `dL_dconic` ([P,2,2]) and `dL_ddepth` ([P,1]) may be NULL; when given they receive the same sums
  *    the reference accumulates there;
- *  - gradient outputs need not be zero-initialised: rows of invisible Gaussians are written as 0.
+ *  - gradient outputs need not be zero-initialised: rows of invisible Gaussians are written as 0;
+ *  - every per-Gaussian gradient output may be NULL and is then not written.  A tracking step (only `viewmatrix` requires
+ *    a gradient) passes them all as NULL together with map_off = 1: the backward then forms the pose gradient alone and
+ *    moves no dense per-Gaussian rows (248 bytes per Gaussian at SH degree 3).
  * `R` is the value forward returned; `radii` may be NULL (internal copy is used). */
 int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,

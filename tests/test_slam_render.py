@@ -230,3 +230,33 @@ def test_fused_pose_and_loss_match_the_torch_ops():
     assert abs(float(la) - float(lb)) <= 2e-6 * abs(float(lb))
     np.testing.assert_allclose(ga_c.cpu().numpy(), c.grad.cpu().numpy(), rtol=1e-6, atol=0)
     np.testing.assert_allclose(ga_d.cpu().numpy(), d.grad.cpu().numpy(), rtol=1e-6, atol=0)
+
+
+@pytest.mark.gpu
+def test_pose_only_backward_equals_the_full_backward():
+    """When no Gaussian input requires a gradient (tracking) the backward skips the dense per-Gaussian rows; the pose
+    gradient is the one the mapping-mode backward returns."""
+    from dgr_amd import light
+    dev = torch.device("cuda:0")
+    W, H = 200, 150
+    s = make_scene(15000, W, H, 3)
+    pc = Model(s, dev)
+    bg, gt = torch.from_numpy(s.bg).to(dev), torch.from_numpy(s.gt).to(dev)
+    gC, gD = torch.from_numpy(s.gC).to(dev), torch.from_numpy(s.gD).to(dev)
+    views = []
+    for need in (False, True):
+        xyz = pc.get_xyz.clone().requires_grad_(need)
+        vm = torch.from_numpy(s.view).to(dev).requires_grad_()
+        st = light.GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=bg, scale_modifier=1.0, viewmatrix=vm.detach(),
+            projmatrix=torch.from_numpy(s.proj).to(dev), sh_degree=3, campos=torch.from_numpy(s.campos).to(dev), prefiltered=False,
+            debug=False, perspec_matrix=torch.from_numpy(s.persp).to(dev), track_off=False, map_off=False)
+        out = light.GaussianRasterizer(st)(means3D=xyz, means2D=torch.zeros_like(xyz), opacities=pc.get_opacity,
+                                           shs=pc.get_features, scales=pc.get_scaling, rotations=pc.get_rotation, viewmatrix=vm,
+                                           gt_depth=gt)
+        torch.autograd.backward([out[0], out[2]], [(gC * (W * H) ** 0.5).reshape(out[0].shape),
+                                                   (gD * (W * H) ** 0.5).reshape(out[2].shape)])
+        views.append(vm.grad.cpu().numpy())
+        assert (xyz.grad is not None) == need
+    assert np.abs(views[0]).max() > 0
+    np.testing.assert_allclose(views[0], views[1], rtol=0, atol=2e-6 * np.abs(views[1]).max())
