@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="N=1: record one view per stream into a hipGraph (dgr_amd.multiview.CapturedStep) and replay the "
                          "graphs round-robin instead of issuing the views from Python; pays for host-bound sizes (config 2)")
+    ap.add_argument("--tracking", action="store_true",
+                    help="not the headline workload: a tracking step instead of a mapping step -- only the viewmatrix requires "
+                         "a gradient (map_off), so the backward forms the pose gradient alone (light variant, N=1)")
     ap.add_argument("--tight-cull", action="store_true",
                     help="opt-in alpha-aware tile rectangles (same images and gradients, NOT the reference's integer "
                          "path: num_rendered and the tile lists shrink); off for the headline number")
@@ -141,12 +144,13 @@ def main():
     P, W, H, deg = WORKLOADS[args.workload]
     s = make_scene(P, W, H, seed=0, view_index=rank)  # rank r renders view r of the same Gaussians
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    means3D = t(s.means).requires_grad_(True)
-    shs = t(s.shs).requires_grad_(True)
-    opac = t(s.opac).requires_grad_(True)
-    scales = t(s.scales).requires_grad_(True)
-    rots = t(s.rots).requires_grad_(True)
-    means2D = torch.zeros((P, 3), device=dev, requires_grad=True)
+    mapping = not args.tracking
+    means3D = t(s.means).requires_grad_(mapping)
+    shs = t(s.shs).requires_grad_(mapping)
+    opac = t(s.opac).requires_grad_(mapping)
+    scales = t(s.scales).requires_grad_(mapping)
+    rots = t(s.rots).requires_grad_(mapping)
+    means2D = torch.zeros((P, 3), device=dev, requires_grad=mapping)
     view = t(s.view).requires_grad_(True)
     gt = t(s.gt)
     gC, gD, gM, gV = t(s.gC), t(s.gD[None]), t(s.gM[None]), t(s.gV[None])
@@ -157,7 +161,7 @@ def main():
             viewmatrix=tt(s.view), projmatrix=tt(s.proj), sh_degree=deg, campos=tt(s.campos), prefiltered=False,
             perspec_matrix=tt(s.persp))
     else:
-        settings = make_settings(s, deg, dev)
+        settings = make_settings(s, deg, dev, map_off=args.tracking)
     rast = GaussianRasterizer(settings)
     params = [means3D, means2D, shs, opac, scales, rots]
     arena = GradientArena(params) if dist is not None else None
@@ -317,7 +321,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
-                                   f"fwd+bwd incl. viewmatrix gradient, one view per step, {K} independent views in flight per GPU", "visible": V,
+                                   f"fwd+bwd incl. viewmatrix gradient, one view per step, {K} independent views in flight per GPU"
+                                   + (" -- TRACKING step: pose gradient only (map_off), not the headline mapping step" if args.tracking else ""), "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
                        "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "hipgraph_replay": bool(args.graph),
                        "pair_evals_per_view": pair_evals,
@@ -343,6 +348,7 @@ def main():
             torch.cuda.synchronize(dev)
             pairs = {"dL_dmeans3D": means3D, "dL_dsh": shs, "dL_dopacity": opac, "dL_dscales": scales,
                      "dL_drotations": rots, "dL_dview": view}
+            pairs = {k: v for k, v in pairs.items() if v.grad is not None}  # (--tracking: the pose gradient only)
             errs = {k: float(np.abs(v.grad.detach().cpu().numpy().reshape(-1).astype(np.float64)
                                     - np.asarray(ref_grads[k], np.float64).reshape(-1)).max()) for k, v in pairs.items()}
             line["config"]["grad_max_abs_err"] = dict(
