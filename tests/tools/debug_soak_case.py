@@ -1,7 +1,7 @@
-"""Looks at one failing draw of profiles/soak_parity.py (full variant): which rows differ, and whether the forward's
+"""Looks at one failing draw of tests/tools/soak_parity.py (full variant): which rows differ, and whether the forward's
 per-pixel valid-contributor counts differ (an alpha-threshold flip)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-gaussian-rasterization_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import hip_helpers as hh

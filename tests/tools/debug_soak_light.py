@@ -1,6 +1,6 @@
-"""Re-runs chosen light draws of profiles/soak_parity.py (seed, indices) and reports which check fails."""
+"""Re-runs chosen light draws of tests/tools/soak_parity.py (seed, indices) and reports which check fails."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-gaussian-rasterization_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import hip_helpers as hh

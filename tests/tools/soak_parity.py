@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Soak run of the parity checks of tests/test_hip_random_sweep.py over many more random draws (not part of the test suite:
-minutes of oracle time).  usage: python profiles/soak_parity.py [n_light] [n_full] [seed]"""
+minutes of oracle time).  usage: python tests/tools/soak_parity.py [n_light] [n_full] [seed]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-gaussian-rasterization_amd"), os.path.join(ROOT, "tests")]
 import numpy as np  # noqa: E402
 
