@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
                 g[13] = fq * dx;  // front-most depth sums
                 g[14] = fq * dy;
                 g[15] = 0.f;
-                const float tot = wave_reduce16(g, lane);
+                const float tot = wave_reduce16(g);
                 if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * BWD_LD + j], tot);
             }
         }

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     g[9] = qq;         // sum q
                     g[10] = DO_POSE ? wd : 0.f;  // -> accumulator component 13
                     g[11] = 0.f;
-                    tot = wave_reduce12(g, lane);
+                    tot = wave_reduce12(g);
                 } else {
                     float g4[4] = {qdx, qdy, wd, 0.f};
                     tot = wave_reduce4(g4);
@@ -349,8 +349,8 @@ __global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, f
     float g12[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) g12[k] = g[k];
-    const float r12 = wave_reduce12(g12, lane);
-    const float r16 = wave_reduce16(g, lane);
+    const float r12 = wave_reduce12(g12);
+    const float r16 = wave_reduce16(g);
     // out16: lanes whose component is < 12 must agree between the 12- and 16-value networks; report a mismatch as NaN
     out16[lane] = (wave_reduce16_comp(lane) < 12 && r12 != r16) ? __builtin_nanf("") : r16;
     out4[lane] = wave_reduce4(g4);

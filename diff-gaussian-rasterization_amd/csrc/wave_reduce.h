@@ -34,7 +34,7 @@ __device__ __forceinline__ int wave_reduce16_comp(int lane) {
 
 // x[0..15] per lane -> total of value wave_reduce16_comp(lane) in every lane.  x[14], x[15] may be anything
 // the caller does not read back (pass zeros).
-__device__ __forceinline__ float wave_reduce16(float (&x)[16], int lane) {
+__device__ __forceinline__ float wave_reduce16(float (&x)[16]) {
     // stage A: span 64 -> 32, 16 registers -> 8
     asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) DGR_SWAP32(2, 3) DGR_SWAP32(4, 5) DGR_SWAP32(6, 7) DGR_SWAP32(8, 9)
                  DGR_SWAP32(10, 11) DGR_SWAP32(12, 13) DGR_SWAP32(14, 15)
@@ -70,7 +70,7 @@ __device__ __forceinline__ float wave_reduce16(float (&x)[16], int lane) {
 }
 
 // Same network for 12 values (x[0..11]): 25 instructions.  Lane quads whose wave_reduce16_comp() is >= 12 hold garbage.
-__device__ __forceinline__ float wave_reduce12(float (&x)[12], int lane) {
+__device__ __forceinline__ float wave_reduce12(float (&x)[12]) {
     asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) DGR_SWAP32(2, 3) DGR_SWAP32(4, 5) DGR_SWAP32(6, 7) DGR_SWAP32(8, 9)
                  DGR_SWAP32(10, 11)
                  : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
