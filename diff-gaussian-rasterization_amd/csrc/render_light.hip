@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     g[9] = qq;         // sum q
                     g[10] = DO_POSE ? wd : 0.f;  // -> accumulator component 13
                     g[11] = 0.f;
-                    tot = wave_reduce12(g);
+                    tot = wave_reduce12<!DO_POSE>(g);
                 } else {
                     float g4[4] = {qdx, qdy, wd, 0.f};
                     tot = wave_reduce4(g4);

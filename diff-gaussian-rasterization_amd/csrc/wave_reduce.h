@@ -70,12 +70,23 @@ __device__ __forceinline__ float wave_reduce16(float (&x)[16]) {
 }
 
 // Same network for 12 values (x[0..11]): 25 instructions.  Lane quads whose wave_reduce16_comp() is >= 12 hold garbage.
+// TEN = true: x[10] and x[11] are known to be zero (the caller need not set them): their swap and add are left out.
+template <bool TEN = false>
 __device__ __forceinline__ float wave_reduce12(float (&x)[12]) {
-    asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) DGR_SWAP32(2, 3) DGR_SWAP32(4, 5) DGR_SWAP32(6, 7) DGR_SWAP32(8, 9)
-                 DGR_SWAP32(10, 11)
-                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
-                   "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
-    float y0 = x[0] + x[1], y1 = x[2] + x[3], y2 = x[4] + x[5], y3 = x[6] + x[7], y4 = x[8] + x[9], y5 = x[10] + x[11];
+    float y0, y1, y2, y3, y4, y5;
+    if (TEN) {
+        asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) DGR_SWAP32(2, 3) DGR_SWAP32(4, 5) DGR_SWAP32(6, 7) DGR_SWAP32(8, 9)
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                       "+v"(x[8]), "+v"(x[9]));
+        y5 = 0.f;
+    } else {
+        asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) DGR_SWAP32(2, 3) DGR_SWAP32(4, 5) DGR_SWAP32(6, 7) DGR_SWAP32(8, 9)
+                     DGR_SWAP32(10, 11)
+                     : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                       "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
+        y5 = x[10] + x[11];
+    }
+    y0 = x[0] + x[1]; y1 = x[2] + x[3]; y2 = x[4] + x[5]; y3 = x[6] + x[7]; y4 = x[8] + x[9];
     asm volatile("s_nop 1\n\t" DGR_SWAP16(0, 1) DGR_SWAP16(2, 3) DGR_SWAP16(4, 5)
                  : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5));
     const float z0 = y0 + y1, z1 = y2 + y3, z2 = y4 + y5;
