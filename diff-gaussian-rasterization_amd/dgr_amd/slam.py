@@ -200,8 +200,14 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         campos = (-(w2c[:3, :3] * w2c[:3, 3:4]).sum(0)).contiguous()  # -(R^T t)
 
     means3D = pc.get_xyz
-    # 3DGS keeps a zero tensor whose .grad receives the screen-space gradient (densification statistics)
-    screenspace_points = torch.zeros_like(means3D, requires_grad=True)
+    # 3DGS keeps a zero tensor whose .grad receives the screen-space gradient (densification statistics).  A tracking
+    # step (map_off, or a map that carries no gradients) has no use for it, and without it the backward can skip every
+    # per-Gaussian gradient row (dgr_amd.light: need_gaussian_grads).
+    shs_or_colors = override_color if override_color is not None else pc.get_features
+    opacity, scaling, rotation = pc.get_opacity, pc.get_scaling, pc.get_rotation
+    mapping = (variant != "light" or not map_off) and any(
+        t.requires_grad for t in (means3D, shs_or_colors, opacity, scaling, rotation))
+    screenspace_points = torch.zeros_like(means3D, requires_grad=mapping)
     debug = bool(getattr(pipe, "debug", False)) if pipe is not None else False
     common = dict(image_height=H, image_width=W, tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color,
                   scale_modifier=scaling_modifier, viewmatrix=vm, projmatrix=projmatrix,
@@ -212,9 +218,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     else:
         settings = mod.GaussianRasterizationSettings(**common, perspec_matrix=perspec)
     rasterizer = mod.GaussianRasterizer(raster_settings=settings)
-    shs, colors = (None, override_color) if override_color is not None else (pc.get_features, None)
-    out = rasterizer(means3D=means3D, means2D=screenspace_points, opacities=pc.get_opacity, shs=shs,
-                     colors_precomp=colors, scales=pc.get_scaling, rotations=pc.get_rotation, cov3D_precomp=None,
+    shs, colors = (None, override_color) if override_color is not None else (shs_or_colors, None)
+    out = rasterizer(means3D=means3D, means2D=screenspace_points, opacities=opacity, shs=shs,
+                     colors_precomp=colors, scales=scaling, rotations=rotation, cov3D_precomp=None,
                      viewmatrix=viewmatrix, gt_depth=gt_depth)
     if variant == "light":
         color, radii, depth, depth_median, depth_var, opacity_map, gau_uncertainty, gau_related_pixels = out
