@@ -51,24 +51,22 @@ WORKLOADS = {
 
 
 def algorithmic_bytes(stage, P, V, R, N, M):
-    """Minimum HBM bytes of one launch of `stage` (V = visible, R = instances, N = pixels).
-    Every stage reads its inputs once and writes its outputs once; tile batches are staged in LDS."""
+    """Minimum HBM bytes of one launch of `stage`: SURVEY.md s8(d)'s per-view model (every stage reads its inputs once and
+    writes its outputs once, tile batches staged in LDS, one gradient read-modify-write per instance), term by term as the
+    survey lists them, assigned to the kernel that does that part here.  The stages add up to the survey's
+    316 P + 566 V + 172 R + 72 N for SH degree 3 (V = visible Gaussians, R = tile instances, N = pixels)."""
     sh = 12 * M
     table = {
-        # means 12 + scales 12 + rot 16 + opacity 4 in; radii 4 + rect 8 out; SH in, record 48 + depth 4 +
-        # cov3D 24 + clamp 1 out per visible Gaussian
-        "preprocess_fwd": 44 * P + 12 * P + (sh + 77) * V,
-        "scan_blocks": 0,
-        "count_rank": 8 * P + 4 * P + 8 * R,              # rect in, offset out; one 4-B histogram RMW + one 4-B rank per instance
-        "scan_tiles": 0,
-        "emit_instances": 12 * P + 4 * V + 12 * R,        # rect + offset + depth in; rank in, one 8-B key out per instance
-        "sort_tiles": 8 * R + 12 * R,                      # keys in; sorted keys + point_list out
-        "render_fwd": 4 * R + 48 * R + 36 * N,             # id + record per instance; gt in, 7 images + n_contrib out
-        "zero_scratch": 64 * P,
-        "render_bwd": 4 * R + 48 * R + 56 * R + 36 * N,        # + 14 accumulator floats RMW per instance; 9 images in
-        # accumulator row 64 + means 12 + cov3D 24 + SH + scale/rot 28 in per visible; dense outputs
-        # (dmeans3D 12, dmeans2D 12, dsh, dscales 12, drot 16, dopacity 4, dcov3D 24, dcolors 12) per Gaussian
-        "preprocess_bwd": 4 * P + (128 + sh) * V + (92 + sh) * P,
+        "preprocess_fwd": 44 * P + 8 * P + (sh + 67) * V,   # means/scales/rot/opacity in, radii + tiles_touched out; SH + state per visible
+        "scan_blocks": 8 * P,                                # the scan of tiles_touched
+        "count_rank": 8 * P + 12 * V,                        # duplicateWithKeys: its reads
+        "emit_instances": 12 * R,                            # ... its key/value pairs out
+        "sort_tiles": 24 * R,                                # one read + one write of the 12-byte pairs
+        "scan_tiles": 8 * R,                                 # range detection
+        "render_fwd": 44 * R + 36 * N,                       # id, xy, conic+opacity, rgb, depth per instance; gt in, images + n_contrib out
+        "zero_scratch": 0,                                   # (no counterpart in the ideal model)
+        "render_bwd": 44 * R + 40 * R + 36 * N,              # instance data again + 10 gradient floats RMW per instance; 9 images in
+        "preprocess_bwd": (103 + sh) * V + (56 + sh) * P,    # 295 V + 248 P at degree 3: per-visible inputs, dense outputs
     }
     return float(table[stage])
 
