@@ -31,10 +31,6 @@ for p in (ROOT, PKG, os.path.join(PKG, "light")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# The step keeps 3 view streams + the default stream + (N > 1) RCCL's stream busy: more than ROCm's default of 4 hardware
-# queues per process, on which streams would share a queue and serialise.  Must be set before the HIP runtime starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
