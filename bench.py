@@ -338,7 +338,7 @@ def main():
                          "isolated_avg_ms": stage_ms[dominant],
                          "isolated_frac": abytes / (stage_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS},
         }
-        if not args.no_cpu_baseline and args.variant == "light":
+        if not args.no_cpu_baseline and args.variant == "light" and world == 1:  # (the CPU baseline: rank 0 at N = 1 only)
             line["cpu_baseline"], ref_grads = cpu_baseline(s, deg, args.cpu_runs)
             # second half of BASELINE's metric: gradient max-abs-err against the CPU restatement of the reference, same
             # inputs and loss scaling (pixel-gradient images N(0,1)/(H W)); one extra untimed view on the default stream
