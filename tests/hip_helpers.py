@@ -162,8 +162,13 @@ def oracle_full(O, s, deg, colors_precomp=None, cov3D_precomp=None, grads=None, 
                              s.H, s.W, s.shs if use_sh else None, deg, s.campos)
     if not backward:
         return st, out, None
+    return st, out, oracle_full_backward(O, st, s, deg, colors_precomp, cov3D_precomp, grads)
+
+
+def oracle_full_backward(O, st, s, deg, colors_precomp=None, cov3D_precomp=None, grads=None):
+    use_sh = colors_precomp is None
+    use_sr = cov3D_precomp is None
     gC, gD, gU = grads if grads is not None else (s.gC, s.gD, s.gV)
-    g = O.full_backward(st, s.bg, s.means, colors_precomp, s.scales if use_sr else None, s.rots if use_sr else None, 1.0,
-                        cov3D_precomp, s.view, s.gt, s.proj, s.tanfovx, s.tanfovy, gC, gD, gU,
-                        s.shs if use_sh else None, deg, s.campos, s.persp)
-    return st, out, g
+    return O.full_backward(st, s.bg, s.means, colors_precomp, s.scales if use_sr else None, s.rots if use_sr else None,
+                           1.0, cov3D_precomp, s.view, s.gt, s.proj, s.tanfovx, s.tanfovy, gC, gD, gU,
+                           s.shs if use_sh else None, deg, s.campos, s.persp)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import assert_grad_close, assert_image_close, make_scene
+from util import assert_grad_close, assert_image_close, make_scene, mask_flipped_pixels
 import hip_helpers as hh
 
 pytestmark = pytest.mark.gpu
@@ -99,11 +99,11 @@ def test_oversize_tiles_and_many_batches(oracle, P):
     for k in ("color", "depth", "depth_median", "opacity_map"):
         assert_image_close(d[k], ref[k], k, max_outliers=2e-3)  # 1024 pixels: one flipped pixel is 1e-3
     grads = tuple(g * (s.W * s.H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
-    if np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib")):
-        g = hh.hip_backward(s, 1, out, grads=grads, alphas=ref["opacity_map"])
-        gr = hh.oracle_backward(oracle, st, s, 1, ref["opacity_map"], grads=grads)
-        for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dview"):
-            assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3)
+    grads, _ = mask_flipped_pixels(grads, hh.hip_state("n_contrib", s, d), st.get("n_contrib"), s.W, s.H, "oversize tiles")
+    g = hh.hip_backward(s, 1, out, grads=grads, alphas=ref["opacity_map"])
+    gr = hh.oracle_backward(oracle, st, s, 1, ref["opacity_map"], grads=grads)
+    for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dview"):
+        assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3)
 
 
 def test_binning_overflow_is_retried(oracle):
@@ -271,6 +271,44 @@ def test_tight_culling_changes_the_lists_but_not_the_results():
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dview"):
         assert_grad_close(g1[k], g0[k], k, rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
 
+
+
+@pytest.mark.parametrize("deg,seed", [(3, 9), (1, 21)])
+def test_tight_culling_against_the_oracle(oracle, deg, seed):
+    """The opt-in tile culling checked against the ORACLE (which has no such option), not against the default HIP path:
+    images inside the usual bars, stage-isolated gradients at 1e-5 of scale, every tile list a subsequence (same
+    order) of the reference's, and every instance the reference blends somewhere still present."""
+    from dgr_amd import _capi
+    s = make_scene(20000, 320, 240, seed)
+    grads = tuple(g * (s.W * s.H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+    st, ref = hh.oracle_forward(oracle, s, deg)
+    _capi.set_option("tight_cull", 1)
+    try:
+        out, d = hh.hip_forward(s, deg)
+        pl = hh.hip_state("point_list", s, d)
+        rg = hh.hip_state("ranges", s, d).reshape(-1, 2)
+        images = ("color", "depth", "depth_median", "opacity_map")
+        for k in images:
+            assert_image_close(d[k], ref[k], k)
+        same = np.zeros(s.W * s.H, np.uint32)  # n_contrib is a position in a different list here: mask by images only
+        grads, _ = mask_flipped_pixels(grads, same, same, s.W, s.H, "tight cull", images=[(d[k], ref[k]) for k in images])
+        g = hh.hip_backward(s, deg, out, grads=grads, alphas=ref["opacity_map"])
+    finally:
+        _capi.set_option("tight_cull", 0)
+    assert d["num_rendered"] < 0.8 * ref["num_rendered"]
+    assert np.array_equal(d["radii"], ref["radii"])
+    assert np.mean(d["gau_related_pixels"] != ref["gau_related_pixels"]) <= 1e-3
+    # lists: per tile a subsequence of the reference's sorted list
+    rpl, rrg = st.get("point_list"), st.get("ranges").reshape(-1, 2)
+    for t in range(len(rrg)):
+        mine, theirs = pl[rg[t, 0]:rg[t, 1]], rpl[rrg[t, 0]:rrg[t, 1]]
+        pos = {int(v): i for i, v in enumerate(theirs)}
+        idx = [pos.get(int(v), -1) for v in mine]
+        assert all(i >= 0 for i in idx) and all(a < b for a, b in zip(idx, idx[1:])), f"tile {t}"
+    gr = hh.oracle_backward(oracle, st, s, deg, ref["opacity_map"], grads=grads)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dview"):
+        assert_grad_close(g[k], gr[k], k, rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-3,
+                          outlier_rows=2 if k == "dL_dmeans3D" else 0)
 
 
 @pytest.mark.parametrize("variant", ["light", "full"])

@@ -4,7 +4,7 @@ The integer path must be bit-exact and images / stage-isolated gradients inside 
 import numpy as np
 import pytest
 
-from util import assert_grad_close, assert_image_close, make_scene
+from util import assert_grad_close, assert_image_close, make_scene, mask_flipped_pixels
 import hip_helpers as hh
 
 pytestmark = pytest.mark.gpu
@@ -36,15 +36,16 @@ def test_random_scene(oracle, draw):
     npx = s.W * s.H
     for k in ("color", "depth", "depth_median", "opacity_map"):
         assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx))  # small images: one flipped pixel
-    if not np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib")):
-        return  # a flipped termination: the backward would be compared on different lists
     grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+    # a flipped termination: that pixel's incoming gradients are zeroed on both sides, everything else is compared
+    grads, _ = mask_flipped_pixels(grads, hh.hip_state("n_contrib", s, d), st.get("n_contrib"), s.W, s.H, "random light",
+                                   images=[(d[k], ref[k]) for k in ("color", "depth", "depth_median", "opacity_map")])
     g = hh.hip_backward(s, deg, out, grads=grads, alphas=ref["opacity_map"], scale_modifier=sm)
     gr = hh.oracle_backward(oracle, st, s, deg, ref["opacity_map"], grads=grads, scale_modifier=sm)
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dview"):
         # one pixel's median-depth term may land on the neighbouring Gaussian (the backward re-derives T by division; its
         # T > 0.5 test is a hard threshold like the others): two rows of dL_dmeans3D, nothing else
-        rows = 2 if k == "dL_dmeans3D" else (1 if g[k].ndim > 1 and k != "dL_dview" else 0)
+        rows = 2 if k == "dL_dmeans3D" else 0
         assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=rows)
 
 
@@ -63,16 +64,17 @@ def test_random_scene_full_variant(oracle, draw):
     deg, npx = draw["deg"], draw["W"] * draw["H"]
     grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gV))
     out, d = hh.hip_full_forward(s, deg)
-    g = hh.hip_full_backward(s, deg, out, grads=grads)
-    st, ref, gr = hh.oracle_full(oracle, s, deg, grads=grads)
+    st, ref, _ = hh.oracle_full(oracle, s, deg, backward=False)
     assert np.array_equal(d["radii"], ref["radii"]) and d["num_rendered"] == ref["num_rendered"]
     assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
     for k in ("color", "depth", "uncertainty"):
         assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx))
-    if not np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib")):
-        return
+    grads, _ = mask_flipped_pixels(grads, hh.hip_state("n_contrib", s, d), st.get("n_contrib"), s.W, s.H, "random full",
+                                   images=[(d[k], ref[k]) for k in ("color", "depth", "uncertainty")])
+    g = hh.hip_full_backward(s, deg, out, grads=grads)
+    gr = hh.oracle_full_backward(oracle, st, s, deg, grads=grads)
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
-        assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=1)
+        assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=0)
     assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=1e-4, elem_rtol=5e-3, elem_frac=0.1)
 
 
@@ -140,17 +142,26 @@ def test_degenerate_inputs_full(oracle):
     npx = s.W * s.H
     grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gV))
     out, d = hh.hip_full_forward(s, 2)
-    g = hh.hip_full_backward(s, 2, out, grads=grads)
-    st, ref, gr = hh.oracle_full(oracle, s, 2, grads=grads)
+    st, ref, _ = hh.oracle_full(oracle, s, 2, backward=False)
     assert np.array_equal(d["radii"], ref["radii"]) and d["num_rendered"] == ref["num_rendered"]
     assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
     for k in ("color", "depth", "uncertainty"):
         assert np.all(np.isfinite(d[k]))
         assert_image_close(d[k], ref[k], k, max_outliers=2.0 / npx)
-    if not np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib")):
-        return
+    grads, _ = mask_flipped_pixels(grads, hh.hip_state("n_contrib", s, d), st.get("n_contrib"), s.W, s.H, "degenerate full")
+    g = hh.hip_full_backward(s, 2, out, grads=grads)
+    gr = hh.oracle_full_backward(oracle, st, s, 2, grads=grads)
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
         assert np.array_equal(np.isfinite(g[k]), np.isfinite(gr[k])), k
         ok = np.isfinite(gr[k])
         assert_grad_close(np.where(ok, g[k], 0), np.where(ok, gr[k], 0), k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3,
                           outlier_rows=1)
+
+
+def test_flip_masking_stayed_rare():
+    """Bookkeeping for the draws above (runs last in this file): how many gradient comparisons needed pixels masked."""
+    from util import FLIP_LOG
+    draws = [e for e in FLIP_LOG if e[0].startswith(("random", "degenerate"))]
+    masked = [e for e in draws if e[1] > 0]
+    print(f"\n[flip log] {len(draws)} gradient comparisons, {len(masked)} with masked pixels: {masked}")
+    assert len(draws) >= 20 and len(masked) <= max(1, len(draws) // 5)
