@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--variant", default="light", choices=["light", "full"],
                     help="light = the headline (config 3); full = the -full flavour (use with --workload config2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-runs", type=int, default=3)
+    ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--views-in-flight", type=int, default=3,
                     help="independent views (forward+backward each) issued round-robin on this many HIP streams: the "
                          "atomic- and latency-bound binning kernels of one view run under the VALU-bound blend kernels "
@@ -90,10 +90,10 @@ def main():
     ap.add_argument("--tight-cull", action="store_true",
                     help="opt-in alpha-aware tile rectangles (same images and gradients, NOT the reference's integer "
                          "path: num_rendered and the tile lists shrink); off for the headline number")
-    ap.add_argument("--views-per-allreduce", type=int, default=0,
+    ap.add_argument("--views-per-allreduce", type=int, default=1,
                     help="N>1: local views whose gradient arenas are summed before ONE all-reduce (global batch = this "
-                         "many views per GPU); 0 = 4 (BASELINE config 5: 32 views over 8 GPUs), 1 = an all-reduce after "
-                         "every view (config 4)")
+                         "many views per GPU); 1 (default) = BASELINE config 4's pattern, one view per GPU and one fused "
+                         "all-reduce after every view; 4 = config 5's (32 views over 8 GPUs)")
     ap.add_argument("--allreduce", default="blocking", choices=["overlap", "blocking"],
                     help="N>1: blocking = the view's stream waits for its gradient all-reduce (with several views in "
                          "flight the other streams keep rendering under it); overlap = additionally defer the wait to "
@@ -103,13 +103,14 @@ def main():
                          "strict: one blocking status read per forward, like the reference")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("DGR_BENCH_SPAWN") == "1"):
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU, RCCL rendezvous on
+        # 127.0.0.1) through torch.distributed.run, exactly as the driver's own launch line does
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        assert world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-        if args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path")
     if os.environ.get("DGR_BENCH_SHARE_GPU") == "1":
@@ -165,7 +166,7 @@ def main():
     arena = GradientArena(params) if dist is not None else None
 
     pending = [None]
-    G = args.views_per_allreduce if args.views_per_allreduce > 0 else 4  # BASELINE config 5: 4 views per GPU and step
+    G = max(1, args.views_per_allreduce)
     grouped = GroupedReduce(arena, dist, G) if (arena is not None and G > 1) else None
 
     def step():
@@ -226,19 +227,22 @@ def main():
     # calibration pass (untimed): every stage bracketed, to find the dominant kernel
     _capi.set_option("profile_every", 1)
     _capi.profile_select("all")
-    for _ in range(3):
+    for _ in range(8):
         radii = step()
+    drain()
     torch.cuda.synchronize(dev)
-    stage_ms = {}
+    stage_ms, stage_n = {}, {}
     for st_name in _capi.profile_stages():
         tot, n = _capi.profile_read(st_name)
         if n:
             stage_ms[st_name] = tot / n
+            stage_n[st_name] = n
     dominant = max(stage_ms, key=stage_ms.get)
-    # during the timed region only the dominant kernel is bracketed, and only every 8th launch: the two events ride in
-    # the kernel's dispatch packet and cost a little of the overlap between streams when attached to every launch
+    # during the timed region only the dominant kernel is bracketed, on ~16 of its launches whatever --steps is: the two
+    # events ride in the kernel's dispatch packet and cost a little of the overlap between streams when attached to
+    # every launch
     _capi.profile_select(dominant)
-    _capi.set_option("profile_every", 8)
+    _capi.set_option("profile_every", max(1, args.steps // 16))
 
     if args.graph:
         if dist is not None:
@@ -274,6 +278,11 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    rank_gpus = [torch.cuda.current_device()]
+    if dist is not None:
+        ids = [None] * world
+        dist.all_gather_object(ids, (rank, torch.cuda.current_device(), torch.cuda.get_device_name(dev)))
+        rank_gpus = ids
     if rank == 0:
         V = int((radii > 0).sum().item())
         R = int(_capi_last_num_rendered(P, H, W, dev))
@@ -297,7 +306,9 @@ def main():
         if not live:  # hipGraph replay: the launches are inside the graphs, nothing is bracketed live
             dom_ms = stage_ms[dominant]
         abytes = algorithmic_bytes(dominant, P, V, R, N, 16)
-        achieved = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        iso_ms = stage_ms[dominant]  # the kernel with nothing else on the GPU (calibration pass, one view at a time):
+        achieved = abytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0  # what a rocprofv3 kernel trace reproduces
+        overlap = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0   # the same kernel sharing the GPU with the other streams
         traffic = None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):
@@ -320,11 +331,18 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
                                    f"fwd+bwd incl. viewmatrix gradient, one view per step, {K} independent views in flight per GPU"
+                                   + ("" if dist is None else f"; {world} GPUs, rank r renders view r of the same Gaussians (weak scaling, the "
+                                      f"per-GPU view is the N=1 workload), exchange pattern of BASELINE config "
+                                      f"{'4: one fused all-reduce of the Gaussian gradients after every view' if G == 1 else '5: one fused all-reduce per ' + str(G) + ' local views'}")
                                    + (" -- TRACKING step: pose gradient only (map_off), not the headline mapping step" if args.tracking else ""), "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
                        "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "hipgraph_replay": bool(args.graph),
                        "pair_evals_per_view": pair_evals,
                        "pair_evals_per_s": None if pair_evals is None else pair_evals * views_per_s / world, "tight_cull": bool(args.tight_cull),
+                       "view_hbm_frac_one_stream": None if not serial_ms else
+                                                   (316 * P + 566 * V + 172 * R + 72 * N) / (serial_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                       "rccl_ranks": None if dist is None else dist.get_world_size(),
+                       "rank_gpus": rank_gpus,
                        "gradient_allreduce": (None if dist is None else
                                               f"one fused RCCL sum of 248 B/Gaussian per {G} local view(s)"
                                               + ("" if G > 1 else f" ({args.allreduce})")),
@@ -333,10 +351,13 @@ def main():
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": abytes,
-                         "avg_ms": dom_ms, "launches": dom_n, "measured_in_timed_region": live,
-                         # the same kernel with nothing else on the GPU (calibration pass, one view at a time)
-                         "isolated_avg_ms": stage_ms[dominant],
-                         "isolated_frac": abytes / (stage_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "avg_ms": iso_ms, "launches": stage_n[dominant],
+                         "how": "HIP events in the kernel's dispatch packet, on the launching stream; `frac` is the kernel alone "
+                                "on the GPU (untimed calibration pass, one view at a time: the figure profiles/*_kernel_stats.txt "
+                                "reproduces); `*_under_overlap` is the same kernel over the timed region, where it shares the "
+                                "CUs with the other streams' kernels",
+                         "frac_under_overlap": overlap / HBM_PEAK_GBS, "avg_ms_under_overlap": dom_ms,
+                         "launches_under_overlap": dom_n, "measured_in_timed_region": live},
         }
         if not args.no_cpu_baseline and args.variant == "light" and world == 1:  # (the CPU baseline: rank 0 at N = 1 only)
             line["cpu_baseline"], ref_grads = cpu_baseline(s, deg, args.cpu_runs)
@@ -366,45 +387,98 @@ def main():
         print(json.dumps(line), flush=True)
 
 
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("DGR_BENCH_SPAWN", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    if "--gpus" not in " ".join(sys.argv[1:]):
+        cmd += ["--gpus", str(n)]
+    return subprocess.call(cmd, env=env)
+
+
 def _capi_last_num_rendered(P, H, W, dev):
     from dgr_amd import light
     return light._capacity_cache.get((dev.index, P, H, W), 0)
 
 
-def cpu_baseline(s, deg, runs):
-    """The CPU oracle (OpenMP restatement of the reference path) timed on this host: full forward+backward of
-    the same view, `runs` repetitions after one warm-up.  A reported baseline, not the thing measured above."""
-    from oracle import oracle as O
-    O.build()
-
-    grads = {}
-
-    def once():
-        st, out = O.light_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj,
-                                  s.tanfovx, s.tanfovy, s.H, s.W, s.shs, deg, s.campos)
-        g = O.light_backward(st, s.bg, s.means, None, s.scales, s.rots, 1.0, None, s.view, s.proj, s.tanfovx, s.tanfovy,
-                             s.gC, s.gD, s.gM, s.gV, s.gt, s.shs, deg, s.campos, out["opacity_map"], s.persp)
-        grads.update(g)
-
-    once()
-    ts = []
-    for _ in range(max(runs, 1)):
-        t0 = time.perf_counter()
-        once()
-        ts.append(time.perf_counter() - t0)
-    med = float(np.median(ts))
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    cpu = "unknown"
+def host_cpu():
+    """(model name, sockets, physical cores, hardware threads) from /proc/cpuinfo."""
+    model, cores, threads = "unknown", set(), 0
     try:
+        phys = core = None
         for ln in open("/proc/cpuinfo"):
-            if ln.startswith("model name"):
-                cpu = ln.split(":", 1)[1].strip()
-                break
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif k == "processor":
+                threads += 1
+            elif not k and phys is not None:
+                cores.add((phys, core))
+                phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
     except OSError:
         pass
+    sockets = len({p for p, _ in cores}) or 1
+    ncores = len(cores) or (os.cpu_count() or 1)
+    try:
+        ncores = min(ncores, len(os.sched_getaffinity(0)))  # a container may expose fewer CPUs than the host lists
+    except AttributeError:
+        pass
+    return model, sockets, ncores, threads or (os.cpu_count() or 1)
+
+
+def cpu_baseline(s, deg, runs):
+    """The CPU oracle (OpenMP restatement of the reference path) timed on this host as BASELINE.md s3 prescribes: built
+    -O3 -march=native here, OMP threads = physical cores, 1 warm-up + `runs` repetitions of the full view, forward and
+    backward timed separately.  A reported baseline, not the thing measured above."""
+    from oracle import oracle as O
+    model, sockets, cores, threads = host_cpu()
+    O.build()
+    O.use_native(True)
+    O.set_threads(cores)
+    grads = {}
+    tf, tb = [], []
+
+    def once(record):
+        t0 = time.perf_counter()
+        st, out = O.light_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj,
+                                  s.tanfovx, s.tanfovy, s.H, s.W, s.shs, deg, s.campos)
+        t1 = time.perf_counter()
+        g = O.light_backward(st, s.bg, s.means, None, s.scales, s.rots, 1.0, None, s.view, s.proj, s.tanfovx, s.tanfovy,
+                             s.gC, s.gD, s.gM, s.gV, s.gt, s.shs, deg, s.campos, out["opacity_map"], s.persp)
+        t2 = time.perf_counter()
+        grads.update(g)
+        if record:
+            tf.append(t1 - t0)
+            tb.append(t2 - t1)
+
+    try:
+        once(False)
+        for _ in range(max(runs, 1)):
+            once(True)
+    finally:
+        O.use_native(False)
+    tot = [a + b for a, b in zip(tf, tb)]
+    med = float(np.median(tot))
     return {"value": 1.0 / med / 1e6, "unit": "Mviews/s", "cores": cores, "kind": "port",
-            "sample": f"{len(ts)} full fwd+bwd views of the same workload after 1 warm-up, median {med:.3f} s "
-                      f"(min {min(ts):.3f} s), OpenMP on {cpu}"}, grads
+            "host": {"cpu": model, "sockets": sockets, "physical_cores": cores, "hardware_threads": threads,
+                     "omp_threads": cores},
+            "sample": f"{len(tot)} full fwd+bwd views of the same workload after 1 warm-up: median {med:.3f} s (min "
+                      f"{min(tot):.3f} s; forward median {float(np.median(tf)):.3f} s, backward {float(np.median(tb)):.3f} s), "
+                      f"oracle built -O3 -march=native, {cores} OpenMP threads = physical cores of {sockets} x {model}"}, grads
 
 
 if __name__ == "__main__":

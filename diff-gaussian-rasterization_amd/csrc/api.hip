@@ -48,7 +48,8 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // num_rendered) waits for a copy issued at that point instead of for the whole forward.
 struct EarlyStatus {
     bool armed = false, pending = false;
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr;   // an event belongs to the device that was current when it was created:
+    int ev_device = -1;        // re-created when this thread moves to another device
     int* pinned = nullptr;
 };
 thread_local EarlyStatus g_early;
@@ -56,10 +57,15 @@ thread_local EarlyStatus g_early;
 int early_status_post(const int* device_status, hipStream_t st) {
     if (!g_early.armed) return DGR_OK;
     g_early.armed = false;
-    if (!g_early.ev) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!g_early.ev || g_early.ev_device != dev) {
+        if (g_early.ev) HIP_TRY(hipEventDestroy(g_early.ev));
+        g_early.ev = nullptr;
         HIP_TRY(hipEventCreateWithFlags(&g_early.ev, hipEventDisableTiming));
-        HIP_TRY(hipHostMalloc((void**)&g_early.pinned, 4 * sizeof(int), hipHostMallocDefault));
+        g_early.ev_device = dev;
     }
+    if (!g_early.pinned) HIP_TRY(hipHostMalloc((void**)&g_early.pinned, 4 * sizeof(int), hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(g_early.pinned, device_status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(g_early.ev, st));
     g_early.pending = true;

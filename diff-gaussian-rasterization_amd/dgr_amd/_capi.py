@@ -108,11 +108,32 @@ def ptr(t):
 
 
 def stream_handle(device_index=None):
-    """Raw handle of the current HIP stream (the private torch binding is ~20x cheaper than building a Stream object)."""
+    """Raw handle of torch's current HIP stream ON THE GIVEN DEVICE -- pass the index of the device the tensors live on
+    (the private torch binding is ~20x cheaper than building a Stream object)."""
     try:
         return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device() if device_index is None else device_index)
     except AttributeError:  # pragma: no cover -- other torch builds
-        return torch.cuda.current_stream().cuda_stream
+        return torch.cuda.current_stream(device_index).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(dev):
+    """Context manager that makes `dev` the current HIP device for the C-ABI calls inside it (kernels are launched on
+    a stream of `dev` against pointers of `dev`; the library's events and workspaces are created on the current
+    device).  Free when `dev` already is current."""
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
 
 
 def set_option(name, value):

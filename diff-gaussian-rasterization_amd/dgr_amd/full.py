@@ -23,10 +23,22 @@ def set_tight_culling(on=True):
     _capi.set_option("tight_cull", 1 if on else 0)
 
 
+def _device_guarded(arg_index):
+    """Runs a `_C` function with its tensors' device current (kernels, events and the stream handle all belong to the
+    device of `means3D`, whichever device the caller had selected)."""
+    def deco(fn):
+        def wrapped(*a, **kw):
+            with _capi.on_device(a[arg_index].device):
+                return fn(*a, **kw)
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return staticmethod(wrapped)
+    return deco
+
+
 class _C:
     """Functions with the signatures of the full variant's pybind11 module (F/ext.cpp:15-19)."""
 
-    @staticmethod
+    @_device_guarded(1)
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                             cov3D_precomp, viewmatrix, gt_depth, projmatrix, tan_fovx, tan_fovy,
                             image_height, image_width, sh, degree, campos, prefiltered):
@@ -51,7 +63,7 @@ class _C:
         out_depth = torch.empty((1, H, W), **f32)
         out_unc = torch.empty((1, H, W), **f32)
         radii = torch.zeros((P,), **i32)
-        st = _capi.stream_handle()
+        st = _capi.stream_handle(dev.index)
         p = _capi.ptr
         common = (P, int(degree), M, p(background), W, H, p(means3D), p(sh), p(colors), p(opacity), p(scales),
                   float(scale_modifier), p(rotations), p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos),
@@ -111,7 +123,7 @@ class _C:
                 cap = int(rendered * 1.1) + 4096
         return rendered, related, out_color, out_depth, out_unc, radii, geomBuffer, binningBuffer, imgBuffer
 
-    @staticmethod
+    @_device_guarded(1)
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, viewmatrix, gt_depth, projmatrix, tan_fovx, tan_fovy,
                                      dL_dout_color, dL_dout_depth, dL_dout_uncertainty, sh, degree, campos, geomBuffer,
@@ -136,7 +148,7 @@ class _C:
         scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes(P, W, H), 1),), dtype=torch.uint8, device=dev)
         p = lambda t: None if t is None else _capi.ptr(t)  # noqa: E731
         _check(lib.dgr_full_backward(
-            _capi.stream_handle(), P, int(degree), M, int(R), p(background), W, H, p(means3D), p(sh), p(colors),
+            _capi.stream_handle(dev.index), P, int(degree), M, int(R), p(background), W, H, p(means3D), p(sh), p(colors),
             p(scales), float(scale_modifier), p(rotations), p(cov3D_precomp), p(viewmatrix), p(projmatrix), p(campos),
             float(tan_fovx), float(tan_fovy), p(radii), p(geomBuffer), p(binningBuffer), p(imageBuffer), p(gC), p(gD),
             p(seg["means2D"]), None, p(seg["opacity"]), p(seg["colors"]), p(seg["means3D"]), p(seg["cov3D"]),
@@ -145,7 +157,7 @@ class _C:
         return (seg["means2D"], seg["colors"], seg["opacity"], seg["means3D"], seg["cov3D"], seg["sh"], seg["scales"],
                 seg["rotations"], dL_dview)
 
-    @staticmethod
+    @_device_guarded(0)
     def mark_visible(means3D, viewmatrix, projmatrix):
         from .light import _C as _LC
         return _LC.mark_visible(means3D, viewmatrix, projmatrix)

@@ -13,6 +13,8 @@ to a caller of the autograd surface:
 """
 import ctypes as C
 import os
+import threading
+import weakref
 from typing import NamedTuple
 
 import torch
@@ -57,12 +59,14 @@ def _sync_mode():
 
 # Status words of forwards recorded into a hipGraph (torch.cuda.graph): nothing can be read back while capturing, so the
 # device tensors are kept and inspected on request after a replay (check_captured_status()).
-_captured_status = []
+_captured_status = []     # weak references: a status word lives as long as the capture that owns it
+_capture_keepalive = []   # strong references collected during ONE capture; CapturedStep takes them over
 
 
 def _post_status(status, key):
     if torch.cuda.is_current_stream_capturing():
-        _captured_status.append(status)
+        _captured_status.append(weakref.ref(status))  # kept alive by the captured step's results (CapturedStep.keep)
+        _capture_keepalive.append(status)
         return
     host = _pinned_pool.pop() if _pinned_pool else torch.empty((4,), dtype=torch.int32, pin_memory=True)
     host.copy_(status, non_blocking=True)
@@ -87,8 +91,13 @@ def _check_oldest():
 
 def check_captured_status():
     """After replaying a graph that contains forwards: raises if one of them overflowed its binning buffer (the graph
-    was captured with a smaller scene than it is replayed on) or hit the prefiltered trap.  Blocks on the device."""
-    for st in _captured_status:
+    was captured with a smaller scene than it is replayed on) or hit the prefiltered trap.  Blocks on the device.
+    Status words whose graph no longer exists (the tensor's storage was freed with the graph's pool) are dropped."""
+    _captured_status[:] = [r for r in _captured_status if r() is not None]
+    for ref in _captured_status:
+        st = ref()
+        if st is None:
+            continue
         s = st.tolist()
         if s[2]:
             raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
@@ -103,8 +112,18 @@ def check_async_errors():
         _check_oldest()
 
 
-# (flat gradient arena of the most recent backward, number of leading floats that are parameter gradients)
-_last_arena = None
+# (weak reference to the flat gradient arena of this THREAD's most recent backward, number of leading floats that are
+# parameter gradients).  Weak: the arena lives exactly as long as the gradients that are views of it.
+_tls = threading.local()
+
+
+def last_arena():
+    """(arena, n) of the calling thread's most recent backward, or None once its gradients have been released."""
+    rec = getattr(_tls, "arena", None)
+    if rec is None:
+        return None
+    arena = rec[0]()
+    return None if arena is None else (arena, rec[1], rec[2])
 
 
 def _grad_arena(P, M, f32):
@@ -112,7 +131,6 @@ def _grad_arena(P, M, f32):
     mapping step all-reduces across GPUs -- means3D, means2D, sh, opacity, scales, rotations -- are one
     contiguous span (dgr_amd.multiview.GradientArena).  Every row is written by the kernels (zeros for
     invisible Gaussians), so the arena is not zero-filled."""
-    global _last_arena
     shapes = [("means3D", (P, 3)), ("means2D", (P, 3)), ("sh", (P, M, 3)), ("opacity", (P, 1)),
               ("scales", (P, 3)), ("rotations", (P, 4)), ("cov3D", (P, 6)), ("colors", (P, 3))]
     offs, o = {}, 0
@@ -123,17 +141,16 @@ def _grad_arena(P, M, f32):
         offs[name] = (o, n, shp)
         o += (n + 63) // 64 * 64  # 256-byte aligned segments (vector stores in the kernels)
     arena = (torch.empty if P else torch.zeros)((max(o, 1),), **f32)
-    _last_arena = (arena, offs["cov3D"][0])  # (flat buffer, length of the all-reduced span)
+    _tls.arena = (weakref.ref(arena), offs["cov3D"][0], offs)  # (flat buffer, length of the all-reduced span, layout)
     return {name: arena[a:a + n].view(shp) for name, (a, n, shp) in offs.items()}
 
 
-_early_buf = (C.c_int * 4)()
-
-
 def _early_status(lib):
-    """{num_rendered, -, prefiltered violation, -} of the presized forward just issued (include/dgr_hip.h: early status)."""
-    _check(lib.dgr_early_status_wait(_early_buf))
-    return list(_early_buf)
+    """{num_rendered, -, prefiltered violation, -} of the presized forward just issued (include/dgr_hip.h: early status).
+    The buffer is per call: ctypes releases the GIL during the wait, so a shared one could be read by another thread."""
+    buf = (C.c_int * 4)()
+    _check(lib.dgr_early_status_wait(buf))
+    return list(buf)
 
 
 def _check(rc):
@@ -153,10 +170,22 @@ def set_tight_culling(on=True):
     _capi.set_option("tight_cull", 1 if on else 0)
 
 
+def _device_guarded(arg_index):
+    """Runs a `_C` function with its tensors' device current (kernels, events and the stream handle all belong to the
+    device of `means3D`, whichever device the caller had selected)."""
+    def deco(fn):
+        def wrapped(*a, **kw):
+            with _capi.on_device(a[arg_index].device):
+                return fn(*a, **kw)
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return staticmethod(wrapped)
+    return deco
+
+
 class _C:
     """Functions with the signatures of the reference's pybind11 module `_C` (L/ext.cpp:15-19)."""
 
-    @staticmethod
+    @_device_guarded(1)
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                             cov3D_precomp, viewmatrix, gt_depth, projmatrix, tan_fovx, tan_fovy,
                             image_height, image_width, sh, degree, campos, prefiltered, debug):
@@ -188,7 +217,7 @@ class _C:
         gau_unc = mk((P, 1), **f32)
         gau_px = mk((P, 1), **i32)
         u8 = dict(dtype=torch.uint8, device=dev)
-        st = _capi.stream_handle()
+        st = _capi.stream_handle(dev.index)
         p = _capi.ptr
 
         common = (P, int(degree), M, p(background), W, H, p(means3D), p(sh), p(colors), p(opacity), p(scales),
@@ -245,7 +274,7 @@ class _C:
         return (rendered, out_color, out_depth, out_median, out_var, out_alpha, radii, geomBuffer, binningBuffer,
                 imgBuffer, gau_unc, gau_px)
 
-    @staticmethod
+    @_device_guarded(1)
     def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                      cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                      dL_dout_depth, dL_dout_median_depth, dL_dout_depth_var, gt_depth, sh, degree,
@@ -275,12 +304,14 @@ class _C:
         else:
             dL_dmeans3D = dL_dmeans2D = dL_dsh = dL_dopacity = dL_dscales = dL_drotations = dL_dcov3D = dL_dcolors = None
             map_off = True  # nobody reads the per-Gaussian sums: the blend kernel forms the three pose sums only
-        dL_dview = torch.empty((4, 4), **f32)
+        # [1,4,4]: the reference binding returns the per-pixel [H*W,4,4] buffer and its __init__.py sums dim 0
+        # (L/rasterize_points.cu:186,235, L/__init__.py:160-161); one already-reduced "pixel" keeps that code working
+        dL_dview = torch.empty((1, 4, 4), **f32)
         scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes(P, W, H), 1),), dtype=torch.uint8, device=dev)
         p = _capi.ptr
         q = lambda t: None if t is None else p(t)  # noqa: E731
         _check(lib.dgr_light_backward(
-            _capi.stream_handle(), P, int(degree), M, int(R), p(background), W, H, p(means3D), p(sh), p(colors),
+            _capi.stream_handle(dev.index), P, int(degree), M, int(R), p(background), W, H, p(means3D), p(sh), p(colors),
             p(alphas), p(scales), float(scale_modifier), p(rotations), p(cov3D_precomp), p(viewmatrix),
             p(projmatrix), p(campos), float(tan_fovx), float(tan_fovy), p(radii), p(geomBuffer), p(binningBuffer),
             p(imageBuffer), p(gC), p(gD), p(gM), p(gV), q(dL_dmeans2D), None, q(dL_dopacity), q(dL_dcolors), None,
@@ -290,7 +321,7 @@ class _C:
         return (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations,
                 dL_dview)
 
-    @staticmethod
+    @_device_guarded(0)
     def mark_visible(means3D, viewmatrix, projmatrix):
         # L/rasterize_points.cu:238-256
         lib = _capi.load()
@@ -299,7 +330,7 @@ class _C:
         present = torch.zeros((P,), dtype=torch.bool, device=dev)
         if P != 0:
             means3D, viewmatrix, projmatrix = _f32c(means3D, dev), _f32c(viewmatrix, dev), _f32c(projmatrix, dev)
-            _check(lib.dgr_mark_visible(_capi.stream_handle(), P, _capi.ptr(means3D), _capi.ptr(viewmatrix),
+            _check(lib.dgr_mark_visible(_capi.stream_handle(dev.index), P, _capi.ptr(means3D), _capi.ptr(viewmatrix),
                                         _capi.ptr(projmatrix), present.data_ptr()))
         return present
 
@@ -443,7 +474,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_viewmatrix) = out
         # reference: torch.sum(grad_viewmatrix, dim=0) over a [H*W,4,4] buffer (__init__.py:160-161);
-        # here grad_viewmatrix already is the reduced [4,4].
+        # here the buffer is [1,4,4], already reduced: a view instead of a reduction kernel.
+        grad_viewmatrix = grad_viewmatrix.view(4, 4)
 
         grads = (
             grad_means3D,

@@ -40,14 +40,39 @@ class ViewStreams:
         views.join()                           # the caller's stream waits for every view
 
     Every view keeps its own state buffers and gradient arena (they are allocated per call), so nothing is shared
-    between views in flight except the read-only inputs.  Leaf `.grad` accumulation across views is done by autograd
-    on the leaf's stream, as usual."""
+    between views in flight except the read-only inputs -- and the leaves' `.grad`.  PyTorch runs a leaf's
+    accumulation (`.grad += ...`) on the stream of the backward that reaches it, and nothing orders two views on two
+    streams that accumulate into the same `.grad`.  Two safe patterns:
+      * no accumulation across views: set `p.grad = None` before every view and collect the per-view gradients
+        yourself (`GroupedReduce` sums the views' arenas on one stream) -- what bench.py does;
+      * accumulation in `.grad`: call `views.before_backward()` between a view's forward and its `backward()`.  It makes
+        the view's stream wait for the END of the previous view, so backward passes run one after the other while a
+        view's forward (binning, atomics, sort: the kernels that leave the chip idle) still overlaps the previous
+        view's backward -- what `dgr_amd.slam.render_batch` does."""
+
+    class _View:
+        def __init__(self, owner, stream, prev_done):
+            self.owner, self.stream, self.prev_done = owner, stream, prev_done
+            self.ctx = torch.cuda.stream(stream)
+
+        def __enter__(self):
+            self.owner._current = self
+            return self.ctx.__enter__()
+
+        def __exit__(self, *exc):
+            done = torch.cuda.Event()
+            done.record(self.stream)
+            self.owner._done = done
+            self.owner._current = None
+            return self.ctx.__exit__(*exc)
 
     def __init__(self, n=3, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(n)))]
         self._i = 0
         self._fresh = set()  # streams already ordered after the caller's stream since the last join()
+        self._done = None    # event at the end of the most recent view
+        self._current = None
 
     def next(self):
         """Context manager: the next stream.  The first use of a stream after construction or join() is ordered after
@@ -59,7 +84,14 @@ class ViewStreams:
         if k not in self._fresh:
             st.wait_stream(torch.cuda.current_stream(self.device))
             self._fresh.add(k)
-        return torch.cuda.stream(st)
+        return ViewStreams._View(self, st, self._done)
+
+    def before_backward(self):
+        """Inside a `with views.next():` block, before `backward()`: orders this view's remaining work after the end of
+        the previous view, so that accumulation into a shared `.grad` is race-free (see the class docstring)."""
+        v = self._current
+        if v is not None and v.prev_done is not None:
+            v.stream.wait_event(v.prev_done)
 
     def join(self):
         """The caller's stream waits for every view issued so far."""
@@ -67,6 +99,7 @@ class ViewStreams:
         for st in self.streams:
             cur.wait_stream(st)
         self._fresh.clear()
+        self._done = None
 
 
 class CapturedStep:
@@ -108,8 +141,13 @@ class CapturedStep:
         self.stream = stream  # replay on this stream (None: the caller's current stream)
         if stream is not None:
             stream.wait_stream(torch.cuda.current_stream(dev))
+        del light._capture_keepalive[:]
         with torch.cuda.graph(self.graph, stream=stream):
             self.result = fn()
+        # the status words of the captured forwards live exactly as long as this object (light.check_captured_status
+        # holds weak references only)
+        self.keep = list(light._capture_keepalive)
+        del light._capture_keepalive[:]
 
     def replay(self):
         if self.stream is None:
@@ -131,16 +169,23 @@ class GradientArena:
         self.params = [p for p in params if p is not None]
 
     def fused_span(self):
-        """The flat span aliasing every parameter's .grad, or None if autograd copied instead of aliasing."""
-        if light._last_arena is None:
+        """The flat span aliasing every parameter's .grad (the arena of the calling thread's most recent backward), or
+        None if autograd copied or accumulated instead of aliasing."""
+        rec = light.last_arena()
+        if rec is None:
             return None
-        arena, n = light._last_arena
+        arena, n, _ = rec
         lo, hi = arena.data_ptr(), arena.data_ptr() + 4 * n
         for p in self.params:
             g = p.grad
             if g is None or not g.is_contiguous() or not (lo <= g.data_ptr() and g.data_ptr() + 4 * g.numel() <= hi):
                 return None
         return arena[:n]
+
+    def grad_offsets(self, span):
+        """[(parameter, first float of its gradient inside `span`)] -- how a reduced span maps back to the parameters."""
+        base = span.data_ptr()
+        return [(p, (p.grad.data_ptr() - base) // 4) for p in self.params]
 
     def all_reduce(self, dist, group=None, async_op=False):
         """Sums the gradients over the ranks.  Returns the number of collectives issued, or with `async_op` a
@@ -171,22 +216,34 @@ class PendingReduce:
 
 class GroupedReduce:
     """One all-reduce per GROUP of local views instead of one per view (fewer, larger collectives: the global batch is
-    `group_size` views per GPU).  Call `add_view()` right after a view's backward, on that view's stream; when the
-    group is full its gradient arenas are summed into the first one (on the current stream, after the other views'
-    streams) and that sum is all-reduced.  `flush()` reduces an incomplete group.  Views whose gradients autograd
-    copied instead of aliasing (no fused span) are reduced immediately, one by one."""
+    `group_size` views per GPU).  Protocol per view: set the parameters' `.grad` to None, run the view's backward, call
+    `add_view()` on that view's stream.  When the group is full its gradient arenas are summed into the first one (on
+    the current stream, after the other views' streams), that sum is all-reduced, and every parameter's `.grad` is
+    pointed at its slice of the reduced buffer, so an optimiser step after `flush()` sees the batch gradient.
+    `flush()` reduces an incomplete group.
+
+    A view whose gradients are not one fused arena (autograd accumulated into an existing `.grad`, or copied) cannot
+    join a group: summing or reducing an accumulating `.grad` again would count earlier views twice.  `add_view()`
+    raises in that case instead of guessing."""
 
     def __init__(self, arena, dist, group_size, group=None):
         self.arena, self.dist, self.n, self.group = arena, dist, max(1, int(group_size)), group
         self.pending = []   # [(span, event recorded on the producing stream)]
+        self.layout = None  # [(parameter, offset)] of the group's first view
         self.collectives = 0
         self.last_total = None
 
     def add_view(self):
         span = self.arena.fused_span()
         if span is None:
-            self.collectives += self.arena.all_reduce(self.dist, self.group)
-            return
+            raise RuntimeError(
+                "GroupedReduce.add_view: the parameters' .grad are not views of one gradient arena (autograd accumulated "
+                "into an existing .grad or copied): set p.grad = None before every view's backward")
+        layout = self.arena.grad_offsets(span)
+        if not self.pending:
+            self.layout = layout
+        elif [o for _, o in layout] != [o for _, o in self.layout]:
+            raise RuntimeError("GroupedReduce.add_view: views of one group must share the arena layout (same P and SH degree)")
         ev = torch.cuda.Event() if span.is_cuda else None
         if ev is not None:
             ev.record()
@@ -207,6 +264,8 @@ class GroupedReduce:
             total.add_(span)
         self.dist.all_reduce(total, op=self.dist.ReduceOp.SUM, group=self.group)
         self.collectives += 1
+        for p, off in self.layout:  # the batch gradient, where an optimiser looks for it
+            p.grad = total[off:off + p.numel()].view(p.shape)
         self.pending = []
         self.last_total = total
         return total

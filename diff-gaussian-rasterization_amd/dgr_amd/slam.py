@@ -237,21 +237,28 @@ def render_batch(cameras, pc, pipe, bg_color, loss_fn, views_in_flight=3, **rend
     """One mapping step over a batch of keyframes: every camera is rendered, `loss_fn(out, k)`
     is evaluated on its output dict and back-propagated, each view's forward + loss + backward on its own HIP stream
     (`dgr_amd.multiview.ViewStreams`) so that the views overlap on the GPU; gradients accumulate in the `.grad` of the
-    Gaussian parameters as usual.  `cameras`: sequence of dicts with `viewmatrix` (W2C^T), `fov`, `HW` and optionally
-    `gt_depth`, `viewpoint_camera`.  Returns the list of detached loss values (device tensors); the caller's stream is
-    ordered after all views on return."""
+    Gaussian parameters as usual.  Accumulation into a shared `.grad` from several streams needs an explicit order
+    (PyTorch gives none): every view's backward waits for the end of the previous view (`views.before_backward()`), its
+    forward and loss still overlap the previous view's backward.  `cameras`: sequence of dicts with `viewmatrix`
+    (W2C^T), `fov`, `HW` and optionally `gt_depth`, `viewpoint_camera`.  Returns the list of detached loss values
+    (device tensors); the caller's stream is ordered after all views on return."""
     from .multiview import ViewStreams
     cameras = list(cameras)
     if not cameras:
         return []
     views = ViewStreams(min(max(1, views_in_flight), len(cameras)), cameras[0]["viewmatrix"].device)
+
+    def one_view(k, cam):  # (a function: no autograd graph of one view is kept alive into the next)
+        out = render(cam.get("viewpoint_camera"), pc, pipe, bg_color, viewmatrix=cam["viewmatrix"], fov=cam["fov"],
+                     HW=cam["HW"], gt_depth=cam.get("gt_depth"), **render_kwargs)
+        loss = loss_fn(out, k)
+        views.before_backward()
+        loss.backward()
+        return loss.detach()
+
     losses = []
     for k, cam in enumerate(cameras):
         with views.next():
-            out = render(cam.get("viewpoint_camera"), pc, pipe, bg_color, viewmatrix=cam["viewmatrix"], fov=cam["fov"],
-                         HW=cam["HW"], gt_depth=cam.get("gt_depth"), **render_kwargs)
-            loss = loss_fn(out, k)
-            loss.backward()
-            losses.append(loss.detach())
+            losses.append(one_view(k, cam))
     views.join()
     return losses

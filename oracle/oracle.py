@@ -17,11 +17,37 @@ _LIBS = {}
 #                         reference -- reproduces SURVEY.md Appendix C digit for digit.
 # use_cmath(True) / DGR_ORACLE_CMATH=1 selects the second one for subsequently created states.
 _CMATH = os.environ.get("DGR_ORACLE_CMATH") == "1"
+_NATIVE = False
 
 
 def use_cmath(flag):
     global _CMATH
     _CMATH = bool(flag)
+
+
+def use_native(flag):
+    """cpu_baseline leg of bench.py only: the same source built `-O3 -march=native` ON THE MACHINE THAT RUNS IT
+    (BASELINE.md s3.1); never the checker."""
+    global _NATIVE
+    _NATIVE = bool(flag)
+
+
+def build_native():
+    import platform
+    import tempfile
+    src = os.path.join(_HERE, "dgr_oracle.cpp")
+    out = os.path.join(tempfile.gettempdir(), f"libdgr_oracle_native_{platform.node()}_{int(os.path.getmtime(src))}.so")
+    if not os.path.exists(out):
+        subprocess.check_call(["g++", "-std=c++17", "-O3", "-march=native", "-ffp-contract=off", "-fopenmp", "-fPIC",
+                               "-Wno-unknown-pragmas", "-shared", "-o", out + ".tmp", src])
+        os.replace(out + ".tmp", out)
+    return out
+
+
+def set_threads(n):
+    """OpenMP threads of the oracle's runtime (libgomp is already initialised once torch or the library is loaded, so
+    the environment variable alone would come too late)."""
+    C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
 
 
 def build(force=False):
@@ -34,8 +60,10 @@ def build(force=False):
 
 def lib(cmath=None):
     cmath = _CMATH if cmath is None else bool(cmath)
+    if _NATIVE:
+        cmath = "native"
     if cmath not in _LIBS:
-        l = C.CDLL(build()[1 if cmath else 0])
+        l = C.CDLL(build_native() if cmath == "native" else build()[1 if cmath else 0])
         l.dgro_state_new.restype = C.c_void_p
         l.dgro_state_free.argtypes = [C.c_void_p]
         l.dgro_state_get.restype = C.c_long

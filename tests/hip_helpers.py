@@ -101,6 +101,8 @@ def hip_backward(s, deg, out, colors_precomp=None, cov3D_precomp=None, track_off
         T(s.campos), geom, R, binning, img, alpha, False, T(s.persp), track_off, map_off)
     names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
              "dL_drotations", "dL_dview"]
+    assert tuple(g[8].shape) == (1, 4, 4)  # what the reference's own __init__.py sums over dim 0
+    g = list(g[:8]) + [torch.sum(g[8], dim=0)]
     return {n: v.cpu().numpy() for n, v in zip(names, g)}
 
 

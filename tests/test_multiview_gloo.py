@@ -111,20 +111,37 @@ def worker_grouped(rank, world, port, q):
     from dgr_amd.multiview import GradientArena, GroupedReduce
     P, W, H, deg = 800, 48, 32, 2
     f32 = dict(dtype=torch.float32, device="cpu")
-    params = [torch.zeros((P, 3), requires_grad=True) for _ in NAMES]  # shapes are irrelevant to the exchange
-    arena = GradientArena([])
+    shapes = dict(means3D=(P, 3), means2D=(P, 3), sh=(P, 16, 3), opacity=(P, 1), scales=(P, 3), rotations=(P, 4))
+    params = [torch.zeros(shapes[n], requires_grad=True) for n in NAMES]  # real leaf parameters
+    opt = torch.optim.SGD(params, lr=0.5)
+    arena = GradientArena(params)
     grouped = GroupedReduce(arena, dist, group_size=2)
     for local in range(2):  # two local views per rank: views 2*rank, 2*rank + 1
         g = view_grads(P, W, H, deg, 2 * rank + local)
-        seg = light._grad_arena(P, 16, f32)  # (sets light._last_arena, as a backward does)
-        for n in NAMES:
-            seg[n].copy_(torch.from_numpy(g[GKEY[n]]))
+        for p in params:
+            p.grad = None
+        seg = light._grad_arena(P, 16, f32)  # what a backward does: a fresh arena ...
+        for n, p in zip(NAMES, params):
+            seg[n].copy_(torch.from_numpy(g[GKEY[n]]).reshape(shapes[n]))
+            p.grad = seg[n]                   # ... whose views autograd hands to .grad without copying
         grouped.add_view()
         if local == 0:
-            first = seg
             assert grouped.collectives == 0  # nothing reduced before the group is complete
     assert grouped.collectives == 1 and not grouped.pending
-    q.put((rank, {n: first[n].numpy().copy() for n in NAMES}))
+    # the batch gradient is where an optimiser looks for it
+    batch = {n: p.grad.numpy().copy() for n, p in zip(NAMES, params)}
+    opt.step()
+    stepped = {n: p.detach().numpy().copy() for n, p in zip(NAMES, params)}
+    # a view that accumulated into an existing .grad instead of aliasing a fresh arena must be refused, not double counted
+    refused = False
+    seg = light._grad_arena(P, 16, f32)
+    for n, p in zip(NAMES, params):
+        p.grad = p.grad + seg[n].zero_()  # (an accumulated gradient: its own storage)
+    try:
+        grouped.add_view()
+    except RuntimeError:
+        refused = True
+    q.put((rank, batch, stepped, refused))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -143,7 +160,9 @@ def test_grouped_reduce_sums_local_views_then_one_collective(oracle):
         assert p.exitcode == 0
     sys.path[:0] = [ROOT, PKG]
     serial = [view_grads(800, 48, 32, 2, k) for k in range(4)]
-    for rank, grads in res:
+    for rank, batch, stepped, refused in res:
+        assert refused
         for n in NAMES:
-            want = sum(sv[GKEY[n]].astype(np.float64) for sv in serial)
-            np.testing.assert_allclose(grads[n], want.reshape(grads[n].shape), rtol=2e-5, atol=1e-8)  # float32 sums of four views
+            want = sum(sv[GKEY[n]].astype(np.float64) for sv in serial).reshape(batch[n].shape)
+            np.testing.assert_allclose(batch[n], want, rtol=2e-5, atol=1e-8)  # float32 sums of four views
+            np.testing.assert_allclose(stepped[n], -0.5 * want, rtol=2e-5, atol=1e-8)  # SGD step from zeros, lr 0.5
