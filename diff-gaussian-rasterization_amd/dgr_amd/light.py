@@ -13,7 +13,6 @@ to a caller of the autograd surface:
 """
 import ctypes as C
 import os
-import threading
 import weakref
 from typing import NamedTuple
 
@@ -112,18 +111,10 @@ def check_async_errors():
         _check_oldest()
 
 
-# (weak reference to the flat gradient arena of this THREAD's most recent backward, number of leading floats that are
-# parameter gradients).  Weak: the arena lives exactly as long as the gradients that are views of it.
-_tls = threading.local()
-
-
-def last_arena():
-    """(arena, n) of the calling thread's most recent backward, or None once its gradients have been released."""
-    rec = getattr(_tls, "arena", None)
-    if rec is None:
-        return None
-    arena = rec[0]()
-    return None if arena is None else (arena, rec[1], rec[2])
+# The flat gradient arena of a backward is found through the gradients themselves (`p.grad._base`, see
+# dgr_amd.multiview.GradientArena): no module-level "last arena" is kept, so nothing outlives the gradients and threads
+# cannot see each other's arenas.  SPAN_SEGMENTS names the leading segments that form the all-reduce payload.
+SPAN_SEGMENTS = ("means3D", "means2D", "sh", "opacity", "scales", "rotations")
 
 
 def _grad_arena(P, M, f32):
@@ -141,7 +132,6 @@ def _grad_arena(P, M, f32):
         offs[name] = (o, n, shp)
         o += (n + 63) // 64 * 64  # 256-byte aligned segments (vector stores in the kernels)
     arena = (torch.empty if P else torch.zeros)((max(o, 1),), **f32)
-    _tls.arena = (weakref.ref(arena), offs["cov3D"][0], offs)  # (flat buffer, length of the all-reduced span, layout)
     return {name: arena[a:a + n].view(shp) for name, (a, n, shp) in offs.items()}
 
 

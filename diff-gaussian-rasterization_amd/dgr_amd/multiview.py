@@ -169,18 +169,26 @@ class GradientArena:
         self.params = [p for p in params if p is not None]
 
     def fused_span(self):
-        """The flat span aliasing every parameter's .grad (the arena of the calling thread's most recent backward), or
-        None if autograd copied or accumulated instead of aliasing."""
-        rec = light.last_arena()
-        if rec is None:
-            return None
-        arena, n, _ = rec
-        lo, hi = arena.data_ptr(), arena.data_ptr() + 4 * n
+        """The flat span covering every parameter's .grad when they are all contiguous pieces of ONE storage (the arena
+        of the backward that produced them), or None if autograd copied or accumulated instead of aliasing.  Found
+        through the gradients themselves: no module-level "last arena", nothing to go stale across threads."""
+        store, lo, hi = None, None, None
         for p in self.params:
             g = p.grad
-            if g is None or not g.is_contiguous() or not (lo <= g.data_ptr() and g.data_ptr() + 4 * g.numel() <= hi):
+            if g is None or not g.is_contiguous() or g.dtype is not torch.float32:
                 return None
-        return arena[:n]
+            st = g.untyped_storage()
+            if store is None:
+                store = st
+            elif st.data_ptr() != store.data_ptr():
+                return None
+            a = g.storage_offset()
+            lo = a if lo is None else min(lo, a)
+            hi = a + g.numel() if hi is None else max(hi, a + g.numel())
+        if store is None:
+            return None
+        g = self.params[0].grad
+        return torch.empty((0,), dtype=g.dtype, device=g.device).set_(store, lo, (hi - lo,))
 
     def grad_offsets(self, span):
         """[(parameter, first float of its gradient inside `span`)] -- how a reduced span maps back to the parameters."""

@@ -1116,10 +1116,11 @@ void renderBackwardFull(const State& st, const float* bg, const float* colors, c
 //  6 sum over quadrants of max over its four 4x4 blocks of [5]-type counts (iterations of a wave whose 16-lane rows
 //    walk one block's list each)               7 the same for [3]-type counts (backward)
 //  8 sum over tiles of max over 4 quadrants of [4]-type counts   9 the same for [2]
-void pairStats(const State& st, double* out, double* out2) {
+void pairStats(const State& st, double* out, double* out2, double* out3 = nullptr) {
     const int W = st.W, H = st.H;
     const int tiles = st.gx * st.gy;
     double acc[10] = {0};
+    double acc3[4] = {0};  // half tiles: 0 valid (16 wide x 8 high, Gaussian) pairs, 1 box-tested; 2/3 the same for 8 wide x 16 high
     double acc2[8] = {0};  // 0 valid (8x4, Gaussian) pairs, 1 tested, 2/3 wave iterations bwd/fwd with per-128-batch max over the
                            // two halves, 4/5 the same for four 4x4 rows, 6/7 for the whole quadrant (one list per wave)
 #pragma omp parallel for schedule(dynamic, 4)
@@ -1135,7 +1136,7 @@ void pairStats(const State& st, double* out, double* out2) {
             done[p] = !inside[p];
         }
         double loc[10] = {0};
-        double loc2[8] = {0};
+        double loc2[8] = {0}, loc3[4] = {0};
         int hb_valid[8] = {0}, hb_tested[8] = {0}, bb_valid[16] = {0}, bb_tested[16] = {0}, qb_valid[4] = {0}, qb_tested[4] = {0};
         auto close_batch = [&]() {
             for (int q = 0; q < 4; q++) {
@@ -1216,6 +1217,19 @@ void pairStats(const State& st, double* out, double* out2) {
                 if (v) { loc[3] += 1; b_valid[b]++; bb_valid[b]++; }
                 if (box && alive) { loc[5] += 1; b_tested[b]++; bb_tested[b]++; }
             }
+            for (int ht = 0; ht < 4; ht++) {  // half tiles: 0/1 top/bottom (16 x 8), 2/3 left/right (8 x 16)
+                const int x0 = ht == 3 ? 8 : 0, y0 = ht == 1 ? 8 : 0, wx = ht < 2 ? 16 : 8, wy = ht < 2 ? 8 : 16;
+                bool v = false, alive = false;
+                for (int yy = 0; yy < wy; yy++)
+                    for (int xx = 0; xx < wx; xx++) {
+                        const int p = (y0 + yy) * 16 + x0 + xx;
+                        v = v || blended[p];
+                        alive = alive || !done[p] || blended[p];
+                    }
+                const bool box = tau > 0 && lx + hx >= x0 && lx - hx <= x0 + wx - 1 && ly + hy >= y0 && ly - hy <= y0 + wy - 1;
+                if (v) loc3[ht < 2 ? 0 : 2] += 1;
+                if (box && alive) loc3[ht < 2 ? 1 : 3] += 1;
+            }
             for (int hb = 0; hb < 8; hb++) {  // 8 wide x 4 high halves of the quadrants
                 const int x0 = (hb & 1) * 8, y0 = (hb >> 1) * 4;
                 bool v = false, alive = false;
@@ -1247,15 +1261,18 @@ void pairStats(const State& st, double* out, double* out2) {
         {
             for (int i = 0; i < 10; i++) acc[i] += loc[i];
             for (int i = 0; i < 8; i++) acc2[i] += loc2[i];
+            for (int i = 0; i < 4; i++) acc3[i] += loc3[i];
         }
     }
     for (int i = 0; i < 10; i++) out[i] = acc[i];
     if (out2) for (int i = 0; i < 8; i++) out2[i] = acc2[i];
+    if (out3) for (int i = 0; i < 4; i++) out3[i] = acc3[i];
 }
 
 extern "C" {
 void dgro_pair_stats(void* st, double* out) { pairStats(*(State*)st, out, nullptr); }
 void dgro_pair_stats2(void* st, double* out, double* out2) { pairStats(*(State*)st, out, out2); }
+void dgro_pair_stats3(void* st, double* out, double* out2, double* out3) { pairStats(*(State*)st, out, out2, out3); }
 
 
 void* dgro_state_new() { return new State(); }

@@ -53,7 +53,7 @@ def test_empty_input_returns_zeros():
                                           hh.T(s.proj), s.tanfovx, s.tanfovy, hh.T(s.gC), hh.T(s.gD[None]), hh.T(s.gM[None]),
                                           hh.T(s.gV[None]), hh.T(s.gt), E(0, 16, 3), 3, hh.T(s.campos), out[7], 0, out[8],
                                           out[9], out[5], False, hh.T(s.persp), False, False)
-    assert g[8].shape == (4, 4) and float(g[8].abs().sum()) == 0.0 and g[3].shape == (0, 3)
+    assert g[8].shape == (1, 4, 4) and float(g[8].abs().sum()) == 0.0 and g[3].shape == (0, 3)
 
 
 def test_bad_means_shape_raises_like_the_reference():
