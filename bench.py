@@ -61,6 +61,7 @@ def algorithmic_bytes(stage, P, V, R, N, M):
         "scan_tiles": 8 * R,                                 # range detection
         "render_fwd": 44 * R + 36 * N,                       # id, xy, conic+opacity, rgb, depth per instance; gt in, images + n_contrib out
         "zero_scratch": 0,                                   # (no counterpart in the ideal model)
+        "zero_counters": 0,                                  # (likewise: the padded tile counters of the fused count)
         "render_bwd": 44 * R + 40 * R + 36 * N,              # instance data again + 10 gradient floats RMW per instance; 9 images in
         "preprocess_bwd": (103 + sh) * V + (56 + sh) * P,    # 295 V + 248 P at degree 3: per-visible inputs, dense outputs
     }

@@ -80,10 +80,10 @@ struct StageProf {
     unsigned seen = 0;  // launches of this stage since it was selected
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
-StageProf g_prof[] = {{"preprocess_fwd"}, {"scan_blocks"}, {"count_rank"}, {"scan_tiles"}, {"emit_instances"}, {"sort_tiles"},
-                      {"render_fwd"}, {"zero_scratch"}, {"render_bwd"}, {"preprocess_bwd"}};
-enum { ST_PRE_FWD, ST_SCAN_BLOCKS, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD, ST_ZERO, ST_RENDER_BWD, ST_PRE_BWD,
-       ST_COUNT };
+StageProf g_prof[] = {{"zero_counters"}, {"preprocess_fwd"}, {"scan_blocks"}, {"count_rank"}, {"scan_tiles"}, {"emit_instances"},
+                      {"sort_tiles"}, {"render_fwd"}, {"zero_scratch"}, {"render_bwd"}, {"preprocess_bwd"}};
+enum { ST_ZERO_FWD, ST_PRE_FWD, ST_SCAN_BLOCKS, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD, ST_ZERO, ST_RENDER_BWD,
+       ST_PRE_BWD, ST_COUNT };
 std::mutex g_prof_mu;
 std::atomic<int> g_profile_every{1};
 
@@ -149,11 +149,15 @@ int zero_outputs(const FwdCommon& c, hipStream_t st) {
     return DGR_OK;
 }
 
-// preprocess; afterwards geom.block_tiles holds the instance totals per 256-Gaussian block
-int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, hipStream_t st) {
+// preprocess.  Callback path (bin == nullptr): afterwards geom.block_tiles holds the instance totals per 256-Gaussian
+// block and scan_blocks turns them into offsets and num_rendered.  Presized path (the binning buffer exists already):
+// the kernel also takes the tile-counter atomics and stores the ranks (count_rank.h), behind one small clear of the
+// counters; scan_blocks and count_rank disappear.
+int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, hipStream_t st,
+                  const dgr::BinningView* bin = nullptr, int capacity = 0, char* image_base = nullptr) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
-    // No memsets: preprocess clears the tile counters and the per-Gaussian median statistics, scan_blocks
-    // initialises the status word.
+    // No memsets: preprocess clears the per-Gaussian median statistics (and, on the callback path, the tile counters);
+    // scan_blocks / scan_tiles initialise the status word.
     dgr::PreprocessFwdArgs a{};
     a.P = c.P; a.D = c.D; a.M = c.M; a.W = c.W; a.H = c.H; a.grid_x = gx; a.grid_y = gy;
     a.means3D = c.means3D; a.scales = c.scales; a.scale_modifier = c.scale_modifier; a.rotations = c.rotations;
@@ -166,21 +170,31 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
     a.tight_cull = g_tight_cull.load();
     a.sh_vec_ok = aligned16(c.shs);
     a.geom = geom; a.radii_out = c.radii;
-    a.zero_words = img.tile_count; a.n_zero_words = (int)(((char*)img.ranges - (char*)img.tile_count) / 4);
     a.gau_uncertainty = c.gau_uncertainty; a.gau_related_pixels = c.gau_related_pixels;
-    { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd(a, st)); }
     (void)tiles;
+    if (bin) {
+        // cursor + padded tile counters: everything between the start of the image buffer and the range table
+        { ScopedStage t(ST_ZERO_FWD, st); HIP_TRY(dgr::launch_zero_fill(image_base, (size_t)((char*)img.ranges - image_base), st)); }
+        a.fused_count = 1; a.tile_count = img.tile_count; a.cursor = img.cursor; a.ranks = bin->ranks; a.capacity = capacity;
+        { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd(a, st)); }
+        return DGR_OK;
+    }
+    a.zero_words = img.tile_count; a.n_zero_words = (int)(((char*)img.ranges - (char*)img.tile_count) / 4);
+    { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd(a, st)); }
     // per-block instance totals -> exclusive prefix; status[0] = num_rendered
     { ScopedStage t(ST_SCAN_BLOCKS, st); HIP_TRY(dgr::launch_scan_blocks(c.P, geom, img, st)); }
     return DGR_OK;
 }
 
 // histogram + ranks, range table (status[0] = num_rendered, status[1] = overflow), key scatter, per-tile sort
+// (`fused`: preprocess_fwd counted already; the status word is complete after scan_tiles, which is where a caller that
+// armed the early status gets its copy)
 int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, int capacity,
-                   hipStream_t st) {
+                   hipStream_t st, bool fused = false) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
-    { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_rank(c.P, geom, img, bin, gx, capacity, st)); }
-    { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, gx, capacity, st)); }
+    if (!fused) { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_rank(c.P, geom, img, bin, gx, capacity, st)); }
+    { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, gx, capacity, fused, st)); }
+    if (fused) { const int rc = early_status_post(img.status, st); if (rc) return rc; }
     { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
     { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
     return DGR_OK;
@@ -312,9 +326,8 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
-    if ((rc = forward_front(c, geom, img, st))) return rc;
-    if ((rc = early_status_post(img.status, st))) return rc;
-    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
+    if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer))) return rc;
+    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, true))) return rc;
     if ((rc = forward_back(c, geom, img, bin, st))) return rc;
     return DGR_OK;
 }
@@ -435,9 +448,8 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
-    if ((rc = forward_front(c, geom, img, st))) return rc;
-    if ((rc = early_status_post(img.status, st))) return rc;
-    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st))) return rc;
+    if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer))) return rc;
+    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, true))) return rc;
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
     return DGR_OK;
 }

@@ -21,17 +21,17 @@
 // the reference.
 #include "dgr_common.h"
 #include "kernels.h"
+#include "count_rank.h"
 
 namespace dgr {
 namespace {
 
 constexpr int SCAN_THREADS = 1024;
 constexpr int SORT_THREADS = 256;
-constexpr int COUNT_STAGE = 4096;   // ranks staged per 256-Gaussian block in count_rank (16 KB)
 constexpr int SORT_LDS_MAX = 2048;  // keys per tile sorted in LDS (16 KB: 8 workgroups per CU; with 4096 keys = 32 KB only
                                     // 5 fit and the latency-bound sort took 37 us instead of 30); larger tiles sort in global memory
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img, int tiles, int grid_x, int capacity) {
+__global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img, int tiles, int grid_x, int capacity, int fused) {
     const int pairs_x = (grid_x + 1) >> 1;
     // tile i = (ty, tx): half tx & 1 of the 64-bit pair counter (ty, tx / 2), one pair per cache line (count_rank)
     auto count_of = [&](int i) {
@@ -94,109 +94,29 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img,
     if (t == 0) {
         img.status[0] = (int)total;
         img.status[1] = overflow ? 1 : 0;
+        if (fused) {  // (otherwise scan_blocks initialised them)
+            img.status[2] = (int)img.cursor[1];  // prefiltered violation
+            img.status[3] = 0;                   // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
+        }
     }
 }
 
 // One thread per Gaussian.  offset = (instances of all earlier 256-Gaussian blocks, from scan_blocks_kernel) +
-// (exclusive scan inside this block).
+// (exclusive scan inside this block).  Callback path only: the presized path counts inside preprocess_fwd.
 __global__ void __launch_bounds__(256) count_rank_kernel(int P, GeometryView geom, ImageView img, BinningView bin,
                                                          int grid_x, int capacity) {
     __shared__ uint32_t wtot[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t stage[COUNT_STAGE];
+    const int tid = threadIdx.x;
     const int idx = blockIdx.x * 256 + tid;
-    // ---- in-block exclusive scan of tiles_touched (block base: scan_blocks_kernel's exclusive prefix)
     ushort4 r = make_ushort4(0, 0, 0, 0);
     if (idx < P) r = geom.rect[idx];
     const uint32_t n = (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y);
-    uint32_t incl = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    uint32_t base = geom.block_tiles[blockIdx.x];
-    for (int ww = 0; ww < wave; ww++) base += wtot[ww];
+    uint32_t block_total;
+    const uint32_t loc = block_exclusive_scan(n, wtot, tid, &block_total);
     const uint32_t block_base = geom.block_tiles[blockIdx.x];
-    const uint32_t block_total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    const uint32_t off0 = base + incl - n;
-    if (idx < P) geom.goff[idx] = off0;
-    // Ranks of one block are contiguous in the output: stage them in LDS and write them out coalesced (the per-thread
-    // 4-byte stores of the direct form are scattered).  Blocks with more instances than the stage holds, and
-    // anything past the capacity, take the direct path / are only counted.
-    __shared__ uint32_t stage[COUNT_STAGE];
-    const bool staged = block_total <= (uint32_t)COUNT_STAGE;
-    const bool store = off0 + n <= (uint32_t)capacity;  // past the capacity an instance is still counted, so that
-                                                        // scan_tiles sees the true total and flags the overflow
-    const uint32_t loc = off0 - block_base;
-    const uint32_t w = (uint32_t)(r.z - r.x);
-    // Horizontally adjacent tiles (2p, 2p + 1) share one 64-bit counter {count(2p), count(2p + 1) << 32}: an instance
-    // pair in the same row takes ONE returning atomic that bumps both halves (the stage is bound by the number of
-    // atomics the memory-side unit retires, not by their width).  Per rectangle row: an unpaired tile first if the row
-    // starts at an odd tile, then pairs, then an unpaired last tile.
-    const uint32_t lead = r.x & 1u;                       // row starts at an odd tile
-    const uint32_t rest = (w > lead) ? w - lead : 0u;
-    const uint32_t ops_row = (w ? (w >= lead ? lead : 0u) : 0u) + (rest >> 1) + (rest & 1u);
-    const uint32_t h = (uint32_t)(r.w - r.y);
-    const uint32_t n_ops = ops_row * h;
-    const int pairs_x = (grid_x + 1) >> 1;
-    unsigned long long* cnt64 = reinterpret_cast<unsigned long long*>(img.tile_count);
-    auto put = [&](uint32_t kk, uint32_t v) {
-        if (staged) stage[loc + kk] = v;
-        else if (store) bin.ranks[off0 + kk] = v;
-    };
-    // four returning atomics in flight per thread
-    for (uint32_t q = 0; q < n_ops; q += 4) {
-        unsigned long long got[4];
-        uint32_t kk0[4];
-        int kind[4];  // 0: none, 1: low half only, 2: high half only, 3: both
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            kind[u] = 0;
-            const uint32_t qq = q + u;
-            if (qq < n_ops) {
-                const uint32_t yy = qq / ops_row, o = qq - yy * ops_row;
-                uint32_t x;  // first tile of this op, relative to r.x
-                bool both = false;
-                if (lead && o == 0) {
-                    x = 0;
-                } else {
-                    x = lead + 2u * (o - lead);
-                    both = x + 1u < w;
-                }
-                const uint32_t tx = r.x + x;
-                unsigned long long* c = cnt64 + ((size_t)(r.y + yy) * pairs_x + (tx >> 1)) * (DGR_COUNT_STRIDE / 2);
-                kk0[u] = yy * w + x;
-                if (both) {
-                    kind[u] = 3;
-                    got[u] = atomicAdd(c, 0x0000000100000001ull);
-                } else if (tx & 1u) {
-                    kind[u] = 2;
-                    got[u] = (unsigned long long)atomicAdd(reinterpret_cast<uint32_t*>(c) + 1, 1u) << 32;
-                } else {
-                    kind[u] = 1;
-                    got[u] = atomicAdd(reinterpret_cast<uint32_t*>(c), 1u);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (kind[u] == 3) {
-                put(kk0[u], (uint32_t)got[u]);
-                put(kk0[u] + 1u, (uint32_t)(got[u] >> 32));
-            } else if (kind[u] == 2) {
-                put(kk0[u], (uint32_t)(got[u] >> 32));
-            } else if (kind[u] == 1) {
-                put(kk0[u], (uint32_t)got[u]);
-            }
-        }
-    }
-    if (staged) {
-        __syncthreads();
-        const uint32_t lim = (block_base >= (uint32_t)capacity) ? 0u : min(block_total, (uint32_t)capacity - block_base);
-        for (uint32_t i = tid; i < lim; i += 256) bin.ranks[block_base + i] = stage[i];
-    }
+    if (idx < P) geom.goff[idx] = block_base + loc;
+    count_and_rank(r, block_base + loc, block_base, block_total, img.tile_count, bin.ranks, grid_x, capacity, stage, tid);
 }
 
 // In-place exclusive scan of the per-block instance totals (P/256 values, one 1024-thread block); the grand total
@@ -367,8 +287,8 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_tiles_kernel(ImageView img,
 
 }  // namespace
 
-hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, hipStream_t stream) {
-    launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, grid_x, capacity);
+hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, hipStream_t stream) {
+    launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, grid_x, capacity, fused ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,

@@ -60,6 +60,8 @@ __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
 
 struct ImageView {
     int* status;          // [4] {num_rendered, overflow, prefiltered violation, reserved}
+    uint32_t* cursor;     // [2] presized path: {instances handed out so far (preprocess_fwd's blocks bump it to place their
+                          //     ranks), prefiltered violation seen}; cleared together with the tile counters
     uint32_t* tile_count; // [tiles * DGR_COUNT_STRIDE] instances per tile (histogram filled by count_rank), one per line
     uint2* ranges;        // [tiles] {start, end} into point_list
     uint32_t* n_contrib;  // [N]
@@ -74,7 +76,8 @@ __host__ __device__ inline ImageView carve_image(char* base, int W, int H) {
     ImageView v;
     const size_t tiles = (size_t)tiles_x(W) * tiles_y(H), N = (size_t)W * H;
     size_t o = 0;
-    v.status = (int*)(base + o);          o = align_up(o + 4 * sizeof(int), 256);
+    v.status = (int*)(base + o);
+    v.cursor = (uint32_t*)(base + o + 64);  o = align_up(o + 4 * sizeof(int), 256);
     v.tile_count = (uint32_t*)(base + o); o = align_up(o + tiles * 4 * DGR_COUNT_STRIDE, 256);
     v.ranges = (uint2*)(base + o);        o = align_up(o + tiles * 8, 256);
     v.n_contrib = (uint32_t*)(base + o);  o = align_up(o + N * 4, 256);

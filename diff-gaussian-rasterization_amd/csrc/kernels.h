@@ -51,6 +51,14 @@ struct PreprocessFwdArgs {
     int n_zero_words;
     float* gau_uncertainty;   // [P] cleared here, accumulated by the forward blend (may be NULL)
     int* gau_related_pixels;  // [P] likewise
+    // presized path (binning buffer exists before the kernel runs): the block also takes the per-instance tile-counter
+    // atomics and stores the arrival ranks -- count_rank.h; offsets come from a global cursor, not from a scan over P.
+    // The counters and the cursor must be zero when the kernel starts (launch_zero_fill before it).
+    int fused_count;
+    uint32_t* tile_count;
+    uint32_t* cursor;
+    uint32_t* ranks;
+    int capacity;
 };
 
 struct PreprocessBwdArgs {
@@ -178,7 +186,9 @@ hipError_t launch_sparse_adam(size_t rows, int k, float* param, const float* gra
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream);
 
 // binning: tile_count -> ranges (+ total in status[0], overflow in status[1]); emit keys; sort tiles
-hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, hipStream_t stream);
+// `fused`: preprocess_fwd counted (no scan_blocks ran): scan_tiles then also fills status[2] (from the cursor's violation
+// word) and status[3]
+hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, hipStream_t stream);
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,
                              hipStream_t stream);
 hipError_t launch_scan_blocks(int P, GeometryView geom, ImageView img, hipStream_t stream);

@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "count_rank.h"
 
 #pragma clang fp contract(off)
 
@@ -214,8 +215,12 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
     bool violation = false;
     float3 p_sh = make_float3(0.f, 0.f, 0.f);  // position of a Gaussian whose colour still has to be evaluated from SH
     bool need_sh = false;
-    // Zeroing that would otherwise be stream memsets (one launch each): the tile counters count_rank increments and
-    // the two per-Gaussian median statistics the forward blend accumulates into.
+    // LDS: the SH transposition buffer and, afterwards, the rank stage of the fused count share one pool
+    constexpr int POOL_WORDS = (4 * SHT_ROWS * SHT_LD > COUNT_STAGE) ? 4 * SHT_ROWS * SHT_LD : COUNT_STAGE;
+    __shared__ float pool[POOL_WORDS];
+    // Zeroing that would otherwise be stream memsets (one launch each): the tile counters count_rank increments
+    // (callback path only -- the fused count needs them cleared before this kernel starts) and the two per-Gaussian
+    // median statistics the forward blend accumulates into.
     for (int i = idx; i < a.n_zero_words; i += gridDim.x * 256) a.zero_words[i] = 0u;
     if (idx < a.P) {
     if (a.gau_uncertainty) a.gau_uncertainty[idx] = 0.0f;
@@ -313,7 +318,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
 
     // computeColorFromSH (forward.cu:20-71) for the Gaussians that survived
     if (a.shs && !a.colors_precomp) {  // uniform
-        __shared__ float sht[4 * SHT_ROWS * SHT_LD];
+        float* sht = pool;
         // whole block in range, 16 coefficients, 16-byte aligned rows: SH rows move through LDS (block-uniform)
         const bool blk_fast = a.sh_vec_ok && a.M == 16 && (size_t)blockIdx.x * 256 + 256 <= (size_t)a.P &&
                               __syncthreads_or(need_sh);
@@ -358,9 +363,29 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
         }
     }
 
-    // instances (tiles_touched) of this block, for count_rank's offsets (the reference scans tiles_touched over P,
-    // L/cuda_rasterizer/rasterizer_impl.cu:283)
     __shared__ uint32_t wsum[4];
+    if (a.fused_count) {
+        // duplicateWithKeys' first half, here: this block's instances get a contiguous run of the rank array handed out
+        // by a global cursor (any unique placement will do -- the ranks are read back through goff), then every
+        // instance takes its tile-counter atomic (count_rank.h).
+        __shared__ uint32_t s_base;
+        const bool any_violation = __syncthreads_or(violation);  // (also orders the SH phase's LDS reads before the stage)
+        const uint32_t n = (uint32_t)(rect.z - rect.x) * (uint32_t)(rect.w - rect.y);
+        uint32_t block_total;
+        const uint32_t loc = block_exclusive_scan(n, wsum, threadIdx.x, &block_total);
+        if (threadIdx.x == 0) {
+            s_base = block_total ? atomicAdd(a.cursor, block_total) : 0u;
+            if (any_violation) atomicOr(a.cursor + 1, 1u);
+        }
+        __syncthreads();
+        const uint32_t base = s_base;
+        if (idx < a.P) a.geom.goff[idx] = base + loc;
+        count_and_rank(rect, base + loc, base, block_total, a.tile_count, a.ranks, a.grid_x, a.capacity,
+                       reinterpret_cast<uint32_t*>(pool), threadIdx.x);
+        return;
+    }
+    // callback path: instances (tiles_touched) of this block, for count_rank's offsets (the reference scans
+    // tiles_touched over P, L/cuda_rasterizer/rasterizer_impl.cu:283)
     uint32_t n = (uint32_t)(rect.z - rect.x) * (uint32_t)(rect.w - rect.y);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
