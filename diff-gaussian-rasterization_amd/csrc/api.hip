@@ -400,7 +400,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
+    { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, st)); }
 
     dgr::RenderBwdLightArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
@@ -420,8 +420,8 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     b.track_off = track_off; b.map_off = map_off; b.geom = geom; b.acc = sc.acc;
     b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor;
     b.dL_ddepth = dL_ddepth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
-    b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part;
-    { ScopedStage t(ST_PRE_BWD, st); HIP_TRY(dgr::launch_preprocess_bwd(b, dL_dview, st)); }
+    b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part; b.ticket = sc.ticket; b.dL_dview = dL_dview;
+    { ScopedStage t(ST_PRE_BWD, st); HIP_TRY(dgr::launch_preprocess_bwd(b, st)); }
     if (debug) HIP_TRY(hipStreamSynchronize(st));
     return DGR_OK;
 }
@@ -527,7 +527,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sizeof(float) * DGR_ACC_STRIDE * (size_t)P, st)); }
+    { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, st)); }
 
     dgr::RenderBwdFullArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
@@ -546,8 +546,8 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     b.track_off = 0; b.map_off = 0; b.full_variant = 1; b.geom = geom; b.acc = sc.acc;
     b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor;
     b.dL_ddepth = dL_dgau_depth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
-    b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part;
-    { ScopedStage t(ST_PRE_BWD, st); HIP_TRY(dgr::launch_preprocess_bwd(b, dL_dview, st)); }
+    b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part; b.ticket = sc.ticket; b.dL_dview = dL_dview;
+    { ScopedStage t(ST_PRE_BWD, st); HIP_TRY(dgr::launch_preprocess_bwd(b, st)); }
     return DGR_OK;
 }
 

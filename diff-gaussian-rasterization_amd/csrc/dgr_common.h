@@ -116,17 +116,21 @@ __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
 //  [10..11] colour-only dL/d(ndc x, y)   [12] dL_depth * alpha T of the pixels whose FRONT-MOST valid Gaussian this is
 //  [13..14] dL_depth * d(depth)/d(ndc x, y) of those same pixels   [15] unused
 #define DGR_ACC_STRIDE 16
+#define DGR_POSE_BUCKETS 64
 struct BackwardScratch {
     float* acc;         // [P * 16]
-    double* pose_part;  // [blocks * 12] per-block partial sums of the pose gradient
+    uint32_t* ticket;   // [1] blocks of preprocess_bwd that have delivered their pose partial (the last one finishes the sum)
+    double* pose_part;  // [DGR_POSE_BUCKETS * 12] partial sums of the pose gradient, block b adds into bucket b % 64
+    size_t zero_bytes;  // acc, ticket and pose_part are contiguous and cleared together before the blend backward
     size_t bytes;
 };
 __host__ __device__ inline BackwardScratch carve_backward_scratch(char* base, int P) {
     BackwardScratch s;
     size_t o = 0;
-    s.acc = (float*)(base + o);       o = align_up(o + sizeof(float) * DGR_ACC_STRIDE * (size_t)P, 256);
-    const size_t blocks = ((size_t)P + 255) / 256;
-    s.pose_part = (double*)(base + o); o = align_up(o + sizeof(double) * 12 * blocks, 256);
+    s.acc = (float*)(base + o);         o = align_up(o + sizeof(float) * DGR_ACC_STRIDE * (size_t)P, 256);
+    s.ticket = (uint32_t*)(base + o);   o = align_up(o + 4, 256);
+    s.pose_part = (double*)(base + o);  o = align_up(o + sizeof(double) * 12 * DGR_POSE_BUCKETS, 256);
+    s.zero_bytes = o;
     s.bytes = o;
     return s;
 }

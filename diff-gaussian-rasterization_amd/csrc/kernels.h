@@ -91,7 +91,9 @@ struct PreprocessBwdArgs {
     float* dL_dsh;      // [P,M,3] optional (M == 0)
     float* dL_dscale;   // [P,3]
     float* dL_drot;     // [P,4]
-    double* pose_part;  // [blocks,12]
+    double* pose_part;  // [DGR_POSE_BUCKETS,12], zero on entry
+    uint32_t* ticket;   // zero on entry
+    float* dL_dview;    // [16] written by the last block to deliver its pose partial
 };
 
 struct RenderFwdLightArgs {
@@ -164,7 +166,7 @@ struct RenderBwdFullArgs {
 
 // ---- launchers (each enqueues on `stream` and returns the hipError_t of the launch) ----
 hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream);
-hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hipStream_t stream);
+hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream);
 // zero-fill of a 16-byte aligned buffer whose size is a multiple of 16 (a kernel rather than hipMemsetAsync: memset nodes of a
 // captured hipGraph were seen to re-execute with corrupted parameters on this ROCm)
 hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream);

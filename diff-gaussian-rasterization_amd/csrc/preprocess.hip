@@ -207,6 +207,36 @@ __device__ __forceinline__ void lanes_to_sh_rows(const float (&f)[48], float* __
     }
 }
 
+// The same for rows of the form coef[k] * rgb (dL_dsh: every coefficient's gradient is a scalar times the colour
+// gradient): the 48 products are formed while the row is written, so that only 16 + 3 registers stay live.
+__device__ __forceinline__ void lanes_to_sh_rows_scaled(const float (&coef)[16], float3 rgb, float* __restrict__ dst, size_t g_block,
+                                                        float* lds) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* my = lds + wave * (SHT_ROWS * SHT_LD);
+    float4* base = reinterpret_cast<float4*>(dst) + (g_block + (size_t)wave * 64) * 12;
+    const float ch[3] = {rgb.x, rgb.y, rgb.z};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        if ((lane >> 5) == r) {
+            float* row = my + (lane & 31) * SHT_LD;
+#pragma unroll
+            for (int c = 0; c < 12; c++)  // element e = 4 c + j of the row is coefficient e / 3, channel e % 3
+                *reinterpret_cast<float4*>(row + 4 * c) =
+                    make_float4(coef[(4 * c) / 3] * ch[(4 * c) % 3], coef[(4 * c + 1) / 3] * ch[(4 * c + 1) % 3],
+                                coef[(4 * c + 2) / 3] * ch[(4 * c + 2) % 3], coef[(4 * c + 3) / 3] * ch[(4 * c + 3) % 3]);
+        }
+        __syncthreads();
+        float4* p = base + (size_t)r * SHT_ROWS * 12;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int e = i * 64 + lane;
+            const int g = e / 12, c = e - 12 * g;
+            p[e] = *reinterpret_cast<const float4*>(my + g * SHT_LD + 4 * c);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -566,9 +596,11 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
             const bool blk_fast = a.sh_vec_ok && ncoef_out == 16 && a.shs != nullptr && (size_t)blockIdx.x * 256 + 256 <= (size_t)a.P;
             float shf[48];
             if (blk_fast) sh_rows_to_lanes(a.shs, (size_t)blockIdx.x * 256, sht, shf);
-            float outf[48];
+            // dL_dsh[k] = coef[k] * dRGB (backward.cu:46-133): the scalars, not the 48 products, stay in registers
+            float coef[16];
 #pragma unroll
-            for (int k = 0; k < 48; k++) outf[k] = 0.0f;
+            for (int k = 0; k < 16; k++) coef[k] = 0.0f;
+            float3 dRGB = make_float3(0.f, 0.f, 0.f);
             if (do_map && a.shs) {
                 SHCoeffs s;
                 if (blk_fast) {
@@ -582,41 +614,38 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
                 const float len = sqrtf(dot3(dir_orig, dir_orig));
                 const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
                 const uint8_t cl = a.geom.clamped[idx];
-                float3 dRGB = make_float3(acc[0], acc[1], acc[2]);
+                dRGB = make_float3(acc[0], acc[1], acc[2]);
                 dRGB.x *= (cl & 1) ? 0 : 1;
                 dRGB.y *= (cl & 2) ? 0 : 1;
                 dRGB.z *= (cl & 4) ? 0 : 1;
                 float3 dRGBdx = make_float3(0, 0, 0), dRGBdy = make_float3(0, 0, 0), dRGBdz = make_float3(0, 0, 0);
                 const float x = dir.x, y = dir.y, z = dir.z;
-                float3 g[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) g[k] = make_float3(0, 0, 0);
-                g[0] = SH_C0 * dRGB;
+                coef[0] = SH_C0;
                 if (a.D > 0) {
-                    g[1] = (-SH_C1 * y) * dRGB;
-                    g[2] = (SH_C1 * z) * dRGB;
-                    g[3] = (-SH_C1 * x) * dRGB;
+                    coef[1] = -SH_C1 * y;
+                    coef[2] = SH_C1 * z;
+                    coef[3] = -SH_C1 * x;
                     dRGBdx = -SH_C1 * s.c[3];
                     dRGBdy = -SH_C1 * s.c[1];
                     dRGBdz = SH_C1 * s.c[2];
                     if (a.D > 1) {
                         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                        g[4] = (SH_C2[0] * xy) * dRGB;
-                        g[5] = (SH_C2[1] * yz) * dRGB;
-                        g[6] = (SH_C2[2] * (2.f * zz - xx - yy)) * dRGB;
-                        g[7] = (SH_C2[3] * xz) * dRGB;
-                        g[8] = (SH_C2[4] * (xx - yy)) * dRGB;
+                        coef[4] = SH_C2[0] * xy;
+                        coef[5] = SH_C2[1] * yz;
+                        coef[6] = SH_C2[2] * (2.f * zz - xx - yy);
+                        coef[7] = SH_C2[3] * xz;
+                        coef[8] = SH_C2[4] * (xx - yy);
                         dRGBdx = dRGBdx + (SH_C2[0] * y * s.c[4] + SH_C2[2] * 2.f * -x * s.c[6] + SH_C2[3] * z * s.c[7] + SH_C2[4] * 2.f * x * s.c[8]);
                         dRGBdy = dRGBdy + (SH_C2[0] * x * s.c[4] + SH_C2[1] * z * s.c[5] + SH_C2[2] * 2.f * -y * s.c[6] + SH_C2[4] * 2.f * -y * s.c[8]);
                         dRGBdz = dRGBdz + (SH_C2[1] * y * s.c[5] + SH_C2[2] * 2.f * 2.f * z * s.c[6] + SH_C2[3] * x * s.c[7]);
                         if (a.D > 2) {
-                            g[9] = (SH_C3[0] * y * (3.f * xx - yy)) * dRGB;
-                            g[10] = (SH_C3[1] * xy * z) * dRGB;
-                            g[11] = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dRGB;
-                            g[12] = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dRGB;
-                            g[13] = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dRGB;
-                            g[14] = (SH_C3[5] * z * (xx - yy)) * dRGB;
-                            g[15] = (SH_C3[6] * x * (xx - 3.f * yy)) * dRGB;
+                            coef[9] = SH_C3[0] * y * (3.f * xx - yy);
+                            coef[10] = SH_C3[1] * xy * z;
+                            coef[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+                            coef[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                            coef[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+                            coef[14] = SH_C3[5] * z * (xx - yy);
+                            coef[15] = SH_C3[6] * x * (xx - 3.f * yy);
                             dRGBdx = dRGBdx + (SH_C3[0] * s.c[9] * 3.f * 2.f * xy + SH_C3[1] * s.c[10] * yz + SH_C3[2] * s.c[11] * -2.f * xy +
                                                SH_C3[3] * s.c[12] * -3.f * 2.f * xz + SH_C3[4] * s.c[13] * (-3.f * xx + 4.f * zz - yy) +
                                                SH_C3[5] * s.c[14] * 2.f * xz + SH_C3[6] * s.c[15] * 3.f * (xx - yy));
@@ -653,19 +682,18 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
                     dmean.z += (-vv.x * vv.z * dv.x - vv.y * vv.z * dv.y + (sum2 - vv.z * vv.z) * dv.z) * invsum32;
                 }
                 if (blk_fast) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) { outf[3 * k] = g[k].x; outf[3 * k + 1] = g[k].y; outf[3 * k + 2] = g[k].z; }
+                    // (written below, through LDS)
                 } else if (a.sh_vec_ok && ncoef_out == 16) {
-                    float f[48];
-#pragma unroll
-                    for (int k = 0; k < 16; k++) { f[3 * k] = g[k].x; f[3 * k + 1] = g[k].y; f[3 * k + 2] = g[k].z; }
+                    const float ch[3] = {dRGB.x, dRGB.y, dRGB.z};
                     float4* o4 = reinterpret_cast<float4*>(out);
 #pragma unroll
-                    for (int i = 0; i < 12; i++) o4[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+                    for (int i = 0; i < 12; i++)
+                        o4[i] = make_float4(coef[(4 * i) / 3] * ch[(4 * i) % 3], coef[(4 * i + 1) / 3] * ch[(4 * i + 1) % 3],
+                                            coef[(4 * i + 2) / 3] * ch[(4 * i + 2) % 3], coef[(4 * i + 3) / 3] * ch[(4 * i + 3) % 3]);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 16; k++)
-                        if (k < ncoef_out) out[k] = g[k];
+                        if (k < ncoef_out) out[k] = coef[k] * dRGB;
                 }
             } else if (!blk_fast) {
                 if (a.sh_vec_ok && ncoef_out == 16) {
@@ -676,7 +704,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
                     for (int k = 0; k < ncoef_out; k++) out[k] = make_float3(0, 0, 0);
                 }
             }
-            if (blk_fast) lanes_to_sh_rows(outf, a.dL_dsh, (size_t)blockIdx.x * 256, sht);
+            if (blk_fast) lanes_to_sh_rows_scaled(coef, dRGB, a.dL_dsh, (size_t)blockIdx.x * 256, sht);
         }
 
         // ---------------- computeCov3D backward (L/cuda_rasterizer/backward.cu:280-343)
@@ -770,53 +798,47 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
         }
     }
 
-    if (!a.track_off) {
-        // block reduction of the 12 pose terms: wave64 butterfly, then the 4 waves through LDS.  In double: the sum
-        // over 4e5 Gaussians cancels to ~1e-3 of its terms, so float partial sums would cost ~2e-5 of the result.
-        __shared__ double red[4][12];
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-            double v = (double)pose[i];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) red[wv][i] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 12)
-            a.pose_part[(size_t)blockIdx.x * 12 + threadIdx.x] =
-                ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    if (a.track_off) {  // no pose gradient asked for: zeros (L/rasterize_points.cu:186)
+        if (blockIdx.x == 0 && threadIdx.x < 16) a.dL_dview[threadIdx.x] = 0.0f;
+        return;
     }
-}
-
-// Final pose reduction: fixed-order double sum of the per-block partials -> dL_dview[16].
-// 1024 threads = 64 row groups x 16 slots (12 used): each thread sums every 64th partial row, then 16 threads fold
-// the 64 groups.  (A single 256-thread block walking all rows took 30 us at P = 500k.)
-__global__ void __launch_bounds__(1024) pose_reduce_kernel(const double* __restrict__ part, int nblocks, float* dL_dview,
-                                                           int track_off) {
-    __shared__ double sm[64][16];
-    const int s = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    double v0 = 0.0, v1 = 0.0;
-    if (!track_off && s < 12) {
-        int b = grp;
-        for (; b + 64 < nblocks; b += 128) {  // two independent chains keep two loads in flight
-            v0 += part[(size_t)b * 12 + s];
-            v1 += part[(size_t)(b + 64) * 12 + s];
-        }
-        if (b < nblocks) v0 += part[(size_t)b * 12 + s];
+    // block reduction of the 12 pose terms: wave64 butterfly, then the 4 waves through LDS.  In double: the sum
+    // over 4e5 Gaussians cancels to ~1e-3 of its terms, so float partial sums would cost ~2e-5 of the result.
+    __shared__ double red[4][12];
+    __shared__ uint32_t s_ticket;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        double v = (double)pose[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wv][i] = v;
     }
-    sm[grp][s] = v0 + v1;
     __syncthreads();
+    // The block's partial goes into one of 64 bucket rows with double atomics performed at L2 (agent scope: no
+    // cache to keep coherent), then the block takes a ticket; the block that draws the last ticket finds every
+    // partial delivered and finishes the sum -- no separate reduction kernel, no fence that writes back an L2.
+    if (threadIdx.x < 12) {
+        const double part = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        double* slot = a.pose_part + (size_t)(blockIdx.x % DGR_POSE_BUCKETS) * 12 + threadIdx.x;
+        __hip_atomic_fetch_add(slot, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the adds are acknowledged before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
     if (threadIdx.x < 16) {
         float out = 0.0f;
         if (threadIdx.x < 12) {
             double t = 0.0;
-            for (int g = 0; g < 64; g++) t += sm[g][threadIdx.x];
+            for (int g = 0; g < DGR_POSE_BUCKETS; g++)  // (agent-scope loads: served by L2, where the adds were performed)
+                t += __hip_atomic_load(a.pose_part + (size_t)g * 12 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             out = (float)t;
         }
         // slot order v0,v1,v2,v4,v5,v6,v8,v9,v10,v12,v13,v14 (L/cuda_rasterizer/backward.cu:723)
-        if (threadIdx.x < 12) dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
-        if (threadIdx.x < 4) dL_dview[threadIdx.x * 4 + 3] = 0.0f;
+        if (threadIdx.x < 12) a.dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
+        if (threadIdx.x < 4) a.dL_dview[threadIdx.x * 4 + 3] = 0.0f;
     }
 }
 
@@ -841,14 +863,10 @@ hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream)
     launch(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), stream, a);
     return hipGetLastError();
 }
-hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, float* dL_dview, hipStream_t stream) {
+hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream) {
     const int blocks = (a.P + 255) / 256;
-    if (blocks > 0) {
-        launch(preprocess_bwd_kernel, dim3(blocks), dim3(256), stream, a);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    launch(pose_reduce_kernel, dim3(1), dim3(1024), stream, a.pose_part, blocks, dL_dview, a.track_off);
+    if (blocks <= 0) return hipSuccess;
+    launch(preprocess_bwd_kernel, dim3(blocks), dim3(256), stream, a);
     return hipGetLastError();
 }
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream) {
