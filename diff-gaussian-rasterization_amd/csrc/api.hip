@@ -89,6 +89,11 @@ std::atomic<int> g_profile_every{1};
 
 // dgr_set_option("tight_cull", 1): alpha-aware tile rectangles (preprocess.hip); process-wide, default off
 std::atomic<int> g_tight_cull{0};
+// dgr_set_option("bwd_rows", 1): light mapping backward with one 4x4 block per 16-lane row (render_light_rows.hip)
+// instead of one 8x8 quadrant per wave (render_light.hip, the default).  Measured 4 % faster on the backward and 7 %
+// slower on the forward that has to produce the 16-bit tags: off by default, kept for A/B runs.
+// Set it before the forward whose backward should use it.
+std::atomic<int> g_bwd_rows{0};
 
 // A kernel stage hands its two events to the stage's first kernel launch (dgr::launch, kernels.h): they then hold
 // that kernel's start and end.  A stage without a kernel (the scratch memset) is bracketed with hipEventRecord.
@@ -207,7 +212,7 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
     r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background; r.gt_depth = c.gt_depth;
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_median = c.out_median_depth; r.out_alpha = c.out_alpha;
     r.out_depth_var = c.out_depth_var; r.n_contrib = img.n_contrib; r.gau_uncertainty = c.gau_uncertainty;
-    r.gau_related_pixels = c.gau_related_pixels;
+    r.gau_related_pixels = c.gau_related_pixels; r.tags16 = g_bwd_rows.load() ? bin.tags16 : nullptr;
     { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_light(r, st)); }
     return DGR_OK;
 }
@@ -408,16 +413,24 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     r.gt_depth = gt_depth; r.alphas = alphas; r.n_contrib = img.n_contrib; r.dL_dpix = dL_dpix;
     r.dL_dpix_depth = dL_dpix_depth; r.dL_dpix_median = dL_dpix_median_depth; r.dL_dpix_var = dL_dpix_depth_var;
     r.means3D = means3D; r.view = viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
-    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_light(r, st)); }
+    r.binning_base = binning_buffer; r.capacity = img.cursor + 2;
+    // mapping modes: one 4x4 block per 16-lane row, raw moments out (preprocess_bwd finishes them); tracking (map_off)
+    // needs three sums only and keeps the quadrant kernel's 4-value butterfly
+    const bool rows = !map_off && g_bwd_rows.load() != 0;
+    {
+        ScopedStage t(ST_RENDER_BWD, st);
+        HIP_TRY(rows ? dgr::launch_render_bwd_light_rows(r, st) : dgr::launch_render_bwd_light(r, st));
+    }
 
     dgr::PreprocessBwdArgs b{};
-    b.P = P; b.D = D; b.M = M; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs; b.scales = scales;
+    b.P = P; b.D = D; b.M = M; b.W = width; b.H = height; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs;
+    b.scales = scales;
     b.rotations = rotations; b.scale_modifier = scale_modifier; b.cov3D_precomp = cov3D_precomp; b.view = viewmatrix;
     b.proj = projmatrix; b.campos = campos; b.perspec = perspec_matrix; b.tan_fovx = tan_fovx; b.tan_fovy = tan_fovy;
     b.focal_y = height / (2.0f * tan_fovy);
     b.focal_x = width / (2.0f * tan_fovx);
     b.sh_vec_ok = aligned16(shs) && aligned16(dL_dsh);
-    b.track_off = track_off; b.map_off = map_off; b.geom = geom; b.acc = sc.acc;
+    b.track_off = track_off; b.map_off = map_off; b.geom = geom; b.acc = sc.acc; b.acc_raw = rows ? 1 : 0;
     b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor;
     b.dL_ddepth = dL_ddepth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
     b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part; b.ticket = sc.ticket; b.dL_dview = dL_dview;
@@ -555,6 +568,10 @@ int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* ou
     HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out4, comp16, comp4, (hipStream_t)stream));
     return DGR_OK;
 }
+int dgr_debug_row_reduce(void* stream, const float* in, float* out, int* comp) {
+    HIP_TRY(dgr::launch_row_reduce_test(in, out, comp, (hipStream_t)stream));
+    return DGR_OK;
+}
 
 int dgr_sparse_adam(void* stream, long rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                     const int* visible, float lr, float beta1, float beta2, float eps, int step) {
@@ -651,6 +668,7 @@ int dgr_early_status_wait(int* host_status4) {
 int dgr_set_option(const char* name, int value) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }
+    if (n == "bwd_rows") { g_bwd_rows.store(value ? 1 : 0); return DGR_OK; }
     if (n == "profile_every") { g_profile_every.store(value > 0 ? value : 1); return DGR_OK; }
     g_last_error = "unknown option: " + n;
     return DGR_ERR_BAD_ARGUMENT;
@@ -658,6 +676,7 @@ int dgr_set_option(const char* name, int value) {
 int dgr_get_option(const char* name) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") return g_tight_cull.load();
+    if (n == "bwd_rows") return g_bwd_rows.load();
     if (n == "profile_every") return g_profile_every.load();
     return DGR_ERR_BAD_ARGUMENT;
 }
@@ -736,6 +755,7 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
         }
         return num_rendered;
     }
+    if (n == "contribution_tags16") return copy(bin.tags16, 2 * (size_t)num_rendered) ? -1 : num_rendered;
     if (n == "keys") {
         hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)tiles), dim3(256), 0, st, img, bin, g, (uint64_t*)dst);
         if (hipGetLastError() != hipSuccess) return -1;

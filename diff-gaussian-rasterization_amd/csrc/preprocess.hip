@@ -460,6 +460,19 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
                 const float4 v = ap[i];
                 acc[4 * i] = v.x; acc[4 * i + 1] = v.y; acc[4 * i + 2] = v.z; acc[4 * i + 3] = v.w;
             }
+            if (a.acc_raw) {
+                // the rows blend kernel leaves raw moments of q = o G dL/dalpha over the pixel offsets; the factors that
+                // depend on the Gaussian alone are applied here (L/cuda_rasterizer/backward.cu:627-631, 669-678):
+                //   dL/dmean2D = -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2;  dL/dconic = -S../2;  dL/dopacity = S0 / o
+                const float4 r0 = a.geom.rec[3 * (size_t)idx], r1 = a.geom.rec[3 * (size_t)idx + 1];
+                const float Sx = acc[4], Sy = acc[5];
+                acc[4] = -(r1.x * Sx + r1.y * Sy) * (0.5f * a.W);
+                acc[5] = -(r1.z * Sy + r1.y * Sx) * (0.5f * a.H);
+                acc[6] *= -0.5f;
+                acc[7] *= -0.5f;
+                acc[8] *= -0.5f;
+                acc[9] = (acc[9] != 0.0f) ? acc[9] / r0.w : 0.0f;
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.0f;

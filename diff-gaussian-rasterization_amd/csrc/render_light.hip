@@ -27,35 +27,56 @@
 // reduction); forward and backward use the identical expression so they agree on every decision.
 #include "render_common.h"
 
+#ifndef DGR_ABLATE
+#define DGR_ABLATE 0  // 1 / 2: measurement builds (profiles/ablate.sh), never shipped
+#endif
+
 namespace dgr {
 namespace {
 
 // ================================================================================ forward
 constexpr int FWD_UNROLL = 2;  // list entries per loop iteration (4 was measured: no faster, more registers)
 
-struct StagedFwd {
+template <bool TAGS16>
+struct StagedFwdT {
     Staged f;
     float unc[DGR_TILE_PIX];   // per staged instance: sum of (d - gt)^2 alpha T over its median pixels (forward.cu:386)
     uint32_t cnt[DGR_TILE_PIX];
-    uint32_t hit[DGR_TILE_PIX];  // byte w of word j != 0: some pixel of quadrant wave w blended staged instance j
+    // TAGS16 (the rows backward is selected): byte 4 w + r of entry j != 0 <=> some pixel of the 4x4 block r of quadrant
+    // wave w blended staged instance j (r = 2 (y / 4) + x / 4 inside the quadrant); otherwise one byte per quadrant
+    uint32_t hit[DGR_TILE_PIX * (TAGS16 ? 4 : 1)];
 };
 
 // Per-slot results of the batch staged at list position `pos0`: the median statistics go to the Gaussian, the
 // contribution tag into the top bits of the list entry (render_common.h).
-__device__ __forceinline__ void flush_slot(const StagedFwd& sf, const RenderFwdLightArgs& a, uint32_t pos0, int tid) {
-    const uint32_t h = sf.hit[tid];
-    if (h == 0u) return;  // nothing blended this instance (never-staged slots included)
+// four 0/1 bytes -> four bits
+__device__ __forceinline__ uint32_t pack4(uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); }
+
+template <bool TAGS16>
+__device__ __forceinline__ void flush_slot(const StagedFwdT<TAGS16>& sf, const RenderFwdLightArgs& a, uint32_t pos0, int tid,
+                                           bool staged) {
+    if (!staged) return;
+    uint32_t tag;
+    if (TAGS16) {
+        const uint4 h = reinterpret_cast<const uint4*>(sf.hit)[tid];
+        const uint32_t tag16 = pack4(h.x) | (pack4(h.y) << 4) | (pack4(h.z) << 8) | (pack4(h.w) << 12);
+        a.tags16[pos0 + tid] = (uint16_t)tag16;  // (every staged entry: the backward reads the tag of every list position)
+        tag = (h.x ? 1u : 0u) | (h.y ? 2u : 0u) | (h.z ? 4u : 0u) | (h.w ? 8u : 0u);  // per quadrant
+    } else {
+        tag = pack4(sf.hit[tid]);
+    }
+    if (tag == 0u) return;  // nothing blended this instance
     const uint32_t gid = sf.f.id[tid];
     if (sf.cnt[tid] != 0u) {
         atomicAdd(&a.gau_uncertainty[gid], sf.unc[tid]);
         atomicAdd(&a.gau_related_pixels[gid], (int)sf.cnt[tid]);
     }
-    const uint32_t tag = (h & 1u) | ((h >> 7) & 2u) | ((h >> 14) & 4u) | ((h >> 21) & 8u);
     a.point_list[pos0 + tid] = gid | (tag << TAG_SHIFT);
 }
 
-__global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
-    __shared__ StagedFwd sf;
+template <bool TAGS16>
+__global__ void __launch_bounds__(256, TAGS16 ? 7 : 8) render_fwd_light_kernel(RenderFwdLightArgs a) {  // (LDS: 7 workgroups per CU with the wide tags)
+    __shared__ StagedFwdT<TAGS16> sf;
     Staged& s = sf.f;
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -66,6 +87,9 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
     const size_t pix_id = (size_t)a.W * py + px;
     const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
+    // byte of a staged entry's hit word(s) this pixel marks: its 4x4 block (quadrant, y / 4, x / 4) or its quadrant
+    const int hit_byte = TAGS16 ? 4 * wave + 2 * (lane >> 5) + ((lane >> 2) & 1) : wave;
+    constexpr int HIT_STRIDE = TAGS16 ? 16 : 4;
 
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
@@ -85,15 +109,20 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         if (__syncthreads_and(ub < 0.f)) break;
         last_base = base;
         // median statistics of the previous batch: slot tid is flushed by the thread that restages it
-        if (have_flush) flush_slot(sf, a, range.x + base - DGR_TILE_PIX, tid);
+        if (have_flush) flush_slot(sf, a, range.x + base - DGR_TILE_PIX, tid, true);  // (an earlier batch is always full)
         sf.unc[tid] = 0.f;
         sf.cnt[tid] = 0u;
-        sf.hit[tid] = 0u;
+        if (TAGS16) reinterpret_cast<uint4*>(sf.hit)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        else sf.hit[tid] = 0u;
         have_flush = true;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
         if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
+#if DGR_ABLATE == 1
+        const int n = build_lists(s, code, tid, wave, lane) * (a.W < 0 ? 1 : 0);  // (measurement build: no pair loop, nothing else removed)
+#else
         const int n = build_lists(s, code, tid, wave, lane);
+#endif
 
         for (int k = 0; k < n; k += FWD_UNROLL) {
             float4 q0[FWD_UNROLL], q1[FWD_UNROLL];
@@ -111,7 +140,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
                     } else {
                         const int j = __float_as_int(q1[u].z);
                         const float4 cd = s.rgbd[j];
-                        reinterpret_cast<unsigned char*>(sf.hit)[4 * j + wave] = 1;  // contribution tag
+                        reinterpret_cast<unsigned char*>(sf.hit)[HIT_STRIDE * j + hit_byte] = 1;  // contribution tag
                         const float w = alpha * T;
                         C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
                         weight += w;
@@ -132,7 +161,10 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         }
     }
     __syncthreads();
-    if (have_flush) flush_slot(sf, a, range.x + last_base, tid);
+    if (have_flush) flush_slot(sf, a, range.x + last_base, tid, tid < total - last_base);
+    // list positions no batch reached (the whole tile finished early): no pixel blended them
+    if (TAGS16)
+        for (int i = (have_flush ? last_base + DGR_TILE_PIX : 0) + tid; i < total; i += DGR_TILE_PIX) a.tags16[range.x + i] = 0;
 
     if (inside) {
         const size_t N = (size_t)a.W * a.H;
@@ -244,7 +276,11 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
 #pragma unroll
         for (int k = 0; k < NACC_LIGHT; k++)
             if (BWD_NB == DGR_TILE_PIX || tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
+#if DGR_ABLATE == 1
+        const int n = build_lists(s, code, tid, wave, lane) * (a.W < 0 ? 1 : 0);  // (measurement build: no pair loop, nothing else removed)
+#else
         const int n = build_lists(s, code, tid, wave, lane);
+#endif
         const int rel_last = last_contributor - lo;  // slots below this are at or before the last contributor
 
         // (the list is padded with sentinels to a multiple of 4, so a multiple of 2 is always readable)
@@ -306,7 +342,11 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     g[9] = qq;         // sum q
                     g[10] = DO_POSE ? wd : 0.f;  // -> accumulator component 13
                     g[11] = 0.f;
+#if DGR_ABLATE == 2
+                    tot = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7])) + ((g[8] + g[9]) + g[10]);  // (measurement build: no butterfly)
+#else
                     tot = wave_reduce12<!DO_POSE>(g);
+#endif
                 } else {
                     float g4[4] = {qdx, qdy, wd, 0.f};
                     tot = wave_reduce4(g4);
@@ -363,7 +403,8 @@ __global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, f
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
-    launch(render_fwd_light_kernel, dim3(tiles), dim3(256), stream, a);
+    if (a.tags16) launch(render_fwd_light_kernel<true>, dim3(tiles), dim3(256), stream, a);
+    else launch(render_fwd_light_kernel<false>, dim3(tiles), dim3(256), stream, a);
     return hipGetLastError();
 }
 hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stream) {

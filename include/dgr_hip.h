@@ -228,6 +228,9 @@ int dgr_get_option(const char* name);
  * values per lane as in[c * 64 + lane]; out16[lane] / out4[lane] receive what each lane holds after the
  * 16-value / 4-value reduction, comp16[lane] / comp4[lane] the index of the value that lane's total belongs to. */
 int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4);
+/* The same for the 16-lane row reduction of the rows backward (render_light_rows.hip): in[c * 64 + lane], c < 12;
+ * out[lane] = what the lane holds afterwards, comp[lane] = the value it belongs to (-1: a duplicate lane). */
+int dgr_debug_row_reduce(void* stream, const float* in, float* out, int* comp);
 
 /* ---- per-stage timing (bench.py's roofline object) ----
  * dgr_profile_select("") disables timing (default), "all" brackets every stage, a stage name brackets that

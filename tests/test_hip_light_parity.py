@@ -97,6 +97,46 @@ def test_contribution_tags(oracle, case):
             assert np.all(((t[blk[blk > 0] - 1] >> q) & 1) == 1)
 
 
+@pytest.mark.parametrize("case", CASES[:5])
+def test_contribution_tags16(oracle, case):
+    """The 16-bit tags (one bit per 4x4 pixel block) the rows backward builds its lists from: the four bits of a quadrant
+    OR to the quadrant's 4-bit tag, a pixel's last contributor is tagged for the pixel's block, and nothing past a
+    block's deepest last contributor is tagged for it."""
+    from dgr_amd import _capi
+    P, W, H, deg, seed = case
+    s = make_scene(P, W, H, seed)
+    _capi.set_option("bwd_rows", 1)  # (the forward produces the wide tags only for the rows backward)
+    try:
+        _, d = hh.hip_forward(s, deg)
+    finally:
+        _capi.set_option("bwd_rows", 0)
+    t4 = hh.hip_state("contribution_tags", s, d).astype(np.uint32)
+    t16 = hh.hip_state("contribution_tags16", s, d).astype(np.uint32)
+    ranges = hh.hip_state("ranges", s, d).reshape(-1, 2)
+    nc = hh.hip_state("n_contrib", s, d).reshape(H, W)
+    quad = np.zeros_like(t4)
+    for q in range(4):
+        quad |= (((t16 >> (4 * q)) & 0xF) != 0).astype(np.uint32) << q
+    listed = np.zeros(len(t4), bool)
+    for lo, hi in ranges:
+        listed[lo:hi] = True
+    assert np.array_equal(quad[listed], t4[listed])
+    gx = (W + 15) // 16
+    for tile, (lo, hi) in enumerate(ranges[:400]):
+        tx, ty = tile % gx, tile // gx
+        t = t16[lo:hi]
+        for b in range(16):
+            q, r = b >> 2, b & 3
+            x0, y0 = tx * 16 + (q & 1) * 8 + (r & 1) * 4, ty * 16 + (q >> 1) * 8 + (r >> 1) * 4
+            blkpix = nc[y0:y0 + 4, x0:x0 + 4]
+            marked = np.nonzero((t >> b) & 1)[0]
+            if blkpix.size == 0 or blkpix.max() == 0:
+                assert marked.size == 0
+                continue
+            assert marked.size and marked.max() == blkpix.max() - 1
+            assert np.all(((t[blkpix[blkpix > 0] - 1] >> b) & 1) == 1)
+
+
 GRAD_NAMES = ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
 
 
@@ -161,6 +201,20 @@ def check_backward(oracle, s, deg, track_off=False, map_off=False, end_to_end=Tr
             else:
                 assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=3e-3, elem_rtol=2e-2,
                                   elem_frac=0.1)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("mode", [(False, False), (True, False)])
+def test_rows_backward_gradients(oracle, case, mode):
+    """The opt-in backward with one 4x4 pixel block per 16-lane row (csrc/render_light_rows.hip, dgr_set_option
+    "bwd_rows"): same bars as the default kernel, stage-isolated and end to end."""
+    from dgr_amd import _capi
+    P, W, H, deg, seed = case
+    _capi.set_option("bwd_rows", 1)
+    try:
+        check_backward(oracle, make_scene(P, W, H, seed), deg, mode[0], mode[1])
+    finally:
+        _capi.set_option("bwd_rows", 0)
 
 
 @pytest.mark.parametrize("view", [0, 3])

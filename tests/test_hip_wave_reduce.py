@@ -51,3 +51,42 @@ def test_one_hot_lane_and_component(comp):
         assert np.array_equal(o16, np.where(c16 == comp, 3.0, 0.0))
         if comp < 4:
             assert np.array_equal(o4, np.where(c4 == comp, 3.0, 0.0))
+
+
+# ---- the 16-lane row reduction of the rows backward (csrc/render_light_rows.hip): twelve values per row of 16 lanes
+def run_rows(x):
+    lib = _capi.load()
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    out = torch.zeros(64, device=dev)
+    comp = torch.zeros(64, dtype=torch.int32, device=dev)
+    rc = lib.dgr_debug_row_reduce(_capi.stream_handle(), t.data_ptr(), out.data_ptr(), comp.data_ptr())
+    assert rc == 0, _capi.last_error()
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), comp.cpu().numpy()
+
+
+def test_row_reduce_sums_every_row_separately():
+    rng = np.random.default_rng(1)
+    x = rng.integers(-64, 64, size=(12, 64)).astype(np.float32)
+    out, comp = run_rows(x)
+    for r in range(4):
+        c = comp[16 * r:16 * r + 16]
+        assert sorted(v for v in c.tolist() if v >= 0) == list(range(12))  # every value has exactly one delivering lane
+        want = x[:, 16 * r:16 * r + 16].sum(1)
+        for lane in range(16):
+            if c[lane] >= 0:
+                assert out[16 * r + lane] == want[c[lane]], (r, lane)
+
+
+@pytest.mark.parametrize("comp_idx", range(12))
+def test_row_reduce_one_hot(comp_idx):
+    for lane in (0, 3, 7, 8, 13, 15, 16, 37, 63):
+        x = np.zeros((12, 64), np.float32)
+        x[comp_idx, lane] = 5.0
+        out, comp = run_rows(x)
+        row = lane >> 4
+        for q in range(64):
+            if comp[q] < 0:
+                continue
+            assert out[q] == (5.0 if (q >> 4) == row and comp[q] == comp_idx else 0.0), (lane, q)
