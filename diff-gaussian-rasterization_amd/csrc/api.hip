@@ -72,6 +72,17 @@ int early_status_post(const int* device_status, hipStream_t st) {
     return DGR_OK;
 }
 
+// ---- asynchronous status read-back (dgr_status_post / _poll): the lazy mode of the bindings copies a forward's status
+// word to pinned host memory behind an event and looks at it one or two calls later.  Slots are pooled per device.
+struct StatusSlot {
+    hipEvent_t ev = nullptr;
+    int* pinned = nullptr;
+    int device = -1;
+    bool busy = false;
+};
+std::mutex g_status_mu;
+std::vector<StatusSlot> g_status_slots;
+
 // ---- optional per-stage timing with HIP events on the launching stream (dgr_profile_* in dgr_hip.h).
 // Disabled by default; when a stage is selected, two events bracket that stage's launch only.
 struct StageProf {
@@ -645,6 +656,60 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
     HIP_TRY(dgr::launch_l1_loss_backward(n_color, color, color_obs, n_depth, depth, depth_obs, w_color, w_depth, upstream,
                                          dL_dcolor, dL_ddepth, (hipStream_t)stream));
     return DGR_OK;
+}
+
+long dgr_status_post(void* stream, const int* device_status) {
+    if (!device_status) { g_last_error = "dgr_status_post: NULL"; return DGR_ERR_BAD_ARGUMENT; }
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    long id = -1;
+    for (size_t i = 0; i < g_status_slots.size(); i++)
+        if (!g_status_slots[i].busy && g_status_slots[i].device == dev) { id = (long)i; break; }
+    if (id < 0) {
+        StatusSlot sl;
+        HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void**)&sl.pinned, 4 * sizeof(int), hipHostMallocDefault));
+        sl.device = dev;
+        g_status_slots.push_back(sl);
+        id = (long)g_status_slots.size() - 1;
+    }
+    StatusSlot& sl = g_status_slots[(size_t)id];
+    HIP_TRY(hipMemcpyAsync(sl.pinned, device_status, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipEventRecord(sl.ev, (hipStream_t)stream));
+    sl.busy = true;
+    return id;
+}
+
+int dgr_status_poll(long ticket, int wait, int* host_status4) {
+    hipEvent_t ev;
+    int* pinned;
+    {
+        std::lock_guard<std::mutex> lk(g_status_mu);
+        if (ticket < 0 || (size_t)ticket >= g_status_slots.size() || !g_status_slots[(size_t)ticket].busy || !host_status4) {
+            g_last_error = "dgr_status_poll: bad ticket";
+            return DGR_ERR_BAD_ARGUMENT;
+        }
+        ev = g_status_slots[(size_t)ticket].ev;
+        pinned = g_status_slots[(size_t)ticket].pinned;
+    }
+    if (wait) {
+        HIP_TRY(hipEventSynchronize(ev));
+    } else {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipErrorNotReady) return 0;
+        if (e != hipSuccess) return hip_fail(e, "hipEventQuery");
+    }
+    for (int i = 0; i < 4; i++) host_status4[i] = pinned[i];
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    g_status_slots[(size_t)ticket].busy = false;
+    return 1;
+}
+
+int dgr_stream_is_capturing(void* stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return st == hipStreamCaptureStatusActive ? 1 : 0;
 }
 
 int dgr_early_status_arm(void) {

@@ -27,6 +27,9 @@ _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # argument lists follow include/dgr_hip.h one to one
 _SIGS = {
     "dgr_last_error": (C.c_char_p, []),
+    "dgr_status_post": (C.c_long, [_vp, _vp]),
+    "dgr_status_poll": (_i, [C.c_long, _i, _vp]),
+    "dgr_stream_is_capturing": (_i, [_vp]),
     "dgr_early_status_arm": (_i, []),
     "dgr_early_status_wait": (_i, [_vp]),
     "dgr_pose_forward": (_i, [_vp] * 7),

@@ -47,9 +47,8 @@ _capacity_cache = {}
 # later call starts (or by check_async_errors()), by which time the event has long fired.  An overflow or a
 # `prefiltered` violation therefore raises one or two calls late.  Default ("strict"): one status read at the end of
 # every forward, like the reference's blocking copy of num_rendered (L/cuda_rasterizer/rasterizer_impl.cu:287).
-_pending_status = []   # [(pinned host int32[4], event, key)]
+_pending_status = []   # [(ticket of dgr_status_post, key)]
 _last_status = {}      # key -> the most recent status word read back for that shape
-_pinned_pool = []
 
 
 def _sync_mode():
@@ -67,18 +66,17 @@ def _post_status(status, key):
         _captured_status.append(weakref.ref(status))  # kept alive by the captured step's results (CapturedStep.keep)
         _capture_keepalive.append(status)
         return
-    host = _pinned_pool.pop() if _pinned_pool else torch.empty((4,), dtype=torch.int32, pin_memory=True)
-    host.copy_(status, non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    _pending_status.append((host, ev, key))
+    # the library copies the word to pinned host memory behind an event (include/dgr_hip.h: dgr_status_post)
+    ticket = _capi.load().dgr_status_post(_capi.stream_handle(status.device.index), status.data_ptr())
+    _check(ticket)
+    _pending_status.append((ticket, key))
 
 
 def _check_oldest():
-    host, ev, key = _pending_status.pop(0)
-    ev.synchronize()  # waits for that forward only
-    s = host.tolist()
-    _pinned_pool.append(host)
+    ticket, key = _pending_status.pop(0)
+    buf = (C.c_int * 4)()
+    _check(_capi.load().dgr_status_poll(ticket, 1, buf))  # waits for that forward only
+    s = list(buf)
     _capacity_cache[key] = max(_capacity_cache.get(key, 0), s[0])
     _last_status[key] = s
     if s[2]:
@@ -323,6 +321,73 @@ class _C:
             _check(lib.dgr_mark_visible(_capi.stream_handle(dev.index), P, _capi.ptr(means3D), _capi.ptr(viewmatrix),
                                         _capi.ptr(projmatrix), present.data_ptr()))
         return present
+
+
+class _CompiledC:
+    """The same three functions over the compiled torch extension (csrc/torch_ext.cpp -> dgr_amd/_dgr_torch_ext.so), the
+    counterpart of the reference's pybind11 `_C` (L/ext.cpp:15-19): tensor allocation, argument marshalling and the C-ABI
+    call happen in C++; only the capacity / status policy above stays in Python.  Selected when the extension is built
+    (DGR_BINDING=ctypes forces the ctypes class)."""
+
+    ext = None
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, gt_depth, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree,
+                            campos, prefiltered, debug):
+        ext = _CompiledC.ext
+        P, H, W = means3D.size(0) if means3D.dim() else 0, int(image_height), int(image_width)
+        key = (means3D.device.index, P, H, W)
+        cap = _capacity_cache.get(key, 0)
+        if os.environ.get("DGR_FORWARD_MODE", "presized") == "callback" or P == 0:
+            mode, use = 0, 0
+        elif _sync_mode() == "lazy" and cap > 0:
+            while len(_pending_status) > 1 and not torch.cuda.is_current_stream_capturing():
+                _check_oldest()  # status words of earlier calls have long completed: no stall
+            mode, use = 2, int(cap * 1.5) + 4096
+        else:
+            mode, use = 1, (int(cap * 1.25) + 4096 if cap else 4 * P + 4096)
+        (rendered, ticket, _, status, color, depth, median, var, alpha, radii, geom, binning, img, unc, px) = ext.light_forward(
+            background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix,
+            gt_depth, projmatrix, float(tan_fovx), float(tan_fovy), H, W, sh, int(degree), campos, bool(prefiltered),
+            bool(debug), use, mode)
+        if mode == 2:
+            if ticket >= 0:
+                _pending_status.append((ticket, key))
+            else:  # recorded into a hipGraph: nothing can be read back now
+                _captured_status.append(weakref.ref(status))
+                _capture_keepalive.append(status)
+            rendered = _capacity_cache[key]
+        elif mode == 1:
+            _capacity_cache[key] = max(cap, rendered)
+        return (rendered, color, depth, median, var, alpha, radii, geom, binning, img, unc, px)
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                     viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                     dL_dout_median_depth, dL_dout_depth_var, gt_depth, sh, degree, campos, geomBuffer, R,
+                                     binningBuffer, imageBuffer, alphas, debug, perspec_matrix, track_off, map_off,
+                                     need_gaussian_grads=True):
+        g = _CompiledC.ext.light_backward(
+            background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix,
+            projmatrix, float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth, dL_dout_median_depth,
+            dL_dout_depth_var, gt_depth, sh, int(degree), campos, geomBuffer, int(R), binningBuffer, imageBuffer, alphas,
+            bool(debug), perspec_matrix, bool(track_off), bool(map_off), bool(need_gaussian_grads))
+        return tuple(g)
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        return _CompiledC.ext.mark_visible(means3D, viewmatrix, projmatrix)
+
+
+_CtypesC = _C
+if os.environ.get("DGR_BINDING", "compiled") != "ctypes":
+    try:
+        from . import _dgr_torch_ext as _ext
+        _CompiledC.ext = _ext
+        _C = _CompiledC
+    except ImportError:  # the extension is optional (make -C diff-gaussian-rasterization_amd builds it); ctypes still binds the C ABI
+        pass
 
 
 def rasterize_gaussians(

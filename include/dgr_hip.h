@@ -171,6 +171,14 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
  * at that point, and dgr_early_status_wait() blocks until that copy -- not the rest of the forward -- has completed and
  * returns {num_rendered, 0, prefiltered violation, 0} (the overflow flag is the caller's own num_rendered > capacity).
  * Returns 1 when nothing was posted (P == 0). */
+/* Asynchronous read-back of a device status word (the bindings' lazy mode): dgr_status_post enqueues a copy of
+ * device_status[0..3] to pinned host memory behind an event on `stream` and returns a ticket (>= 0) or an error code;
+ * dgr_status_poll returns 1 and fills host_status4 once the copy has landed (the ticket is then released), 0 when
+ * `wait` == 0 and it has not yet.  dgr_stream_is_capturing: 1 while `stream` records a hipGraph (nothing can be read
+ * back then). */
+long dgr_status_post(void* stream, const int* device_status);
+int dgr_status_poll(long ticket, int wait, int* host_status4);
+int dgr_stream_is_capturing(void* stream);
 int dgr_early_status_arm(void);
 int dgr_early_status_wait(int* host_status4);
 

@@ -525,3 +525,38 @@ def test_captured_steps_on_their_own_streams(monkeypatch):
         for a, b in zip(got[1:], w[1:]):
             assert_grad_close(a, b, "replay on a stream", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
     caps[0].check()
+
+
+def test_compiled_and_ctypes_bindings_agree():
+    """`_C` exists twice: the compiled torch extension (csrc/torch_ext.cpp, the counterpart of L/ext.cpp) and the ctypes
+    class over the same C ABI.  Same 12-tuple / 9-tuple shapes, bit-identical forward, gradients equal up to atomic order."""
+    from dgr_amd import light as L
+    assert L._C is L._CompiledC, "the compiled extension was not built / not importable"
+    s = make_scene(4000, 112, 80, 12)
+    a = (hh.T(s.bg), hh.T(s.means), hh.E(), hh.T(s.opac), hh.T(s.scales), hh.T(s.rots), 1.0, hh.E(), hh.T(s.view), hh.T(s.gt),
+         hh.T(s.proj), s.tanfovx, s.tanfovy, s.H, s.W, hh.T(s.shs), 3, hh.T(s.campos), False, False)
+    outs = [C.rasterize_gaussians(*a) for C in (L._CompiledC, L._CtypesC)]
+    assert len(outs[0]) == len(outs[1]) == 12 and outs[0][0] == outs[1][0] > 0
+    for i in (1, 2, 3, 4, 5, 6, 11):
+        assert torch.equal(outs[0][i], outs[1][i]), i
+    assert torch.allclose(outs[0][10], outs[1][10], rtol=1e-5, atol=1e-7)  # gau_uncertainty: float atomics
+    grads = []
+    for C, o in zip((L._CompiledC, L._CtypesC), outs):
+        (R, color, depth, median, var, alpha, radii, geom, binning, img, _, _) = o
+        grads.append(C.rasterize_gaussians_backward(
+            hh.T(s.bg), hh.T(s.means), radii, hh.E(), hh.T(s.scales), hh.T(s.rots), 1.0, hh.E(), hh.T(s.view), hh.T(s.proj),
+            s.tanfovx, s.tanfovy, hh.T(s.gC), hh.T(s.gD[None]), hh.T(s.gM[None]), hh.T(s.gV[None]), hh.T(s.gt), hh.T(s.shs), 3,
+            hh.T(s.campos), geom, R, binning, img, alpha, False, hh.T(s.persp), False, False))
+    assert len(grads[0]) == len(grads[1]) == 9 and tuple(grads[0][8].shape) == (1, 4, 4)
+    for ga, gb in zip(*grads):
+        assert ga.shape == gb.shape
+        assert_grad_close(ga.cpu().numpy(), gb.cpu().numpy(), "binding", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
+    # tracking form: no per-Gaussian gradients
+    (R, color, depth, median, var, alpha, radii, geom, binning, img, _, _) = outs[0]
+    g = L._CompiledC.rasterize_gaussians_backward(
+        hh.T(s.bg), hh.T(s.means), radii, hh.E(), hh.T(s.scales), hh.T(s.rots), 1.0, hh.E(), hh.T(s.view), hh.T(s.proj),
+        s.tanfovx, s.tanfovy, hh.T(s.gC), hh.T(s.gD[None]), hh.T(s.gM[None]), hh.T(s.gV[None]), hh.T(s.gt), hh.T(s.shs), 3,
+        hh.T(s.campos), geom, R, binning, img, alpha, False, hh.T(s.persp), False, True, need_gaussian_grads=False)
+    assert all(x is None for x in g[:8]) and g[8].abs().sum() > 0
+    present = L._CompiledC.mark_visible(hh.T(s.means), hh.T(s.view), hh.T(s.proj))
+    assert torch.equal(present, L._CtypesC.mark_visible(hh.T(s.means), hh.T(s.view), hh.T(s.proj)))
