@@ -13,6 +13,20 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+// DGR_EXACT_ALPHA = 1 is a MEASUREMENT build (profiles/exact_alpha.sh, tests/test_hip_error_budget.py), never shipped: the
+// blend kernels then evaluate alpha as the reference writes it -- power = -0.5 (a dx dx + c dy dy) - b dx dy in that
+// association, o * expf(power), T / (1 - alpha) with IEEE division -- instead of o * 2^p2 with a conic pre-scaled by
+// log2(e) (one v_exp_f32) and v_rcp_f32.  It exists to separate how much of the end-to-end gradient error comes from the
+// fast alpha path and how much is inherent.
+#ifndef DGR_EXACT_ALPHA
+#define DGR_EXACT_ALPHA 0
+#endif
+constexpr float PSCALE = DGR_EXACT_ALPHA ? 1.0f : LOG2E;           // scale of the staged conic
+constexpr float PUNSCALE = DGR_EXACT_ALPHA ? 1.0f : 0.6931471805599453f;  // its inverse (ln 2)
+__device__ __forceinline__ float alpha_raw(float o, float p2) {     // o G
+    return DGR_EXACT_ALPHA ? o * expf(p2) : o * __builtin_amdgcn_exp2f(p2);
+}
+__device__ __forceinline__ float recip(float x) { return DGR_EXACT_ALPHA ? 1.0f / x : __builtin_amdgcn_rcpf(x); }
 constexpr float ALPHA_MIN = 15.0f / 255.0f;  // forward.cu:365
 
 // bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of tiles
@@ -55,9 +69,9 @@ __device__ __forceinline__ unsigned stage_one(StagedT<NB>& s, int slot, uint32_t
     // log-domain threshold: alpha >= 15/255 <=> p2 >= log2(15/(255 o)); the loop compares against a slightly lower
     // value and re-tests alpha itself on the rare path, so decisions are those of the linear-domain test.
     const float l2 = __log2f(o * (255.0f / 15.0f));  // = tau / (2 ln 2)
-    const float lthr = (o > 0.f) ? (-l2 - 1.0e-4f) : 3.0e38f;
-    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -0.5f * LOG2E * q1.z);
-    s.rec[2 * slot + 1] = make_float4(-LOG2E * q1.y, o, __int_as_float(slot), lthr);
+    const float lthr = (o > 0.f) ? (-l2 * (DGR_EXACT_ALPHA ? 0.6931471805599453f : 1.0f) - 1.0e-4f) : 3.0e38f;
+    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
+    s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, o, __int_as_float(slot), lthr);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
     const float tau = 2.0f * 0.6931471805599453f * l2;
@@ -89,8 +103,8 @@ __device__ __forceinline__ unsigned stage_tagged(StagedT<NB>& s, int slot, uint3
     const float4 q0 = rec[3 * (size_t)gid + 0];
     const float4 q1 = rec[3 * (size_t)gid + 1];
     const float4 q2 = rec[3 * (size_t)gid + 2];
-    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -0.5f * LOG2E * q1.z);
-    s.rec[2 * slot + 1] = make_float4(-LOG2E * q1.y, q0.w, __int_as_float(slot), 0.f);
+    s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
+    s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, q0.w, __int_as_float(slot), 0.f);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
     return code;
@@ -134,9 +148,17 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float pair_p2(const float4& q0, const float4& q1, f2 pxy, f2& dxy) {
     const f2 g = {q0.x, q0.y}, ac = {q0.z, q0.w};
     dxy = g - pxy;
+#if DGR_EXACT_ALPHA
+    {   // the reference's association (forward.cu:354, backward.cu:561), no contraction; the staged a2, c2 carry the -0.5
+#pragma clang fp contract(off)
+        const float A = (q0.z * dxy.x) * dxy.x, Cc = (q0.w * dxy.y) * dxy.y, B = (q1.x * dxy.x) * dxy.y;
+        return (A + Cc) + B;
+    }
+#else
     const f2 m = ac * dxy;                                      // a2 dx, c2 dy
     const float t = __builtin_fmaf(q1.x, dxy.y, m.x);           // a2 dx + b2 dy
     return __builtin_fmaf(dxy.x, t, m.y * dxy.y);
+#endif
 }
 
 // two consecutive list entries: one 4-byte LDS read yields two record offsets

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
                 f2 dxy;
                 const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
                 if ((p2 <= ub) & (p2 >= q1[u].w)) {
-                  const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
+                  const float alpha = fminf(0.99f, alpha_raw(q1[u].y, p2));
                   if (alpha >= ALPHA_MIN) {
                     const int j = __float_as_int(q1[u].z);
                     const float4 cd = s.rgbd[j];
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
                 const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
-                const float oG = q1[u].y * __builtin_amdgcn_exp2f(p2);  // o G: alpha before the 0.99 clamp
+                const float oG = alpha_raw(q1[u].y, p2);  // o G: alpha before the 0.99 clamp
                 const float alpha = fminf(0.99f, oG);
                 const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
 
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
                 const float4 cd = s.rgbd[j];
                 if (valid) {
                     const float om_now = 1.f - alpha;
-                    const float inv = __builtin_amdgcn_rcpf(om_now);
+                    const float inv = recip(om_now);
                     T = T * inv;
                     w = alpha * T;  // dchannel_dcolor
                     e = cd.w - gt_px;
@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
         __syncthreads();
         // moments -> gradients per staged Gaussian: every "d/d(ndc)" sum is -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2
         if (code != 0u) {
-            constexpr float LN2 = 0.6931471805599453f;
+            constexpr float LN2 = PUNSCALE;  // (undoes the scale of the staged conic)
             const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
             const float ca = r0.z * (-2.f * LN2), cb = r1.x * (-LN2), cc = r0.w * (-2.f * LN2);
 #pragma unroll
@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
             sb.acc[6 * BWD_LD + tid] *= -0.5f;
             sb.acc[7 * BWD_LD + tid] *= -0.5f;
             sb.acc[8 * BWD_LD + tid] *= -0.5f;
-            sb.acc[9 * BWD_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
+            sb.acc[9 * BWD_LD + tid] *= recip(r1.y);
         }
         __syncthreads();
         flush_acc<NACC_FULL, BWD_LD>(sb.acc, s.id, cnt, a.acc, tid);

@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256, TAGS16 ? 7 : 8) render_fwd_light_kernel(R
                 f2 dxy;
                 const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
                 if ((p2 <= ub) & (p2 >= q1[u].w)) {  // cheap log-domain pre-test: v_exp stays off the common path
-                  const float alpha = fminf(0.99f, q1[u].y * __builtin_amdgcn_exp2f(p2));
+                  const float alpha = fminf(0.99f, alpha_raw(q1[u].y, p2));
                   if (alpha >= ALPHA_MIN) {
                     const float test_T = T * (1.0f - alpha);
                     if (test_T < 0.0001f) {
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                 const float dx = dxy.x, dy = dxy.y;
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
-                const float oG = q1[u].y * __builtin_amdgcn_exp2f(p2);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
+                const float oG = alpha_raw(q1[u].y, p2);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
                 const float alpha = fminf(0.99f, oG);
                 const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
 
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                 const float4 cd = s.rgbd[j];
                 if (valid) {
                     const float om = 1.f - alpha;
-                    const float inv = __builtin_amdgcn_rcpf(om);
+                    const float inv = recip(om);
                     T = T * inv;
                     w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
                     e = cd.w - gt_px;
@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         // moments -> gradients, one thread per staged Gaussian (backward.cu:627-631, 669-678):
         //   dL/dmean2D = -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2;  dL/dconic = -Sxx/2, -Sxy/2, -Syy/2;  dL/dopacity = S0/o
         if (code != 0u) {
-            constexpr float LN2 = 0.6931471805599453f;
+            constexpr float LN2 = PUNSCALE;  // (undoes the scale of the staged conic)
             const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
             const float ca = r0.z * (-2.f * LN2), cb = r1.x * (-LN2), cc = r0.w * (-2.f * LN2);  // unscaled conic
             const float Sx = sb.acc[4 * BWD_LD + tid], Sy = sb.acc[5 * BWD_LD + tid];
@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                 sb.acc[6 * BWD_LD + tid] *= -0.5f;
                 sb.acc[7 * BWD_LD + tid] *= -0.5f;
                 sb.acc[8 * BWD_LD + tid] *= -0.5f;
-                sb.acc[9 * BWD_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
+                sb.acc[9 * BWD_LD + tid] *= recip(r1.y);
             }
         }
         __syncthreads();

@@ -195,8 +195,8 @@ __global__ void __launch_bounds__(256, 5) render_bwd_light_rows_kernel(RenderBwd
                 const float4 q0 = a.rec[3 * (size_t)gid + 0];
                 const float4 q1 = a.rec[3 * (size_t)gid + 1];
                 const float4 q2 = a.rec[3 * (size_t)gid + 2];
-                sb.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * LOG2E * q1.x, -0.5f * LOG2E * q1.z);
-                sb.rec[2 * slot + 1] = make_float4(-LOG2E * q1.y, q0.w, 0.f, 0.f);
+                sb.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
+                sb.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, q0.w, 0.f, 0.f);
                 sb.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
                 sb.id[slot] = gid;
             }
@@ -228,13 +228,13 @@ __global__ void __launch_bounds__(256, 5) render_bwd_light_rows_kernel(RenderBwd
             f2 dxy;
             const float p2 = pair_p2(q0, q1, pxy, dxy);
             const float dx = dxy.x, dy = dxy.y;
-            const float oG = q1.y * __builtin_amdgcn_exp2f(p2);
+            const float oG = alpha_raw(q1.y, p2);
             const float alpha = fminf(0.99f, oG);
             const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
             float w = 0.f, qq = 0.f, e = 0.f;
             if (valid) {
                 const float om = 1.f - alpha;
-                const float inv = __builtin_amdgcn_rcpf(om);
+                const float inv = recip(om);
                 T = T * inv;
                 w = alpha * T;
                 e = cd.w - gt_px;

@@ -381,7 +381,8 @@ class _CompiledC:
 
 
 _CtypesC = _C
-if os.environ.get("DGR_BINDING", "compiled") != "ctypes":
+# (DGR_HIP_LIB selects another build of the C ABI for the ctypes loader; the extension is linked against the in-tree one)
+if os.environ.get("DGR_BINDING", "compiled") != "ctypes" and not os.environ.get("DGR_HIP_LIB"):
     try:
         from . import _dgr_torch_ext as _ext
         _CompiledC.ext = _ext

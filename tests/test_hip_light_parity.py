@@ -188,7 +188,8 @@ def check_backward(oracle, s, deg, track_off=False, map_off=False, end_to_end=Tr
                 assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-4,
                                   outlier_rows=2 * max(1, P // 500000) if k == "dL_dmeans3D" else 0)
             else:
-                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=3e-3, elem_rtol=2e-2, elem_frac=2e-2,
+                # end to end: measured worst 1.0e-3 of scale over these cases (tests/tools/e2e_margin.py); bar = 2x
+                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=2e-3, elem_rtol=2e-2, elem_frac=2e-2,
                                   outlier_rows=0)
         assert g["dL_dview"].shape == (4, 4)
         if track_off:
@@ -199,7 +200,7 @@ def check_backward(oracle, s, deg, track_off=False, map_off=False, end_to_end=Tr
                 assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=1e-5, elem_rtol=1e-3,
                                   elem_frac=0.0 if P < 200000 else 0.1)
             else:
-                assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=3e-3, elem_rtol=2e-2,
+                assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=2e-3, elem_rtol=2e-2,
                                   elem_frac=0.1)
 
 
