@@ -1,7 +1,9 @@
 #!/bin/bash
-# End-of-round evidence: full GPU test suite, rocprofv3 passes (run_profile.sh), default bench line.
+# End-of-round evidence (run on the GPU box): rocprofv3 kernel-trace stats + PMC passes (run_profile.sh), summaries into
+# gpurun_out/prof_<tag>/, default bench line.  usage: bash profiles/final_round.sh <tag>
 cd "$(dirname "$0")/.."
-timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -3 | tee gpurun_out/pytest_gpu_tail.txt
-bash profiles/run_profile.sh v14 > /dev/null 2>&1
-python profiles/summarize.py gpurun_out/prof_v14 gpurun_out/prof_v14/r1_v14_final
-python bench.py > gpurun_out/bench_default.json 2>/dev/null; tail -1 gpurun_out/bench_default.json | cut -c1-200
+TAG=${1:-r2}
+bash profiles/run_profile.sh $TAG > /dev/null 2>&1
+python profiles/summarize.py gpurun_out/prof_$TAG gpurun_out/prof_$TAG/${TAG}
+python bench.py > gpurun_out/bench_default_$TAG.json 2>/dev/null; tail -1 gpurun_out/bench_default_$TAG.json | cut -c1-300
+python bench.py --views-in-flight 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/bench_one_stream_$TAG.json
