@@ -158,6 +158,12 @@ __device__ __forceinline__ M3 diag3(float a, float b, float c) {
 // at a time with contiguous 1-KB accesses and transposes them in LDS (row stride 52 dwords: b128-aligned, and the 64
 // lanes' rows fall on all banks evenly).  Used for blocks that lie entirely inside [0, P).
 constexpr int SHT_ROWS = 32, SHT_LD = 52;
+// Every wave transposes through ITS OWN slab of the buffer, so the stores and the loads that follow them need no
+// workgroup barrier: the LDS executes one wave's instructions in order; the fence keeps the compiler from reordering.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ void sh_rows_to_lanes(const float* __restrict__ src, size_t g_block, float* lds, float (&f)[48]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* my = lds + wave * (SHT_ROWS * SHT_LD);
@@ -171,7 +177,7 @@ __device__ __forceinline__ void sh_rows_to_lanes(const float* __restrict__ src, 
             const int g = e / 12, c = e - 12 * g;
             *reinterpret_cast<float4*>(my + g * SHT_LD + 4 * c) = p[e];
         }
-        __syncthreads();
+        wave_sync();
         if ((lane >> 5) == r) {
             const float* row = my + (lane & 31) * SHT_LD;
 #pragma unroll
@@ -180,7 +186,7 @@ __device__ __forceinline__ void sh_rows_to_lanes(const float* __restrict__ src, 
                 f[4 * c] = v.x; f[4 * c + 1] = v.y; f[4 * c + 2] = v.z; f[4 * c + 3] = v.w;
             }
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 __device__ __forceinline__ void lanes_to_sh_rows(const float (&f)[48], float* __restrict__ dst, size_t g_block, float* lds) {
@@ -195,7 +201,7 @@ __device__ __forceinline__ void lanes_to_sh_rows(const float (&f)[48], float* __
             for (int c = 0; c < 12; c++)
                 *reinterpret_cast<float4*>(row + 4 * c) = make_float4(f[4 * c], f[4 * c + 1], f[4 * c + 2], f[4 * c + 3]);
         }
-        __syncthreads();
+        wave_sync();
         float4* p = base + (size_t)r * SHT_ROWS * 12;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -203,7 +209,7 @@ __device__ __forceinline__ void lanes_to_sh_rows(const float (&f)[48], float* __
             const int g = e / 12, c = e - 12 * g;
             p[e] = *reinterpret_cast<const float4*>(my + g * SHT_LD + 4 * c);
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -225,7 +231,7 @@ __device__ __forceinline__ void lanes_to_sh_rows_scaled(const float (&coef)[16],
                     make_float4(coef[(4 * c) / 3] * ch[(4 * c) % 3], coef[(4 * c + 1) / 3] * ch[(4 * c + 1) % 3],
                                 coef[(4 * c + 2) / 3] * ch[(4 * c + 2) % 3], coef[(4 * c + 3) / 3] * ch[(4 * c + 3) % 3]);
         }
-        __syncthreads();
+        wave_sync();
         float4* p = base + (size_t)r * SHT_ROWS * 12;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -233,7 +239,7 @@ __device__ __forceinline__ void lanes_to_sh_rows_scaled(const float (&coef)[16],
             const int g = e / 12, c = e - 12 * g;
             p[e] = *reinterpret_cast<const float4*>(my + g * SHT_LD + 4 * c);
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -451,20 +457,41 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
     for (int i = 0; i < 12; i++) pose[i] = 0.0f;
 
     if (idx < a.P) {
-        const bool vis = a.radii[idx] > 0;
+        // Every per-Gaussian input is requested up front, unconditionally (a culled Gaussian wastes ~130 bytes): behind
+        // `if (vis)` / `if (do_map)` the loads formed a chain of three dependent round trips per wave, and this kernel
+        // spends 60 % of its wave-cycles waiting for memory.
+        const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)idx * DGR_ACC_STRIDE);
+        const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+        const int rad = a.radii[idx];
+        const float3 m = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+        float c3[6];
+        {
+            const float* c3p = a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : a.geom.cov3D + 6 * (size_t)idx;
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = c3p[i];
+        }
+        float3 sc_in = make_float3(0.f, 0.f, 0.f);
+        float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.scales) {
+            sc_in = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
+            q_in = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
+        }
+        const uint8_t cl_in = a.geom.clamped[idx];
+        float4 r0_in = make_float4(0.f, 0.f, 0.f, 1.f), r1_in = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.acc_raw) {
+            r0_in = a.geom.rec[3 * (size_t)idx];
+            r1_in = a.geom.rec[3 * (size_t)idx + 1];
+        }
+        const bool vis = rad > 0;
         float acc[16];
         if (vis) {
-            const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)idx * DGR_ACC_STRIDE);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float4 v = ap[i];
-                acc[4 * i] = v.x; acc[4 * i + 1] = v.y; acc[4 * i + 2] = v.z; acc[4 * i + 3] = v.w;
-            }
+            acc[0] = a0.x; acc[1] = a0.y; acc[2] = a0.z; acc[3] = a0.w; acc[4] = a1.x; acc[5] = a1.y; acc[6] = a1.z; acc[7] = a1.w;
+            acc[8] = a2.x; acc[9] = a2.y; acc[10] = a2.z; acc[11] = a2.w; acc[12] = a3.x; acc[13] = a3.y; acc[14] = a3.z; acc[15] = a3.w;
             if (a.acc_raw) {
                 // the rows blend kernel leaves raw moments of q = o G dL/dalpha over the pixel offsets; the factors that
                 // depend on the Gaussian alone are applied here (L/cuda_rasterizer/backward.cu:627-631, 669-678):
                 //   dL/dmean2D = -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2;  dL/dconic = -S../2;  dL/dopacity = S0 / o
-                const float4 r0 = a.geom.rec[3 * (size_t)idx], r1 = a.geom.rec[3 * (size_t)idx + 1];
+                const float4 r0 = r0_in, r1 = r1_in;
                 const float Sx = acc[4], Sy = acc[5];
                 acc[4] = -(r1.x * Sx + r1.y * Sy) * (0.5f * a.W);
                 acc[5] = -(r1.z * Sy + r1.y * Sx) * (0.5f * a.H);
@@ -477,7 +504,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.0f;
         }
-        const float3 m = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
 
         // ---- outputs that are plain copies of the blend kernel's sums
         // (with map_off the blend kernel still sums acc[4], acc[5] for the pose gradient, but the
@@ -519,10 +545,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
 
         if (do_map) {
             // ---------------- computeCov2DCUDA (L/cuda_rasterizer/backward.cu:144-276)
-            float c3[6];
-            const float* c3p = a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : a.geom.cov3D + 6 * (size_t)idx;
-#pragma unroll
-            for (int i = 0; i < 6; i++) c3[i] = c3p[i];
             const float3 dconic = make_float3(acc[6], acc[7], acc[8]);
             Cov2D c;
             cov2d_common(m, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.view, c);
@@ -626,7 +648,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
                 const float3 dir_orig = m - cam;
                 const float len = sqrtf(dot3(dir_orig, dir_orig));
                 const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
-                const uint8_t cl = a.geom.clamped[idx];
+                const uint8_t cl = cl_in;
                 dRGB = make_float3(acc[0], acc[1], acc[2]);
                 dRGB.x *= (cl & 1) ? 0 : 1;
                 dRGB.y *= (cl & 2) ? 0 : 1;
@@ -722,9 +744,8 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
 
         // ---------------- computeCov3D backward (L/cuda_rasterizer/backward.cu:280-343)
         if (do_map && a.scales) {
-            const float3 sc = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
-            const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2],
-                                         a.rotations[4 * idx + 3]);
+            const float3 sc = sc_in;
+            const float4 q = q_in;
             const float r = q.x, x = q.y, y = q.z, z = q.w;
             M3 R;
             quat_to_R(q, R);
