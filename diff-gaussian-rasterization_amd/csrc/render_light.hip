@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     // The reference keeps five "accumulated behind me" recurrences (3 colours, depth, variance: backward.cu:580-608)
     // only to form dL/dalpha = sum_c (c_j - accum_rec_c) dL/dpixel_c.  They are linear, so one scalar suffices:
     //   X_j = <features_j, dL/dpixel>,   S <- alpha_last X_last + (1 - alpha_last) S,   dL/dalpha = X_j - S.
-    float S = 0.f, X_last = 0.f, last_alpha = 0.f, last_om = 1.f;  // last_om = 1 - last_alpha
+    float S = 0.f;
     bool mid_once = true;
     // which accumulator component this lane's quad delivers after the butterfly (-1: none)
     int my_comp;
@@ -309,11 +309,8 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
                     e = cd.w - gt_px;
                     const float X = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2 + cd.w * dpix_depth + (e * e) * dpix_var;
-                    S = last_alpha * X_last + last_om * S;
-                    X_last = X;
-                    last_alpha = alpha;
-                    last_om = om;
                     const float dL_dalpha = (X - S) * T + bg_term * inv;
+                    S = alpha * X + om * S;  // what the NEXT valid pair (towards the front) subtracts: same operations, same order
                     qq = oG * dL_dalpha;
                     if (DO_MAP && T > 0.5f && mid_once) {
                         // backward.cu:654-664, once per pixel: the median-depth term of dL/dmean3D is
