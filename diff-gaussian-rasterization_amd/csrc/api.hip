@@ -575,6 +575,21 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     return DGR_OK;
 }
 
+int dgr_cov3d_forward(void* stream, int P, const float* scales, const float* rotations, float scale_modifier, float* cov3D) {
+    if (P < 0 || (P > 0 && (!scales || !rotations || !cov3D))) { g_last_error = "dgr_cov3d_forward: bad argument"; return DGR_ERR_BAD_ARGUMENT; }
+    HIP_TRY(dgr::launch_cov3d_forward(P, scales, rotations, scale_modifier, cov3D, (hipStream_t)stream));
+    return DGR_OK;
+}
+int dgr_cov3d_backward(void* stream, int P, const float* scales, const float* rotations, float scale_modifier,
+                       const float* dL_dcov3D, float* dL_dscales, float* dL_drotations) {
+    if (P < 0 || (P > 0 && (!scales || !rotations || !dL_dcov3D || !dL_dscales || !dL_drotations))) {
+        g_last_error = "dgr_cov3d_backward: bad argument";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    HIP_TRY(dgr::launch_cov3d_backward(P, scales, rotations, scale_modifier, dL_dcov3D, dL_dscales, dL_drotations, (hipStream_t)stream));
+    return DGR_OK;
+}
+
 int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4) {
     HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out4, comp16, comp4, (hipStream_t)stream));
     return DGR_OK;

@@ -190,6 +190,10 @@ hipError_t launch_densification_stats(int rows, const float* dmeans2D, const int
 hipError_t launch_sparse_adam(size_t rows, int k, float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                               const int* visible, float lr, float beta1, float beta2, float eps, int step,
                               const int* step_dev, hipStream_t stream);
+// view-independent covariance of a batch of views (preprocess.hip)
+hipError_t launch_cov3d_forward(int P, const float* scales, const float* rotations, float mod, float* cov3D, hipStream_t stream);
+hipError_t launch_cov3d_backward(int P, const float* scales, const float* rotations, float mod, const float* dL_dcov3D,
+                                 float* dL_dscale, float* dL_drot, hipStream_t stream);
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream);
 
 // binning: tile_count -> ranges (+ total in status[0], overflow in status[1]); emit keys; sort tiles

@@ -876,9 +876,84 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// View-independent half of the per-Gaussian work, shared by the views of a batch: the 3D
+// covariance depends on scale and rotation only.  cov3d_fwd is computeCov3D (forward.cu:118-152) exactly as
+// preprocess_fwd evaluates it (same expression: the six floats are bit-identical), to be passed to every view as
+// `cov3D_precomp`; cov3d_bwd is its backward (L/cuda_rasterizer/backward.cu:280-343), which is LINEAR in dL_dcov3D, so
+// the views' dL_dcov3D are summed first (autograd does that) and converted to dL_dscale / dL_drot once.
+__global__ void __launch_bounds__(256) cov3d_fwd_kernel(int P, const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                        float mod, float* __restrict__ cov3D) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+    const float4 q = make_float4(rotations[4 * idx], rotations[4 * idx + 1], rotations[4 * idx + 2], rotations[4 * idx + 3]);
+    M3 R;
+    quat_to_R(q, R);
+    const M3 S = diag3(mod * sc.x, mod * sc.y, mod * sc.z);
+    const M3 Mm = mul(S, R);
+    const M3 Sigma = mul(transpose(Mm), Mm);
+    float* o = cov3D + 6 * (size_t)idx;
+    o[0] = Sigma.m[0][0]; o[1] = Sigma.m[0][1]; o[2] = Sigma.m[0][2];
+    o[3] = Sigma.m[1][1]; o[4] = Sigma.m[1][2]; o[5] = Sigma.m[2][2];
+}
+__global__ void __launch_bounds__(256) cov3d_bwd_kernel(int P, const float* __restrict__ scales, const float* __restrict__ rotations,
+                                                        float mod, const float* __restrict__ dL_dcov3D, float* __restrict__ dL_dscale,
+                                                        float* __restrict__ dL_drot) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float* dcov = dL_dcov3D + 6 * (size_t)idx;
+    const float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+    const float4 q = make_float4(rotations[4 * idx], rotations[4 * idx + 1], rotations[4 * idx + 2], rotations[4 * idx + 3]);
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    M3 R;
+    quat_to_R(q, R);
+    const float3 s = make_float3(mod * sc.x, mod * sc.y, mod * sc.z);
+    const M3 Mm = mul(diag3(s.x, s.y, s.z), R);
+    M3 dSigma;
+    dSigma.m[0][0] = dcov[0]; dSigma.m[0][1] = 0.5f * dcov[1]; dSigma.m[0][2] = 0.5f * dcov[2];
+    dSigma.m[1][0] = 0.5f * dcov[1]; dSigma.m[1][1] = dcov[3]; dSigma.m[1][2] = 0.5f * dcov[4];
+    dSigma.m[2][0] = 0.5f * dcov[2]; dSigma.m[2][1] = 0.5f * dcov[4]; dSigma.m[2][2] = dcov[5];
+    M3 M2;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) M2.m[c][rr] = Mm.m[c][rr] * 2.0f;
+    const M3 dL_dM = mul(M2, dSigma);
+    const M3 Rt = transpose(R);
+    M3 dMt = transpose(dL_dM);
+    float3 dscale;
+    dscale.x = dot3(make_float3(Rt.m[0][0], Rt.m[0][1], Rt.m[0][2]), make_float3(dMt.m[0][0], dMt.m[0][1], dMt.m[0][2]));
+    dscale.y = dot3(make_float3(Rt.m[1][0], Rt.m[1][1], Rt.m[1][2]), make_float3(dMt.m[1][0], dMt.m[1][1], dMt.m[1][2]));
+    dscale.z = dot3(make_float3(Rt.m[2][0], Rt.m[2][1], Rt.m[2][2]), make_float3(dMt.m[2][0], dMt.m[2][1], dMt.m[2][2]));
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dMt.m[0][k] *= s.x; dMt.m[1][k] *= s.y; dMt.m[2][k] *= s.z; }
+    float4 drot;
+    drot.x = 2 * z * (dMt.m[0][1] - dMt.m[1][0]) + 2 * y * (dMt.m[2][0] - dMt.m[0][2]) + 2 * x * (dMt.m[1][2] - dMt.m[2][1]);
+    drot.y = 2 * y * (dMt.m[1][0] + dMt.m[0][1]) + 2 * z * (dMt.m[2][0] + dMt.m[0][2]) + 2 * r * (dMt.m[1][2] - dMt.m[2][1]) - 4 * x * (dMt.m[2][2] + dMt.m[1][1]);
+    drot.z = 2 * x * (dMt.m[1][0] + dMt.m[0][1]) + 2 * r * (dMt.m[2][0] - dMt.m[0][2]) + 2 * z * (dMt.m[1][2] + dMt.m[2][1]) - 4 * y * (dMt.m[2][2] + dMt.m[0][0]);
+    drot.w = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
+    // the reference scales dL_dscale by the modifier through `s` only (backward.cu:318-322): so does preprocess_bwd
+    dL_dscale[3 * (size_t)idx + 0] = dscale.x;
+    dL_dscale[3 * (size_t)idx + 1] = dscale.y;
+    dL_dscale[3 * (size_t)idx + 2] = dscale.z;
+    reinterpret_cast<float4*>(dL_drot)[idx] = drot;
+}
+
 }  // namespace dgr
 
 namespace dgr {
+hipError_t launch_cov3d_forward(int P, const float* scales, const float* rotations, float mod, float* cov3D, hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    launch(cov3d_fwd_kernel, dim3((P + 255) / 256), dim3(256), stream, P, scales, rotations, mod, cov3D);
+    return hipGetLastError();
+}
+hipError_t launch_cov3d_backward(int P, const float* scales, const float* rotations, float mod, const float* dL_dcov3D,
+                                 float* dL_dscale, float* dL_drot, hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    launch(cov3d_bwd_kernel, dim3((P + 255) / 256), dim3(256), stream, P, scales, rotations, mod, dL_dcov3D, dL_dscale, dL_drot);
+    return hipGetLastError();
+}
 namespace {
 __global__ void __launch_bounds__(256) zero_fill_kernel(float4* dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * 256;

@@ -24,6 +24,44 @@ def make_settings(s, sh_degree, device, track_off=False, map_off=False, debug=Fa
         track_off=track_off, map_off=map_off)
 
 
+class _SharedCov3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scales, rotations, scale_modifier):
+        from . import _capi
+        scales, rotations = scales.contiguous().float(), rotations.contiguous().float()
+        cov = torch.empty((scales.shape[0], 6), dtype=torch.float32, device=scales.device)
+        with _capi.on_device(scales.device):
+            rc = _capi.load().dgr_cov3d_forward(_capi.stream_handle(scales.device.index), scales.shape[0], _capi.ptr(scales),
+                                                _capi.ptr(rotations), float(scale_modifier), _capi.ptr(cov))
+        if rc:
+            raise RuntimeError(_capi.last_error())
+        ctx.save_for_backward(scales, rotations)
+        ctx.mod = float(scale_modifier)
+        return cov
+
+    @staticmethod
+    def backward(ctx, dL_dcov):
+        from . import _capi
+        scales, rotations = ctx.saved_tensors
+        dL_dcov = dL_dcov.contiguous().float()
+        ds, dr = torch.empty_like(scales), torch.empty_like(rotations)
+        with _capi.on_device(scales.device):
+            rc = _capi.load().dgr_cov3d_backward(_capi.stream_handle(scales.device.index), scales.shape[0], _capi.ptr(scales),
+                                                 _capi.ptr(rotations), ctx.mod, _capi.ptr(dL_dcov), _capi.ptr(ds), _capi.ptr(dr))
+        if rc:
+            raise RuntimeError(_capi.last_error())
+        return ds, dr, None
+
+
+def shared_cov3D(scales, rotations, scale_modifier=1.0):
+    """The view-independent part of a keyframe batch, computed once: the 3D covariances of all Gaussians,
+    bit-identical to what every view's forward would compute from `scales` / `rotations`.  Pass the result as
+    `cov3D_precomp=` (and no scales / rotations) to the rasterizer of every view of the batch: the views then skip
+    computeCov3D and its backward, autograd sums their `dL_dcov3D` ([P,6]) and ONE conversion -- the covariance backward is
+    linear in dL_dcov3D -- produces `scales.grad` and `rotations.grad`.  Same images; gradients equal up to summation order."""
+    return _SharedCov3D.apply(scales, rotations, scale_modifier)
+
+
 class ViewStreams:
     """Independent views in flight on several HIP streams.
 

@@ -232,6 +232,15 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
 int dgr_set_option(const char* name, int value);
 int dgr_get_option(const char* name);
 
+/* ---- work shared by the views of a batch ----
+ * The 3D covariance depends on scale and rotation only.  dgr_cov3d_forward evaluates computeCov3D (cr/forward.cu:118-152)
+ * once -- bit-identical to what the forward would compute per view -- for use as `cov3D_precomp` of every view of the batch;
+ * dgr_cov3d_backward is its backward (L/cr/backward.cu:280-343), linear in dL_dcov3D: sum the views' dL_dcov3D first, convert
+ * once.  scales [P,3], rotations [P,4] (r,x,y,z; not normalised), cov3D / dL_dcov3D [P,6], dL_dscales [P,3], dL_drotations [P,4]. */
+int dgr_cov3d_forward(void* stream, int P, const float* scales, const float* rotations, float scale_modifier, float* cov3D);
+int dgr_cov3d_backward(void* stream, int P, const float* scales, const float* rotations, float scale_modifier,
+                       const float* dL_dcov3D, float* dL_dscales, float* dL_drotations);
+
 /* Self-test of the wave64 multi-value butterfly reductions the backward blend relies on.  `in` holds 16
  * values per lane as in[c * 64 + lane]; out16[lane] / out4[lane] receive what each lane holds after the
  * 16-value / 4-value reduction, comp16[lane] / comp4[lane] the index of the value that lane's total belongs to. */

@@ -560,3 +560,46 @@ def test_compiled_and_ctypes_bindings_agree():
     assert all(x is None for x in g[:8]) and g[8].abs().sum() > 0
     present = L._CompiledC.mark_visible(hh.T(s.means), hh.T(s.view), hh.T(s.proj))
     assert torch.equal(present, L._CtypesC.mark_visible(hh.T(s.means), hh.T(s.view), hh.T(s.proj)))
+
+
+def test_shared_cov3D_across_the_views_of_a_batch():
+    """dgr_amd.multiview.shared_cov3D: the covariance of every Gaussian computed once for a batch of views
+    and handed to each view as cov3D_precomp; autograd sums the views' dL_dcov3D and ONE conversion gives the scale /
+    rotation gradients.  Against the per-view scale / rotation path: cov3D bit-identical, images bit-identical, every
+    gradient equal to summation order."""
+    from dgr_amd import light as L
+    from dgr_amd.multiview import make_settings, shared_cov3D
+    dev = hh.dev()
+    scenes = [make_scene(6000, 128, 96, 33, view_index=k) for k in range(3)]
+    s0 = scenes[0]
+
+    def leaves():
+        return [hh.T(a).requires_grad_() for a in (s0.means, s0.shs, s0.opac, s0.scales, s0.rots)]
+
+    results = []
+    for shared in (False, True):
+        means3D, shs, opac, scales, rots = leaves()
+        cov = shared_cov3D(scales, rots, 1.0) if shared else None
+        imgs = []
+        for s in scenes:
+            rast = L.GaussianRasterizer(make_settings(s, 3, dev))
+            view = hh.T(s.view).requires_grad_()
+            kw = dict(cov3D_precomp=cov) if shared else dict(scales=scales, rotations=rots)
+            color, radii, depth, median, var, alpha, unc, px = rast(
+                means3D=means3D, means2D=torch.zeros((s.P, 3), device=dev, requires_grad=True), opacities=opac, shs=shs,
+                viewmatrix=view, gt_depth=hh.T(s.gt), **kw)
+            torch.autograd.backward([color, depth, median], [hh.T(s.gC) * 1e3, hh.T(s.gD[None]) * 1e3, hh.T(s.gM[None]) * 1e3],
+                                    retain_graph=shared)
+            imgs.append((color.detach(), depth.detach(), view.grad.clone()))
+        results.append((imgs, [t.grad.clone() for t in (means3D, shs, opac, scales, rots)], cov))
+    (img_a, g_a, _), (img_b, g_b, cov) = results
+    # the shared covariance is what the forward computes per view (exported from the state of a plain forward)
+    _, d = hh.hip_forward(s0, 3)
+    vis = d["radii"] > 0
+    assert np.array_equal(cov.detach().cpu().numpy()[vis], hh.hip_state("cov3D", s0, d).reshape(-1, 6)[vis])
+    for (ca, da, va), (cb, db, vb) in zip(img_a, img_b):
+        assert torch.equal(ca, cb) and torch.equal(da, db)
+        assert_grad_close(vb.cpu().numpy(), va.cpu().numpy(), "dL_dview", rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=0.1)
+    for name, a, b in zip(("means3D", "sh", "opacity", "scales", "rotations"), g_a, g_b):
+        assert a.abs().max() > 0
+        assert_grad_close(b.cpu().numpy(), a.cpu().numpy(), name, rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-3)
