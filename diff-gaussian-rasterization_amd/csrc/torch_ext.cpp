@@ -204,6 +204,131 @@ std::vector<Tensor> light_backward(const Tensor& background, const Tensor& means
     return g;
 }
 
+
+// ------------------------------------------------------------------------------------------------ full variant
+// F/rasterize_points.cu:35-120.  Modes as light_forward.  Returns (num_rendered or -1, num_related or -1, ticket or -1,
+// capacity used, device status word, color, depth, uncertainty, radii, geom, binning, img).
+std::tuple<long, long, long, long, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor>
+full_forward(const Tensor& background, const Tensor& means3D_, const Tensor& colors_, const Tensor& opacity_, const Tensor& scales_,
+             const Tensor& rotations_, double scale_modifier, const Tensor& cov3D_, const Tensor& viewmatrix_,
+             const Tensor& gt_depth_, const Tensor& projmatrix_, double tan_fovx, double tan_fovy, long H, long W,
+             const Tensor& sh_, long degree, const Tensor& campos_, bool prefiltered, long capacity, long mode) {
+    if (means3D_.dim() != 2 || means3D_.size(1) != 3) throw std::runtime_error("means3D must have dimensions (num_points, 3)");
+    const c10::Device dev = means3D_.device();
+    if (!dev.is_cuda()) throw std::runtime_error("dgr_hip runs on the GPU only (no CPU path exists, as in the reference)");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    const int P = (int)means3D_.size(0);
+    const Tensor means3D = f32c(means3D_, dev), bg = f32c(background, dev), colors = f32c(colors_, dev),
+                 opacity = f32c(opacity_, dev), scales = f32c(scales_, dev), rotations = f32c(rotations_, dev),
+                 cov3D = f32c(cov3D_, dev), view = f32c(viewmatrix_, dev), proj = f32c(projmatrix_, dev),
+                 campos = f32c(campos_, dev), gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev);
+    const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
+    const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+    const auto i32 = at::TensorOptions().dtype(at::kInt).device(dev);
+    const auto u8 = at::TensorOptions().dtype(at::kByte).device(dev);
+    Tensor color = at::empty({3, H, W}, f32), depth = at::empty({1, H, W}, f32), unc = at::empty({1, H, W}, f32);
+    Tensor radii = at::zeros({P}, i32);
+    void* st = stream_of(dev);
+    Tensor geom, binning, img, status = at::empty({4}, i32);
+    long rendered = -1, related = -1, ticket = -1;
+    if (mode == 0 || P == 0) {
+        geom = at::empty({0}, u8); binning = at::empty({0}, u8); img = at::empty({0}, u8);
+        Alloc3 al{{&geom, dev}, {&binning, dev}, {&img, dev}};
+        int ng = 0;
+        const int rc = dgr_full_forward(st, cb_geom, cb_binning, cb_img, &al, P, (int)degree, M, ptr<float>(bg), (int)W, (int)H,
+                                        ptr<float>(means3D), ptr<float>(sh), ptr<float>(colors), ptr<float>(opacity),
+                                        ptr<float>(scales), (float)scale_modifier, ptr<float>(rotations), ptr<float>(cov3D),
+                                        ptr<float>(view), ptr<float>(proj), ptr<float>(campos), (float)tan_fovx, (float)tan_fovy,
+                                        prefiltered ? 1 : 0, ptr<float>(color), ptr<float>(depth), ptr<float>(gt), ptr<float>(unc),
+                                        ptr<int>(radii), &ng);
+        check(rc);
+        return {rc, ng, ticket, rc, status, color, depth, unc, radii, geom, binning, img};
+    }
+    geom = at::empty({(long long)dgr_geometry_bytes(P)}, u8);
+    img = at::empty({(long long)dgr_image_bytes((int)W, (int)H)}, u8);
+    auto run = [&](long cap) {
+        binning = at::empty({(long long)dgr_binning_bytes((int)cap, (int)W, (int)H)}, u8);
+        check(dgr_full_forward_presized(st, (char*)geom.data_ptr(), (char*)binning.data_ptr(), (int)cap, (char*)img.data_ptr(),
+                                        status.data_ptr<int>(), P, (int)degree, M, ptr<float>(bg), (int)W, (int)H,
+                                        ptr<float>(means3D), ptr<float>(sh), ptr<float>(colors), ptr<float>(opacity),
+                                        ptr<float>(scales), (float)scale_modifier, ptr<float>(rotations), ptr<float>(cov3D),
+                                        ptr<float>(view), ptr<float>(proj), ptr<float>(campos), (float)tan_fovx, (float)tan_fovy,
+                                        prefiltered ? 1 : 0, ptr<float>(color), ptr<float>(depth), ptr<float>(gt), ptr<float>(unc),
+                                        ptr<int>(radii)));
+    };
+    if (mode == 2) {
+        run(capacity);
+        if (!dgr_stream_is_capturing(st)) {
+            ticket = dgr_status_post(st, status.data_ptr<int>());
+            check(ticket);
+        }
+        return {rendered, related, ticket, capacity, status, color, depth, unc, radii, geom, binning, img};
+    }
+    long cap = capacity;
+    for (;;) {
+        check(dgr_early_status_arm());
+        run(cap);
+        int s[4] = {0, 0, 0, 0};
+        check(dgr_early_status_wait(s));
+        if (s[2]) throw std::runtime_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+        rendered = s[0];
+        if (rendered <= cap) break;
+        cap = (long)(rendered * 1.1) + 4096;
+    }
+    // num_related (the reference's NG) is produced by the forward blend: the reference's second blocking read
+    // (F/cuda_rasterizer/rasterizer_impl.cu:498)
+    related = status.to(at::kCPU).data_ptr<int>()[3];
+    return {rendered, related, ticket, cap, status, color, depth, unc, radii, geom, binning, img};
+}
+
+// F/rasterize_points.cu:122-239; returns the nine gradients in the reference's order, dL_dview as [4,4]
+std::vector<Tensor> full_backward(const Tensor& background, const Tensor& means3D_, const Tensor& radii, const Tensor& colors_,
+                                  const Tensor& scales_, const Tensor& rotations_, double scale_modifier, const Tensor& cov3D_,
+                                  const Tensor& viewmatrix_, const Tensor& gt_depth_, const Tensor& projmatrix_, double tan_fovx,
+                                  double tan_fovy, const Tensor& dL_dout_color, const Tensor& dL_dout_depth,
+                                  const Tensor& dL_dout_unc, const Tensor& sh_, long degree, const Tensor& campos_,
+                                  const Tensor& geomBuffer, long R, const Tensor& binningBuffer, const Tensor& imageBuffer,
+                                  long NG, const Tensor& perspec_, bool need_gaussian_grads) {
+    (void)NG;
+    const c10::Device dev = means3D_.device();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    const int P = (int)means3D_.size(0);
+    const long H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+    const Tensor means3D = f32c(means3D_, dev), bg = f32c(background, dev), colors = f32c(colors_, dev),
+                 scales = f32c(scales_, dev), rotations = f32c(rotations_, dev), cov3D = f32c(cov3D_, dev),
+                 view = f32c(viewmatrix_, dev), proj = f32c(projmatrix_, dev), campos = f32c(campos_, dev),
+                 gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev), perspec = f32c(perspec_, dev), gC = f32c(dL_dout_color, dev),
+                 gD = f32c(dL_dout_depth, dev), gU = f32c(dL_dout_unc, dev);
+    const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
+    const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+    std::vector<Tensor> g(9);
+    float* gp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (need_gaussian_grads) {
+        const long long n[8] = {3LL * P, 3LL * P, 3LL * M * P, P, 3LL * P, 4LL * P, 6LL * P, 3LL * P};
+        long long off[8], o = 0;
+        for (int i = 0; i < 8; i++) { off[i] = o; o += (n[i] + 63) / 64 * 64; }
+        Tensor arena = P ? at::empty({std::max<long long>(o, 1)}, f32) : at::zeros({std::max<long long>(o, 1)}, f32);
+        auto seg = [&](int i, c10::IntArrayRef shape) { return arena.narrow(0, off[i], n[i]).view(shape); };
+        g[3] = seg(0, {P, 3}); g[0] = seg(1, {P, 3}); g[5] = seg(2, {P, M, 3}); g[2] = seg(3, {P, 1});
+        g[6] = seg(4, {P, 3}); g[7] = seg(5, {P, 4}); g[4] = seg(6, {P, 6}); g[1] = seg(7, {P, 3});
+        for (int i = 0; i < 8; i++) gp[i] = ptr<float>(g[i]);
+    }
+    Tensor dview = at::empty({4, 4}, f32);
+    Tensor scratch = at::empty({(long long)std::max<size_t>(dgr_light_backward_scratch_bytes(P, (int)W, (int)H), 1)},
+                               at::TensorOptions().dtype(at::kByte).device(dev));
+    // gp: [0] means2D [1] colors [2] opacity [3] means3D [4] cov3D [5] sh [6] scales [7] rotations
+    check(dgr_full_backward(stream_of(dev), P, (int)degree, M, (int)R, ptr<float>(bg), (int)W, (int)H, ptr<float>(means3D),
+                            ptr<float>(sh), ptr<float>(colors), ptr<float>(scales), (float)scale_modifier, ptr<float>(rotations),
+                            ptr<float>(cov3D), ptr<float>(view), ptr<float>(proj), ptr<float>(campos), (float)tan_fovx,
+                            (float)tan_fovy, ptr<int>(radii), bytes(geomBuffer), bytes(binningBuffer), bytes(imageBuffer),
+                            ptr<float>(gC), ptr<float>(gD), gp[0], nullptr, gp[2], gp[1], gp[3], gp[4], gp[5], gp[6], gp[7], nullptr,
+                            nullptr, nullptr, nullptr, nullptr, ptr<float>(perspec), nullptr, nullptr, nullptr,
+                            dview.data_ptr<float>(), nullptr, nullptr, nullptr, ptr<float>(gt), ptr<float>(gU),
+                            (char*)scratch.data_ptr(), (size_t)scratch.numel()));
+    g[8] = dview;
+    return g;
+}
+
 Tensor mark_visible(const Tensor& means3D_, const Tensor& viewmatrix_, const Tensor& projmatrix_) {  // L/rasterize_points.cu:238-256
     const c10::Device dev = means3D_.device();
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
@@ -232,6 +357,8 @@ py::object status_poll(long ticket, bool wait) {
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("light_forward", &light_forward);
     m.def("light_backward", &light_backward);
+    m.def("full_forward", &full_forward);
+    m.def("full_backward", &full_backward);
     m.def("mark_visible", &mark_visible);
     m.def("status_poll", &status_poll);
 }

@@ -163,6 +163,63 @@ class _C:
         return _LC.mark_visible(means3D, viewmatrix, projmatrix)
 
 
+class _CompiledC:
+    """The same functions over the compiled torch extension (csrc/torch_ext.cpp), the counterpart of F/ext.cpp:15-19;
+    see dgr_amd.light._CompiledC."""
+
+    ext = None
+
+    @staticmethod
+    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                            gt_depth, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered):
+        P, H, W = means3D.size(0) if means3D.dim() else 0, int(image_height), int(image_width)
+        key = (means3D.device.index, P, H, W)
+        cap = _capacity_cache.get(key, 0)
+        if os.environ.get("DGR_FORWARD_MODE", "presized") == "callback" or P == 0:
+            mode, use = 0, 0
+        elif _light._sync_mode() == "lazy" and cap > 0:
+            while len(_light._pending_status) > 1 and not torch.cuda.is_current_stream_capturing():
+                _light._check_oldest()
+            mode, use = 2, int(cap * 1.5) + 4096
+        else:
+            mode, use = 1, (int(cap * 1.25) + 4096 if cap else 4 * P + 4096)
+        (rendered, related, ticket, _, status, color, depth, unc, radii, geom, binning, img) = _CompiledC.ext.full_forward(
+            background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix,
+            gt_depth, projmatrix, float(tan_fovx), float(tan_fovy), H, W, sh, int(degree), campos, bool(prefiltered), use, mode)
+        if mode == 2:
+            if ticket >= 0:
+                _light._pending_status.append((ticket, key))
+            else:
+                import weakref
+                _light._captured_status.append(weakref.ref(status))
+                _light._capture_keepalive.append(status)
+            rendered, related = _capacity_cache[key], _light._last_status.get(key, (0, 0, 0, 0))[3]
+        elif mode == 1:
+            _capacity_cache[key] = max(cap, rendered)
+            _light._last_status[key] = [rendered, 0, 0, related]
+        return rendered, related, color, depth, unc, radii, geom, binning, img
+
+    @staticmethod
+    def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                     viewmatrix, gt_depth, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth,
+                                     dL_dout_uncertainty, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, NG,
+                                     perspec_matrix, need_gaussian_grads=True):
+        return tuple(_CompiledC.ext.full_backward(
+            background, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix, gt_depth,
+            projmatrix, float(tan_fovx), float(tan_fovy), dL_dout_color, dL_dout_depth, dL_dout_uncertainty, sh, int(degree),
+            campos, geomBuffer, int(R), binningBuffer, imageBuffer, int(NG), perspec_matrix, bool(need_gaussian_grads)))
+
+    @staticmethod
+    def mark_visible(means3D, viewmatrix, projmatrix):
+        return _CompiledC.ext.mark_visible(means3D, viewmatrix, projmatrix)
+
+
+_CtypesC = _C
+if _light._C is getattr(_light, "_CompiledC", None):  # the light module decided (DGR_BINDING, DGR_HIP_LIB, extension built)
+    _CompiledC.ext = _light._CompiledC.ext
+    _C = _CompiledC
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         viewmatrix, gt_depth, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
