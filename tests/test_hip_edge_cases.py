@@ -603,3 +603,41 @@ def test_shared_cov3D_across_the_views_of_a_batch():
     for name, a, b in zip(("means3D", "sh", "opacity", "scales", "rotations"), g_a, g_b):
         assert a.abs().max() > 0
         assert_grad_close(b.cpu().numpy(), a.cpu().numpy(), name, rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-3)
+
+
+@pytest.mark.parametrize("binding", ["compiled", "ctypes"])
+def test_callback_entry_points_match_the_presized_path(monkeypatch, oracle, binding):
+    """dgr_light_forward / dgr_full_forward -- the literal mirror of CudaRasterizer::Rasterizer::forward with its three
+    allocation callbacks and the reference's blocking read of num_rendered (L/cr/rasterizer.h:40-70) -- against the
+    presized entry points the bindings use by default (which count inside preprocess_fwd): same num_rendered, same
+    lists, bit-identical images, and a backward that runs on the callback-allocated state."""
+    from dgr_amd import _capi, light as L, full as F
+    LC = L._CompiledC if binding == "compiled" else L._CtypesC
+    FC = F._CompiledC if binding == "compiled" else F._CtypesC
+    s = make_scene(5000, 144, 100, 21)
+    a = (hh.T(s.bg), hh.T(s.means), hh.E(), hh.T(s.opac), hh.T(s.scales), hh.T(s.rots), 1.0, hh.E(), hh.T(s.view), hh.T(s.gt),
+         hh.T(s.proj), s.tanfovx, s.tanfovy, s.H, s.W, hh.T(s.shs), 3, hh.T(s.campos), False)
+    st, ref = hh.oracle_forward(oracle, s, 3)
+    outs = {}
+    for mode in ("presized", "callback"):
+        monkeypatch.setenv("DGR_FORWARD_MODE", mode)
+        outs[mode] = (LC.rasterize_gaussians(*a, False), FC.rasterize_gaussians(*a))
+    for v in (0, 1):
+        p, c = outs["presized"][v], outs["callback"][v]
+        assert p[0] == c[0] == ref["num_rendered"]
+        for x, y in zip(p[1:], c[1:]):
+            if isinstance(x, torch.Tensor) and x.dtype != torch.uint8 and x.dtype == torch.float32 and x.dim() == 3:
+                assert torch.equal(x, y)  # images
+    lt = outs["callback"][0]
+    names = ["num_rendered", "color", "depth", "depth_median", "depth_var", "opacity_map", "radii", "geom", "binning", "img"]
+    d = dict(zip(names, lt))
+    assert lt[8].numel() == _capi.load().dgr_binning_bytes(lt[0], s.W, s.H)  # sized from num_rendered, as the reference does
+    assert np.array_equal(hh.hip_state("point_list", s, d, capacity=lt[0]), st.get("point_list"))
+    assert np.array_equal(hh.hip_state("ranges", s, d, capacity=lt[0]), st.get("ranges"))
+    g = LC.rasterize_gaussians_backward(
+        hh.T(s.bg), hh.T(s.means), lt[6], hh.E(), hh.T(s.scales), hh.T(s.rots), 1.0, hh.E(), hh.T(s.view), hh.T(s.proj),
+        s.tanfovx, s.tanfovy, hh.T(s.gC), hh.T(s.gD[None]), hh.T(s.gM[None]), hh.T(s.gV[None]), hh.T(s.gt), hh.T(s.shs), 3,
+        hh.T(s.campos), lt[7], lt[0], lt[8], lt[9], hh.T(ref["opacity_map"]), False, hh.T(s.persp), False, False)
+    gr = hh.oracle_backward(oracle, st, s, 3, ref["opacity_map"])
+    for i, k in ((3, "dL_dmeans3D"), (5, "dL_dsh"), (6, "dL_dscales"), (7, "dL_drotations")):
+        assert_grad_close(g[i].cpu().numpy(), gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=2)
