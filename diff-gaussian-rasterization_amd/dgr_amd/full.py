@@ -304,6 +304,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.perspec_matrix)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_viewmatrix) = _C.rasterize_gaussians_backward(*args, need_gaussian_grads=any(ctx.needs_input_grad[:8]))
+        _light._consume_post_backward_wait()  # (dgr_amd.multiview.ViewStreams.before_backward)
         grads = (
             grad_means3D,
             grad_means2D,

@@ -109,6 +109,20 @@ def check_async_errors():
         _check_oldest()
 
 
+# dgr_amd.multiview.ViewStreams.before_backward(): a (stream, event) the NEXT rasterizer backward makes its stream wait for
+# once its kernels are issued -- i.e. before autograd goes on to the activations' backward and to the accumulation into the
+# leaves' .grad, the only part of a view's backward that touches state shared with the previous view.  Module-level on
+# purpose: it is set by the thread that calls loss.backward() and consumed by the autograd engine's thread.
+_post_backward_wait = None
+
+
+def _consume_post_backward_wait():
+    global _post_backward_wait
+    w, _post_backward_wait = _post_backward_wait, None
+    if w is not None:
+        w[0].wait_event(w[1])
+
+
 # The flat gradient arena of a backward is found through the gradients themselves (`p.grad._base`, see
 # dgr_amd.multiview.GradientArena): no module-level "last arena" is kept, so nothing outlives the gradients and threads
 # cannot see each other's arenas.  SPAN_SEGMENTS names the leading segments that form the all-reduce payload.
@@ -532,6 +546,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # reference: torch.sum(grad_viewmatrix, dim=0) over a [H*W,4,4] buffer (__init__.py:160-161);
         # here the buffer is [1,4,4], already reduced: a view instead of a reduction kernel.
         grad_viewmatrix = grad_viewmatrix.view(4, 4)
+        _consume_post_backward_wait()
 
         grads = (
             grad_means3D,

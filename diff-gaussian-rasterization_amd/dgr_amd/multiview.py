@@ -83,10 +83,13 @@ class ViewStreams:
     streams that accumulate into the same `.grad`.  Two safe patterns:
       * no accumulation across views: set `p.grad = None` before every view and collect the per-view gradients
         yourself (`GroupedReduce` sums the views' arenas on one stream) -- what bench.py does;
-      * accumulation in `.grad`: call `views.before_backward()` between a view's forward and its `backward()`.  It makes
-        the view's stream wait for the END of the previous view, so backward passes run one after the other while a
-        view's forward (binning, atomics, sort: the kernels that leave the chip idle) still overlaps the previous
-        view's backward -- what `dgr_amd.slam.render_batch` does."""
+      * accumulation in `.grad`: call `views.before_backward()` between a view's forward and its `backward()`.  The
+        view's stream then waits for the END of the previous view at the one point where it matters: right after the
+        rasterizer's own backward kernels have been issued, before autograd goes on to the activations' backward and
+        the accumulation into the leaves (`dgr_amd.light._post_backward_wait`).  The rasterizer kernels of consecutive
+        views keep overlapping; only the short tail that touches shared `.grad` is ordered -- what
+        `dgr_amd.slam.render_batch` does.  (If the loss reaches other shared leaves before the rasterizer node, order
+        the whole backward instead: `views.before_backward(whole=True)`.)"""
 
     class _View:
         def __init__(self, owner, stream, prev_done):
@@ -124,12 +127,16 @@ class ViewStreams:
             self._fresh.add(k)
         return ViewStreams._View(self, st, self._done)
 
-    def before_backward(self):
-        """Inside a `with views.next():` block, before `backward()`: orders this view's remaining work after the end of
-        the previous view, so that accumulation into a shared `.grad` is race-free (see the class docstring)."""
+    def before_backward(self, whole=False):
+        """Inside a `with views.next():` block, before `backward()`: orders the part of this view's backward that
+        accumulates into shared `.grad` after the end of the previous view (see the class docstring)."""
         v = self._current
-        if v is not None and v.prev_done is not None:
+        if v is None or v.prev_done is None:
+            return
+        if whole:
             v.stream.wait_event(v.prev_done)
+        else:
+            light._post_backward_wait = (v.stream, v.prev_done)
 
     def join(self):
         """The caller's stream waits for every view issued so far."""
