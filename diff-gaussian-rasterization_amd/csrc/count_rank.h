@@ -87,8 +87,14 @@ __device__ __forceinline__ void count_and_rank(ushort4 r, uint32_t off0, uint32_
     }
     if (staged) {
         __syncthreads();
-        const uint32_t lim = (block_base >= (uint32_t)capacity) ? 0u : min(block_total, (uint32_t)capacity - block_base);
-        for (uint32_t i = tid; i < lim; i += 256) ranks[block_base + i] = stage[i];
+        // The bound is tested per element in 64 bits on purpose.  `block_base >= capacity ? 0 : min(block_total,
+        // capacity - block_base)` becomes llvm.usub.sat(capacity, block_base), and hipcc 7.2 selects a wave-uniform
+        // usub.sat as a plain s_sub_i32 without the saturation (the VALU form gets `clamp` and is right): a block whose
+        // run starts past the capacity then wrote all of its ranks behind the buffer (seen as a memory fault by
+        // tests/tools/soak_parity.py; tests/test_hip_edge_cases.py::test_overflow_writes_stay_inside_the_state_buffers).
+        const unsigned long long cap64 = (unsigned long long)(uint32_t)capacity;
+        for (uint32_t i = tid; i < block_total; i += 256)
+            if ((unsigned long long)block_base + i < cap64) ranks[block_base + i] = stage[i];
     }
 }
 

@@ -118,6 +118,67 @@ def test_binning_overflow_is_retried(oracle):
         assert np.array_equal(d0[k], d1[k]), k
 
 
+@pytest.mark.parametrize("variant", ["light", "full"])
+@pytest.mark.parametrize("P,W,H,seed,sm,cap", [
+    (6000, 128, 96, 6, 1.0, 4116),      # every 256-Gaussian block stages its ranks in LDS; most runs start past the capacity
+    (9734, 64, 97, 1107, 2.5, 43032),   # the draw of tests/tools/soak_parity.py that faulted: R = 81 804 > capacity
+    (9734, 64, 97, 1107, 2.5, 1000),    # capacity inside the first block
+    (3000, 48, 48, 5, 6.0, 20000),      # blocks above the LDS stage (direct stores), capacity in the middle of a block
+])
+def test_overflow_writes_stay_inside_the_state_buffers(variant, P, W, H, seed, sm, cap):
+    """A presized forward whose binning buffer is too small must report the overflow (status[0] > capacity, status[1] = 1)
+    and must not write one byte outside the three state buffers: they sit between 1 MiB guard regions here.
+    (Round 2: a wave-uniform saturating subtraction was compiled without the saturation and every block whose ranks
+    started past the capacity wrote them behind the buffer -- csrc/count_rank.h.)"""
+    from dgr_amd import _capi
+    lib = _capi.load(); dev = hh.dev(); G = 1 << 20
+    s = make_scene(P, W, H, seed)
+    s = s._replace(opac=(s.opac * 0.12).astype(np.float32))
+
+    def guarded(n):
+        whole = torch.full((n + 2 * G,), 0xAB, dtype=torch.uint8, device=dev)
+        return whole, whole[G:G + n]
+    gb, geom = guarded(lib.dgr_geometry_bytes(P)); bb, binning = guarded(lib.dgr_binning_bytes(cap, W, H))
+    ib, img = guarded(lib.dgr_image_bytes(W, H))
+    f = lambda *sh: torch.empty(sh, device=dev)  # noqa: E731
+    color, depth, median, var, alpha, unc = f(3, H, W), f(1, H, W), f(1, H, W), f(1, H, W), f(1, H, W), f(P, 1)
+    radii = torch.empty(P, dtype=torch.int32, device=dev); px = torch.empty((P, 1), dtype=torch.int32, device=dev)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    k = dict(bg=hh.T(s.bg), means=hh.T(s.means), opac=hh.T(s.opac), scales=hh.T(s.scales), rots=hh.T(s.rots), view=hh.T(s.view),
+             proj=hh.T(s.proj), campos=hh.T(s.campos), gt=hh.T(s.gt), colors=torch.rand((P, 3), device=dev))
+    p = _capi.ptr
+    front = (_capi.stream_handle(), p(geom), p(binning), cap, p(img), p(status), P, 1, 0, p(k["bg"]), W, H, p(k["means"]), None,
+             p(k["colors"]), p(k["opac"]), p(k["scales"]), sm, p(k["rots"]), None, p(k["view"]), p(k["proj"]), p(k["campos"]),
+             s.tanfovx, s.tanfovy, 0)
+    if variant == "light":
+        rc = lib.dgr_light_forward_presized(*front, p(color), p(depth), p(median), p(alpha), p(k["gt"]), p(var), p(unc), p(px),
+                                            p(radii))
+    else:
+        rc = lib.dgr_full_forward_presized(*front, p(color), p(depth), p(k["gt"]), p(unc), p(radii))
+    torch.cuda.synchronize()
+    assert rc == 0
+    st = status.tolist()
+    assert st[0] > cap and st[1] == 1, st
+    for name, whole, n in (("geometry", gb, geom.numel()), ("binning", bb, binning.numel()), ("image", ib, img.numel())):
+        lo, hi = whole[:G], whole[G + n:]
+        assert int((lo != 0xAB).sum()) == 0, f"{name}: bytes written below the buffer"
+        assert int((hi != 0xAB).sum()) == 0, f"{name}: bytes written above the buffer"
+    # and the same call with room for everything renders (the caller's retry)
+    cap2 = st[0]
+    bb2, binning2 = guarded(lib.dgr_binning_bytes(cap2, W, H))
+    front = front[:2] + (p(binning2), cap2) + front[4:]
+    if variant == "light":
+        rc = lib.dgr_light_forward_presized(*front, p(color), p(depth), p(median), p(alpha), p(k["gt"]), p(var), p(unc), p(px),
+                                            p(radii))
+    else:
+        rc = lib.dgr_full_forward_presized(*front, p(color), p(depth), p(k["gt"]), p(unc), p(radii))
+    torch.cuda.synchronize()
+    st2 = status.tolist()
+    assert rc == 0 and st2[0] == st[0] and st2[1] == 0, st2
+    assert int((bb2[:G] != 0xAB).sum()) == 0 and int((bb2[G + binning2.numel():] != 0xAB).sum()) == 0
+    assert float(depth.max()) > 0.0
+
+
 def test_lazy_status_mode_matches_strict(monkeypatch):
     """DGR_SYNC_MODE=lazy: no host read in forward once the shape is known; results identical, errors raised late."""
     from dgr_amd import light as L
