@@ -1274,6 +1274,56 @@ void dgro_pair_stats(void* st, double* out) { pairStats(*(State*)st, out, nullpt
 void dgro_pair_stats2(void* st, double* out, double* out2) { pairStats(*(State*)st, out, out2); }
 void dgro_pair_stats3(void* st, double* out, double* out2, double* out3) { pairStats(*(State*)st, out, out2, out3); }
 
+// Test infrastructure for the median depth (L/cr/forward.cu:353-364, L/cr/backward.cu:1545-1560): the forward takes the
+// Gaussian at which the transmittance crosses 0.5, the backward finds it again from a transmittance it reconstructs by
+// division.  Two correct implementations can disagree on that Gaussian when some T_k lies within rounding of 0.5 -- with
+// no trace in any output image when the neighbours have (nearly) the same depth.  out[pixel] = min_k |T_k - 0.5| over the
+// transmittances before / after every blended Gaussian of the pixel (forward order, fp32, same thresholds as
+// renderForward<true>) and, with `alphas` (the alpha image the backward is given), over the backward's reconstructed
+// sequence; the parity tests mask pixels whose margin is within the reconstruction error (tests/util.py).
+void dgro_light_median_margin(void* sp, const float* alphas, float* out) {
+    State& st = *static_cast<State*>(sp);
+    const int W = st.W, H = st.H, tiles = st.gx * st.gy;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int tile = 0; tile < tiles; tile++) {
+        const uint32_t r0 = st.ranges[2 * tile], r1 = st.ranges[2 * tile + 1];
+        const int tx = tile % st.gx, ty = tile / st.gx;
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                const uint32_t px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
+                const float pfx = (float)px, pfy = (float)py;
+                float T = 1.0f, margin = 0.5f;
+                std::vector<float> blended;
+                for (uint32_t k = r0; k < r1; k++) {
+                    const uint32_t id = st.point_list[k];
+                    const float dx = st.means2D[2 * (size_t)id] - pfx, dy = st.means2D[2 * (size_t)id + 1] - pfy;
+                    const float* co = &st.conic_opacity[4 * (size_t)id];
+                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float alpha = std::min<decltype(co[3] * m_exp(power))>(0.99f, co[3] * m_exp(power));
+                    if (alpha < 15.0f / 255.0f) continue;
+                    const float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) break;
+                    margin = std::min(margin, std::fabs(test_T - 0.5f));
+                    T = test_T;
+                    blended.push_back(alpha);
+                }
+                // the backward's view of the same sequence: T_final = 1 - alpha image, then one division per Gaussian
+                // (L/cr/backward.cu:477,1500) -- off from the forward's products by the rounding of the alpha sum
+                // divided by T_final, which is why the margin has to be taken on THIS sequence
+                if (alphas) {
+                    float Tb = 1.0f - alphas[(size_t)W * py + px];
+                    for (size_t j = blended.size(); j-- > 0;) {
+                        Tb = Tb / (1.f - blended[j]);
+                        margin = std::min(margin, std::fabs(Tb - 0.5f));
+                    }
+                }
+                out[(size_t)W * py + px] = margin;
+            }
+    }
+}
+
 
 void* dgro_state_new() { return new State(); }
 void dgro_state_free(void* s) { delete static_cast<State*>(s); }

@@ -182,6 +182,17 @@ def light_render_forward(st, bg, colors_precomp, gt_depth):
     return out
 
 
+def light_median_margin(st, alphas=None):
+    """[H, W] min_k |T_k - 0.5| over the blended Gaussians of each pixel (dgr_oracle.cpp: dgro_light_median_margin): how
+    close the median-depth decision of L/cr/forward.cu:353 / backward.cu:1545 came to going the other way."""
+    W, H, _ = _dims(st)
+    out = np.zeros((H, W), np.float32)
+    st._l.dgro_light_median_margin.restype = None
+    alphas = None if alphas is None else _f(alphas)
+    st._l.dgro_light_median_margin(st._h, _p(alphas), _p(out))
+    return out
+
+
 def _dims(st):
     ptr, elem = C.c_void_p(), C.c_int()
     P = st._l.dgro_state_get(st._h, b"radii", C.byref(ptr), C.byref(elem))

@@ -74,7 +74,8 @@ for i in range(n_light):
         # pixels on which the two forward passes decided a hard threshold differently get zero incoming gradient on both
         # sides (tests/util.py): every draw is compared, with no outlier allowance beyond the backward's own median test
         grads, nmask = mask_flipped_pixels(grads, hh.hip_state("n_contrib", s, d), st.get("n_contrib"), s.W, s.H, tag,
-                                           images=[(d[k], ref[k]) for k in ("color", "depth", "depth_median", "opacity_map")])
+                                           images=[(d[k], ref[k]) for k in ("color", "depth", "depth_median", "opacity_map")],
+                                           median_margin=O.light_median_margin(st, ref["opacity_map"]))
         flips += int(nmask > 0)
         modes = [(False, False), (True, False), (False, True)][i % 3]
         if only:
@@ -87,8 +88,11 @@ for i in range(n_light):
         names += [] if "cov3D_precomp" in kw else ["dL_dscales", "dL_drotations"]
         for k in names:
             assert_grad_close(g[k], gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3,
-                              outlier_rows=2 if k == "dL_dmeans3D" else 0)
-        assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=0.1)
+                              outlier_rows=0)
+        # ONE float sum over every (pixel, Gaussian) pair: summation order shows from ~1e5 Gaussians on (the config 5 test
+        # of tests/test_hip_light_parity.py carries the same bar)
+        assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=2e-5 if s.means.shape[0] < 50000 else 5e-4,
+                          elem_rtol=2e-3, elem_frac=0.1)
         if only:
             import torch
             torch.cuda.synchronize()
@@ -123,6 +127,6 @@ for i in range(n_full):
         fails.append((tag, str(e)[:300]))
         print("FAIL", tag, str(e)[:300], flush=True)
 
-print(f"{n_light} light + {n_full} full draws in {time.time() - t0:.0f} s: {len(fails)} failures, {flips} draws with a pair the "
-      f"two implementations decided differently")
+print(f"{n_light} light + {n_full} full draws in {time.time() - t0:.0f} s: {len(fails)} failures, {flips} draws with masked "
+      f"pixels (a hard decision within rounding of its threshold)")
 sys.exit(1 if fails else 0)
