@@ -118,6 +118,9 @@ std::atomic<int> g_tight_cull{0};
 // slower on the forward that has to produce the 16-bit tags: off by default, kept for A/B runs.
 // Set it before the forward whose backward should use it.
 std::atomic<int> g_bwd_rows{0};
+// dgr_set_option("lds_count", 0): presized forward counts tile instances with returning global atomics inside
+// preprocess_fwd (round 2's fused count) instead of in per-workgroup LDS histograms (binning.hip: count_lds); for A/B runs
+std::atomic<int> g_lds_count{1};
 
 // A kernel stage hands its two events to the stage's first kernel launch (dgr::launch, kernels.h): they then hold
 // that kernel's start and end.  A stage without a kernel (the scratch memset) is bracketed with hipEventRecord.
@@ -182,8 +185,15 @@ int zero_outputs(const FwdCommon& c, hipStream_t st) {
 // block and scan_blocks turns them into offsets and num_rendered.  Presized path (the binning buffer exists already):
 // the kernel also takes the tile-counter atomics and stores the ranks (count_rank.h), behind one small clear of the
 // counters; scan_blocks and count_rank disappear.
+// Presized path, counting mode: COUNT_LDS = per-workgroup LDS histograms after preprocess (binning.hip; frames whose tile
+// histogram fits LDS), COUNT_FUSED = returning global atomics inside preprocess_fwd.
+enum { COUNT_CALLBACK = 0, COUNT_FUSED = 1, COUNT_LDS = 2 };
+int presized_count_mode(int W, int H) {
+    return (g_lds_count.load() && dgr::count_lds_fits(dgr::tiles_x(W) * dgr::tiles_y(H))) ? COUNT_LDS : COUNT_FUSED;
+}
 int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, hipStream_t st,
-                  const dgr::BinningView* bin = nullptr, int capacity = 0, char* image_base = nullptr) {
+                  const dgr::BinningView* bin = nullptr, int capacity = 0, char* image_base = nullptr,
+                  int mode = COUNT_CALLBACK) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
     // No memsets: preprocess clears the per-Gaussian median statistics (and, on the callback path, the tile counters);
     // scan_blocks / scan_tiles initialise the status word.
@@ -201,6 +211,12 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
     a.geom = geom; a.radii_out = c.radii;
     a.gau_uncertainty = c.gau_uncertainty; a.gau_related_pixels = c.gau_related_pixels;
     (void)tiles;
+    if (bin && mode == COUNT_LDS) {
+        // nothing to clear: the kernel leaves its per-block instance totals (and the `prefiltered` flag) in
+        // geom.block_tiles, count_lds / scan_table take it from there
+        { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd(a, st)); }
+        return DGR_OK;
+    }
     if (bin) {
         // cursor + padded tile counters: everything between the start of the image buffer and the range table
         { ScopedStage t(ST_ZERO_FWD, st); HIP_TRY(dgr::launch_zero_fill(image_base, (size_t)((char*)img.ranges - image_base), st)); }
@@ -219,8 +235,18 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
 // (`fused`: preprocess_fwd counted already; the status word is complete after scan_tiles, which is where a caller that
 // armed the early status gets its copy)
 int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, int capacity,
-                   hipStream_t st, bool fused = false) {
+                   hipStream_t st, int mode = COUNT_CALLBACK, char* binning_base = nullptr) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
+    if (mode == COUNT_LDS) {
+        const dgr::CountTable ct = dgr::carve_count_table(binning_base + bin.bytes, c.W, c.H);
+        { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_lds(c.P, geom, bin, ct, gx, tiles, capacity, st)); }
+        { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_table(c.P, geom, img, ct, tiles, capacity, st)); }
+        { const int rc = early_status_post(img.status, st); if (rc) return rc; }
+        { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st, ct.table, tiles, dgr::count_lds_workgroups(c.P))); }
+        { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
+        return DGR_OK;
+    }
+    const bool fused = mode == COUNT_FUSED;
     if (!fused) { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_rank(c.P, geom, img, bin, gx, capacity, st)); }
     { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, gx, capacity, fused, st)); }
     if (fused) { const int rc = early_status_post(img.status, st); if (rc) return rc; }
@@ -323,7 +349,10 @@ const char* dgr_version(void) { return "dgr_hip 0.1 gfx950"; }
 
 size_t dgr_geometry_bytes(int P) { return dgr::carve_geometry(nullptr, P).bytes; }
 size_t dgr_image_bytes(int width, int height) { return dgr::carve_image(nullptr, width, height).bytes; }
-size_t dgr_binning_bytes(int cap, int, int) { return dgr::carve_binning(nullptr, (size_t)(cap > 0 ? cap : 0)).bytes; }
+size_t dgr_binning_bytes(int cap, int width, int height) {
+    // the sorted list, keys, ranks and tags of `cap` instances, then the forward-only workspace of the LDS count
+    return dgr::carve_binning(nullptr, (size_t)(cap > 0 ? cap : 0)).bytes + dgr::carve_count_table(nullptr, width, height).bytes;
+}
 size_t dgr_light_backward_scratch_bytes(int P, int, int) { return dgr::carve_backward_scratch(nullptr, P).bytes; }
 
 int dgr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present) {
@@ -355,8 +384,9 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
-    if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer))) return rc;
-    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, true))) return rc;
+    const int mode = presized_count_mode(width, height);
+    if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer, mode))) return rc;
+    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer))) return rc;
     if ((rc = forward_back(c, geom, img, bin, st))) return rc;
     return DGR_OK;
 }
@@ -485,8 +515,9 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
-    if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer))) return rc;
-    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, true))) return rc;
+    const int mode = presized_count_mode(width, height);
+    if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer, mode))) return rc;
+    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer))) return rc;
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
     return DGR_OK;
 }
@@ -762,6 +793,7 @@ int dgr_set_option(const char* name, int value) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }
     if (n == "bwd_rows") { g_bwd_rows.store(value ? 1 : 0); return DGR_OK; }
+    if (n == "lds_count") { g_lds_count.store(value ? 1 : 0); return DGR_OK; }
     if (n == "profile_every") { g_profile_every.store(value > 0 ? value : 1); return DGR_OK; }
     g_last_error = "unknown option: " + n;
     return DGR_ERR_BAD_ARGUMENT;
@@ -770,6 +802,7 @@ int dgr_get_option(const char* name) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") return g_tight_cull.load();
     if (n == "bwd_rows") return g_bwd_rows.load();
+    if (n == "lds_count") return g_lds_count.load();
     if (n == "profile_every") return g_profile_every.load();
     return DGR_ERR_BAD_ARGUMENT;
 }

@@ -22,6 +22,7 @@
 #include "dgr_common.h"
 #include "kernels.h"
 #include "count_rank.h"
+#include <mutex>
 
 namespace dgr {
 namespace {
@@ -166,17 +167,212 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_blocks_kernel(uint32_t* blo
     }
 }
 
+// `table` (LDS count, below): slot = table[w][tile] + rank, where w is the counting workgroup of the Gaussian's
+// 1024-chunk and table[w][tile] already holds range start + the instances workgroups < w counted for that tile;
+// otherwise (global tile counters) slot = range start + arrival rank.
 __global__ void __launch_bounds__(256) emit_instances_kernel(int P, GeometryView geom, ImageView img, BinningView bin,
-                                                             int grid_x) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+                                                             int grid_x, const uint32_t* __restrict__ table, int tiles, int nwg) {
+    int vb = blockIdx.x;
+    if (table) {
+        // Row w of the table is read by the Gaussians of the chunks w, w + nwg, ...: hand every XCD (block b runs on XCD
+        // b % 8) the chunks c with c % 8 == its index -- nwg is a multiple of 8 or the whole grid is tiny -- so that a row
+        // is fetched into ONE L2 (32 rows = 1 MB per XCD at 1080p) instead of into up to eight (measured: 37 -> 27 us).
+        const int xcd = vb & 7, local = vb >> 3;
+        vb = 4 * (xcd + 8 * (local >> 2)) + (local & 3);
+    }
+    const int idx = vb * 256 + threadIdx.x;
     if (idx >= P) return;
     if (img.status[1]) return;  // binning buffer too small: leave every tile list empty
     const ushort4 r = geom.rect[idx];
     if (r.z <= r.x || r.w <= r.y) return;
     const uint64_t key = ((uint64_t)__float_as_uint(geom.depths[idx]) << 32) | (uint32_t)idx;
     const uint32_t* rk = bin.ranks + geom.goff[idx];
+    if (table) {
+        const uint32_t* row = table + (size_t)((idx >> 10) % nwg) * tiles;  // (idx >> 10 = the Gaussian's counting chunk)
+        for (int y = r.y; y < r.w; y++)
+            for (int x = r.x; x < r.z; x++) bin.keys[row[y * grid_x + x] + *rk++] = key;
+        return;
+    }
     for (int y = r.y; y < r.w; y++)
         for (int x = r.x; x < r.z; x++) bin.keys[img.ranges[y * grid_x + x].x + *rk++] = key;
+}
+
+// ---- counting in LDS (presized path) ----------------------------------------------------------------------------
+// The memory-side atomic unit retires ~26 G operations/s for the whole chip (profiles/microbench/atomics.hip): one
+// returning atomic per tile instance is 55 us at config 3 and 230 us at config 4, with the CUs idle.  An LDS atomic
+// costs a few cycles of ONE CU's LDS, and a whole frame's tile histogram fits one workgroup's LDS (8 160 tiles = 32 KB
+// at 1080p, 32 400 = 127 KB at 3840x2160, of 160 KB).  So the instances are counted by DGR_COUNT_WGS persistent
+// 1024-thread workgroups, each with a PRIVATE histogram of the whole frame in LDS:
+//   count_lds  : workgroup w takes the 1024-Gaussian chunks w, w + G, ...; a Gaussian's instance run starts at
+//                (instances of all earlier chunks, from preprocess_fwd's per-256-block totals) + (scan inside the chunk)
+//                -- the reference's point_offsets -- and every instance takes a returning ds_add on the workgroup's
+//                histogram: its rank among the instances THIS workgroup sends to that tile.  At the end the histogram
+//                goes to row w of table[G][tiles] and its running sums over 64-tile segments to seg[segment][w];
+//   scan_table : one workgroup per 64-tile segment: instances of all earlier segments (G values of seg), column sums = tile
+//                totals -> ranges, status word; table[w][tile] <- range start + instances workgroups < w sent there;
+//   emit       : slot = table[w][tile] + rank.  Any unique placement inside the tile's segment will do: sort_tiles orders it.
+// No global atomics, no cleared counters, no cursor: the zero_fill launch in front of the forward is gone too.
+constexpr int CL_THREADS = 1024;
+constexpr int SEG_TILES = 64;
+
+__global__ void __launch_bounds__(CL_THREADS) count_lds_kernel(int P, GeometryView geom, uint32_t* __restrict__ ranks,
+                                                               uint32_t* __restrict__ table, uint32_t* __restrict__ seg,
+                                                               int grid_x, int tiles, int nseg, int capacity) {
+    extern __shared__ uint32_t hist[];  // [tiles]
+    __shared__ uint32_t wsum[CL_THREADS / 64], psum[CL_THREADS / 64];
+    __shared__ uint32_t segsum[(DGR_COUNT_LDS_MAX_TILES + SEG_TILES - 1) / SEG_TILES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < tiles; i += CL_THREADS) hist[i] = 0u;
+    const int nblocks = (P + 255) / 256, nchunks = (P + CL_THREADS - 1) / CL_THREADS;
+    uint32_t run = 0;    // instances of the 256-blocks [0, next_block)
+    int next_block = 0;
+    __syncthreads();
+    for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        // instances of the chunks between the previous one of this workgroup and this one
+        const int first = 4 * chunk;
+        uint32_t part = 0;
+        for (int b = next_block + tid; b < first; b += CL_THREADS) part += geom.block_tiles[b] & 0x7fffffffu;
+        const int idx = chunk * CL_THREADS + tid;
+        ushort4 r = make_ushort4(0, 0, 0, 0);
+        if (idx < P) r = geom.rect[idx];
+        const uint32_t w = (uint32_t)(r.z - r.x), h = (uint32_t)(r.w - r.y);
+        const uint32_t n = w * h;
+        uint32_t incl = n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        if (lane == 63) wsum[wave] = incl;
+        if (lane == 0) psum[wave] = part;
+        __syncthreads();
+        uint32_t before = 0, chunk_total = 0, skipped = 0;
+#pragma unroll
+        for (int ww = 0; ww < CL_THREADS / 64; ww++) {
+            const uint32_t v = wsum[ww];
+            if (ww < wave) before += v;
+            chunk_total += v;
+            skipped += psum[ww];
+        }
+        __syncthreads();  // (wsum / psum are rewritten by the next chunk)
+        const uint32_t off0 = run + skipped + before + incl - n;
+        run += skipped + chunk_total;
+        next_block = min(first + 4, nblocks);
+        if (idx < P) geom.goff[idx] = off0;
+        // past the capacity an instance is still counted, so that scan_table sees the true total and flags the overflow
+        const bool store = (unsigned long long)off0 + n <= (unsigned long long)(uint32_t)capacity;
+        uint32_t k = off0;
+        for (uint32_t y = r.y; y < r.w; y++) {
+            uint32_t* hrow = hist + y * (uint32_t)grid_x;
+            for (uint32_t x = r.x; x < r.z; x++, k++) {
+                const uint32_t rank = atomicAdd(hrow + x, 1u);
+                if (store) ranks[k] = rank;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t* row = table + (size_t)blockIdx.x * tiles;
+    for (int i = tid; i < tiles; i += CL_THREADS) row[i] = hist[i];
+    // seg[s][w] = instances this workgroup sent to the tiles of segments 0..s (inclusive scan over the segments)
+    for (int sgm = wave; sgm < nseg; sgm += CL_THREADS / 64) {
+        const int t = sgm * SEG_TILES + lane;
+        uint32_t v = (t < tiles) ? hist[t] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) segsum[sgm] = v;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t carry = 0;
+        for (int b0 = 0; b0 < nseg; b0 += 64) {
+            uint32_t incl = (b0 + lane < nseg) ? segsum[b0 + lane] : 0u;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += v;
+            }
+            if (b0 + lane < nseg) seg[(size_t)(b0 + lane) * gridDim.x + blockIdx.x] = carry + incl;
+            carry += __shfl(incl, 63, 64);
+        }
+    }
+}
+
+// One workgroup per 64-tile segment; wave g handles the table rows [g * rows_per, (g + 1) * rows_per) of the segment's
+// 64 columns (lane = tile: 256-byte row pieces).  nwg <= 16 * ROWS_MAX.
+constexpr int ST_ROWS_MAX = 16;
+__global__ void __launch_bounds__(CL_THREADS) scan_table_kernel(ImageView img, uint32_t* __restrict__ table,
+                                                                const uint32_t* __restrict__ seg,
+                                                                const uint32_t* __restrict__ block_tiles, int nblocks,
+                                                                int tiles, int nwg, int capacity) {
+    __shared__ uint32_t grp[CL_THREADS / 64][SEG_TILES];
+    __shared__ uint32_t red[3][CL_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sgm = blockIdx.x;
+    const int tile = sgm * SEG_TILES + lane;
+    const bool live = tile < tiles;
+    const int rows_per = (nwg + CL_THREADS / 64 - 1) / (CL_THREADS / 64);
+    const int r0 = wave * rows_per;
+    uint32_t c[ST_ROWS_MAX];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int i = 0; i < ST_ROWS_MAX; i++) {
+        c[i] = (live && i < rows_per && r0 + i < nwg) ? table[(size_t)(r0 + i) * tiles + tile] : 0u;
+        mine += c[i];
+    }
+    grp[wave][lane] = mine;
+    // instances of all earlier segments and the grand total, from the workgroups' inclusive segment sums; block 0 also
+    // collects the `prefiltered` flag from preprocess_fwd's block totals
+    uint32_t before_seg = 0, total = 0, flag = 0;
+    const int nseg = gridDim.x;
+    for (int i = tid; i < nwg; i += CL_THREADS) {
+        if (sgm > 0) before_seg += seg[(size_t)(sgm - 1) * nwg + i];
+        total += seg[(size_t)(nseg - 1) * nwg + i];
+    }
+    if (sgm == 0)
+        for (int i = tid; i < nblocks; i += CL_THREADS) flag |= block_tiles[i] >> 31;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        before_seg += __shfl_xor(before_seg, off, 64);
+        total += __shfl_xor(total, off, 64);
+        flag |= __shfl_xor(flag, off, 64);
+    }
+    if (lane == 0) { red[0][wave] = before_seg; red[1][wave] = total; red[2][wave] = flag; }
+    __syncthreads();
+    before_seg = 0; total = 0; flag = 0;
+#pragma unroll
+    for (int ww = 0; ww < CL_THREADS / 64; ww++) { before_seg += red[0][ww]; total += red[1][ww]; flag |= red[2][ww]; }
+    uint32_t above = 0, count = 0;  // instances the row groups before this wave's sent to the tile; the tile's total
+#pragma unroll
+    for (int ww = 0; ww < CL_THREADS / 64; ww++) {
+        const uint32_t v = grp[ww][lane];
+        if (ww < wave) above += v;
+        count += v;
+    }
+    uint32_t incl = count;  // exclusive scan over the segment's 64 tiles (every wave computes the same)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    const bool overflow = total > (uint32_t)capacity;
+    const uint32_t start = before_seg + incl - count;
+    uint32_t base = start + above;
+#pragma unroll
+    for (int i = 0; i < ST_ROWS_MAX; i++) {
+        if (live && i < rows_per && r0 + i < nwg) table[(size_t)(r0 + i) * tiles + tile] = base;
+        base += c[i];
+    }
+    // (empty tiles keep {0, 0}: the reference clears the table and writes only tiles that own instances)
+    if (wave == 0 && live) img.ranges[tile] = (overflow || count == 0u) ? make_uint2(0u, 0u) : make_uint2(start, start + count);
+    if (sgm == 0 && tid == 0) {
+        img.status[0] = (int)total;
+        img.status[1] = overflow ? 1 : 0;
+        img.status[2] = (int)flag;  // prefiltered violation
+        img.status[3] = 0;          // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
+        img.cursor[2] = (uint32_t)capacity;
+    }
 }
 
 // ---- per-tile sort ------------------------------------------------------------------------------
@@ -302,9 +498,34 @@ hipError_t launch_scan_blocks(int P, GeometryView geom, ImageView img, hipStream
     launch(scan_blocks_kernel, dim3(1), dim3(SCAN_THREADS), stream, geom.block_tiles, (P + 255) / 256, img.status);
     return hipGetLastError();
 }
-hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream) {
+hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream,
+                                 const uint32_t* table, int tiles, int nwg) {
     if (P <= 0) return hipSuccess;
-    launch(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), stream, P, geom, img, bin, grid_x);
+    // with a table: 8 XCDs x (chunks per XCD) x 4 blocks per 1024-chunk (blocks past P return at once)
+    const int nblocks = table ? 8 * 4 * (((P + 1023) / 1024 + 7) / 8) : (P + 255) / 256;
+    launch(emit_instances_kernel, dim3(nblocks), dim3(256), stream, P, geom, img, bin, grid_x, table, tiles, nwg);
+    return hipGetLastError();
+}
+int count_lds_workgroups(int P) { return max(1, min(DGR_COUNT_WGS, (P + CL_THREADS - 1) / CL_THREADS)); }
+bool count_lds_fits(int tiles) { return tiles > 0 && tiles <= DGR_COUNT_LDS_MAX_TILES; }
+hipError_t launch_count_lds(int P, GeometryView geom, BinningView bin, CountTable ct, int grid_x, int tiles, int capacity,
+                            hipStream_t stream) {
+    static std::once_flag once;
+    static hipError_t attr_rc = hipSuccess;
+    std::call_once(once, [] {
+        attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(count_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      DGR_COUNT_LDS_MAX_TILES * 4);
+    });
+    if (attr_rc != hipSuccess) return attr_rc;
+    const int nwg = count_lds_workgroups(P), nseg = (tiles + SEG_TILES - 1) / SEG_TILES;
+    launch_shmem(count_lds_kernel, dim3(nwg), dim3(CL_THREADS), (size_t)tiles * 4, stream, P, geom, bin.ranks, ct.table, ct.seg,
+                 grid_x, tiles, nseg, capacity);
+    return hipGetLastError();
+}
+hipError_t launch_scan_table(int P, GeometryView geom, ImageView img, CountTable ct, int tiles, int capacity, hipStream_t stream) {
+    const int nwg = count_lds_workgroups(P), nseg = (tiles + SEG_TILES - 1) / SEG_TILES;
+    launch(scan_table_kernel, dim3(nseg), dim3(CL_THREADS), stream, img, ct.table, ct.seg, geom.block_tiles, (P + 255) / 256,
+           tiles, nwg, capacity);
     return hipGetLastError();
 }
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream) {

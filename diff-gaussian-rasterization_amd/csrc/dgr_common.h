@@ -109,6 +109,28 @@ __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
     return b;
 }
 
+// Forward-only workspace of the LDS count (binning.hip), carved behind the binning arrays: row w of `table` is the tile
+// histogram of counting workgroup w (afterwards: slot bases), seg[s][w] its sums over 64-tile segments.
+#ifndef DGR_COUNT_WGS
+#define DGR_COUNT_WGS 256              // one persistent counting workgroup per CU
+#endif
+#define DGR_COUNT_LDS_MAX_TILES 40000  // 160 000 B of the 160 KB of LDS: 3840x2160 has 32 400 tiles
+struct CountTable {
+    uint32_t* table;  // [DGR_COUNT_WGS * tiles]
+    uint32_t* seg;    // [ceil(tiles / 64) * DGR_COUNT_WGS]
+    size_t bytes;
+};
+__host__ __device__ inline CountTable carve_count_table(char* base, int W, int H) {
+    CountTable t;
+    const size_t tiles = (size_t)((W + DGR_BLOCK_X - 1) / DGR_BLOCK_X) * ((H + DGR_BLOCK_Y - 1) / DGR_BLOCK_Y);
+    size_t o = 0;
+    if (tiles == 0 || tiles > DGR_COUNT_LDS_MAX_TILES) { t.table = nullptr; t.seg = nullptr; t.bytes = 0; return t; }
+    t.table = (uint32_t*)(base + o); o = align_up(o + 4 * tiles * DGR_COUNT_WGS, 256);
+    t.seg = (uint32_t*)(base + o);   o = align_up(o + 4 * ((tiles + 63) / 64) * DGR_COUNT_WGS, 256);
+    t.bytes = o;
+    return t;
+}
+
 // ---- backward scratch --------------------------------------------------------------------------
 // One 64-byte accumulator row per Gaussian so that every atomic of a (pixel, Gaussian) pair lands
 // in a single cache line:

@@ -26,6 +26,16 @@ inline void launch(K kernel, dim3 grid, dim3 block, hipStream_t stream, Args... 
         hipLaunchKernelGGL(kernel, grid, block, 0, stream, args...);
     }
 }
+template <typename K, typename... Args>
+inline void launch_shmem(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t stream, Args... args) {
+    LaunchEvents* ev = g_launch_events;
+    if (ev && !ev->used) {
+        ev->used = true;
+        hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ev->start, ev->stop, 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, grid, block, shmem, stream, args...);
+    }
+}
 
 
 struct PreprocessFwdArgs {
@@ -203,7 +213,14 @@ hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity,
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,
                              hipStream_t stream);
 hipError_t launch_scan_blocks(int P, GeometryView geom, ImageView img, hipStream_t stream);
-hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream);
+hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream,
+                                 const uint32_t* table = nullptr, int tiles = 0, int nwg = 1);
+// counting in LDS (binning.hip): presized path, frames of at most DGR_COUNT_LDS_MAX_TILES tiles
+bool count_lds_fits(int tiles);
+int count_lds_workgroups(int P);
+hipError_t launch_count_lds(int P, GeometryView geom, BinningView bin, CountTable ct, int grid_x, int tiles, int capacity,
+                            hipStream_t stream);
+hipError_t launch_scan_table(int P, GeometryView geom, ImageView img, CountTable ct, int tiles, int capacity, hipStream_t stream);
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);
 
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream);

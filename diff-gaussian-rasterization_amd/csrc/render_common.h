@@ -46,7 +46,7 @@ struct StagedT {
     static constexpr int LIST_LD = NB + 8;    // list row: NB entries + sentinel padding, 8-byte aligned rows
     float4 rec[2 * (NB + 1)];  // [2*slot] = {x, y, a2, c2}, [2*slot+1] = {b2, opacity, slot (int bits), lthr}
                                //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power (pair_p2)
-    float4 rgbd[NB];           // {r, g, b, depth}
+    float4 rgbd[NB + 1];       // {r, g, b, depth}; [NB] = zeros (the sentinel's entry: the branch-free backward reads it)
     uint32_t id[NB];
     unsigned short list[4][LIST_LD];  // per consumer wave: byte offsets (slot * 32) into rec, tile-list order
     int cnt4[4][4];                   // [staging wave][consumer wave] entries contributed
@@ -104,7 +104,8 @@ __device__ __forceinline__ unsigned stage_tagged(StagedT<NB>& s, int slot, uint3
     const float4 q1 = rec[3 * (size_t)gid + 1];
     const float4 q2 = rec[3 * (size_t)gid + 2];
     s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
-    s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, q0.w, __int_as_float(slot), 0.f);
+    // (.w: byte offset of the slot's rgbd entry -- the light backward addresses LDS with it directly)
+    s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, q0.w, __int_as_float(slot), __int_as_float(slot * 16));
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
     return code;
@@ -175,11 +176,13 @@ __device__ __forceinline__ void load2(const StagedT<NB>& s, int wave, int k, flo
 }
 
 
-// sentinel record: p2 = 0 but lthr = +big, so it never passes `p2 >= lthr`
-template <int NB>
+// sentinel record: p2 = 0 but lthr = +big, so it never passes `p2 >= lthr`; opacity 0, so its alpha is 0.
+// TAGGED (backward staging, stage_tagged): .w carries the byte offset of the sentinel's all-zero rgbd entry instead.
+template <bool TAGGED = false, int NB>
 __device__ __forceinline__ void write_sentinel(StagedT<NB>& s) {
     s.rec[2 * NB] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s.rec[2 * NB + 1] = make_float4(0.f, 0.f, __int_as_float(NB), 3.0e38f);
+    s.rec[2 * NB + 1] = make_float4(0.f, 0.f, __int_as_float(NB), TAGGED ? __int_as_float(NB * 16) : 3.0e38f);
+    s.rgbd[NB] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 constexpr int NACC = DGR_ACC_STRIDE;          // accumulator components carried per staged instance (<= 16)

@@ -27,6 +27,9 @@
 // reduction); forward and backward use the identical expression so they agree on every decision.
 #include "render_common.h"
 
+#ifndef DGR_REDUCE_DPP
+#define DGR_REDUCE_DPP 0  // 1: the twelve-value reduction with its within-row stages first (wave_reduce12d)
+#endif
 #ifndef DGR_ABLATE
 #define DGR_ABLATE 0  // 1 / 2: measurement builds (profiles/ablate.sh), never shipped
 #endif
@@ -221,7 +224,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
 
     if (tid == 0) {
         sb.max_last = 0;
-        write_sentinel(s);
+        write_sentinel<true>(s);
     }
     __syncthreads();
     {
@@ -255,12 +258,18 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     // only to form dL/dalpha = sum_c (c_j - accum_rec_c) dL/dpixel_c.  They are linear, so one scalar suffices:
     //   X_j = <features_j, dL/dpixel>,   S <- alpha_last X_last + (1 - alpha_last) S,   dL/dalpha = X_j - S.
     float S = 0.f;
-    bool mid_once = true;
+    float mid_thr = 0.5f;
     // which accumulator component this lane's quad delivers after the butterfly (-1: none)
     int my_comp;
     if (DO_MAP) {
-        const int c = wave_reduce16_comp(lane);  // butterfly slots 0..9 = components 0..9, slot 10 = component 13
-        my_comp = ((lane & 3) != 0 || c > 10) ? -1 : (c == 10 ? (DO_POSE ? 13 : -1) : c);
+        // butterfly slots 0..9 = components 0..9; with the pose gradient slot 10 = component 13 (pose depth) and slot 11 =
+        // component 10 (median), without it slot 10 = component 10
+#if DGR_REDUCE_DPP
+        const int c = (lane >= 48) ? 12 : wave_reduce12d_comp(lane);  // (rows 2 and 3 hold the same four totals: row 2 delivers)
+#else
+        const int c = wave_reduce16_comp(lane);
+#endif
+        my_comp = ((lane & 3) != 0 || c > 11) ? -1 : (c == 10 ? (DO_POSE ? 13 : 10) : c == 11 ? (DO_POSE ? 10 : -1) : c);
     } else {
         const int c = wave_reduce4_comp(lane);  // {4: gmx, 5: gmy, 13: pose depth}
         my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
@@ -295,37 +304,38 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
                 const float oG = alpha_raw(q1[u].y, p2);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
-                const float alpha = fminf(0.99f, oG);
-                const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
-
-                // per-lane scalars of this pair; they stay 0 on lanes the Gaussian does not reach, so the products
-                // below need no masking:  w = alpha T,  qq = o G dL/dalpha  (dL_dG * G)
-                float w = 0.f, qq = 0.f, e = 0.f;
-                const float4 cd = s.rgbd[j];
-                if (valid) {
-                    const float om = 1.f - alpha;
-                    const float inv = recip(om);
-                    T = T * inv;
-                    w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
-                    e = cd.w - gt_px;
-                    const float X = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2 + cd.w * dpix_depth + (e * e) * dpix_var;
-                    const float dL_dalpha = (X - S) * T + bg_term * inv;
-                    S = alpha * X + om * S;  // what the NEXT valid pair (towards the front) subtracts: same operations, same order
-                    qq = oG * dL_dalpha;
-                    if (DO_MAP && T > 0.5f && mid_once) {
-                        // backward.cu:654-664, once per pixel: the median-depth term of dL/dmean3D is
-                        // (v_k - v_{k+1} mul3) * dL/dmedian with factors that depend on the Gaussian alone, so only
-                        // the pixel sum of dL/dmedian is formed here (one LDS atomic); preprocess_bwd applies them.
-                        atomicAdd(&sb.acc[10 * BWD_LD + j], dpix_median);
-                        mid_once = false;
-                    }
-                }
+                const float alpha0 = fminf(0.99f, oG);
+                const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha0 >= ALPHA_MIN);
+                // No branch: a lane the Gaussian does not reach runs the same instructions with alpha = 0 and o G = 0, which
+                // leave its state untouched -- 1/(1 - 0) is exactly 1, so T, and S = 0 X + 1 S, keep their bits -- and
+                // make every one of its contributions 0.  (The list's sentinel entries have opacity 0 and an all-zero
+                // rgbd entry.)  Valid lanes execute the operations of the reference's order unchanged.
+                const float alpha = valid ? alpha0 : 0.f;
+                const float oGm = valid ? oG : 0.f;
+                const float4 cd = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rgbd) + __float_as_int(q1[u].w));
+                const float om = 1.f - alpha;
+                const float inv = recip(om);
+                T = T * inv;
+                const float w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
+                const float e = cd.w - gt_px;
+                const float X = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2 + cd.w * dpix_depth + (e * e) * dpix_var;
+                const float dL_dalpha = (X - S) * T + bg_term * inv;
+                S = alpha * X + om * S;  // what the NEXT valid pair (towards the front) subtracts: same operations, same order
+                const float qq = oGm * dL_dalpha;  // o G dL/dalpha  (dL_dG * G)
                 // Per-lane contributions are the raw moments of qq over the pixel offsets; the factors that depend on the
                 // Gaussian only (conic, 1/opacity, the ndc scale) are applied once per (tile, Gaussian) in finish_rows().
                 const float qdx = qq * dx, qdy = qq * dy;
                 const float wd = w * dpix_depth;
                 float tot;
                 if (DO_MAP) {
+                    // backward.cu:654-664, once per pixel -- at its first valid pair from the back with T > 0.5: the
+                    // median-depth term of dL/dmean3D is (v_k - v_{k+1} mul3) * dL/dmedian with factors that depend on
+                    // the Gaussian alone, so only the pixel sum of dL/dmedian is formed here, as one more value of the
+                    // butterfly (its twelfth slot is free); preprocess_bwd applies the factors.  `mid_thr` turns to +inf
+                    // once the pixel has fired.
+                    const bool fire = valid & (T > mid_thr);
+                    const float gmed = fire ? dpix_median : 0.f;
+                    mid_thr = fire ? __builtin_inff() : mid_thr;
                     float g[12];
                     g[0] = w * dpix0;
                     g[1] = w * dpix1;
@@ -337,19 +347,27 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     g[7] = qdx * dy;   // sum q dx dy
                     g[8] = qdy * dy;   // sum q dy^2
                     g[9] = qq;         // sum q
-                    g[10] = DO_POSE ? wd : 0.f;  // -> accumulator component 13
-                    g[11] = 0.f;
+                    g[10] = DO_POSE ? wd : gmed;   // -> accumulator component 13 / 10
+                    g[11] = DO_POSE ? gmed : 0.f;  // -> accumulator component 10
 #if DGR_ABLATE == 2
-                    tot = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7])) + ((g[8] + g[9]) + g[10]);  // (measurement build: no butterfly)
+                    tot = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7])) + ((g[8] + g[9]) + (g[10] + g[11]));  // (measurement build: no butterfly)
 #else
-                    tot = wave_reduce12<!DO_POSE>(g);
+#if DGR_REDUCE_DPP
+                    tot = wave_reduce12d(g);
+#else
+                    tot = wave_reduce12(g);
+#endif
 #endif
                 } else {
                     float g4[4] = {qdx, qdy, wd, 0.f};
                     tot = wave_reduce4(g4);
                 }
                 // j is wave-uniform here (every lane read the same record)
+#if DGR_ABLATE == 3
+                if (my_comp >= 0) sb.acc[my_comp * BWD_LD + j] = tot;  // (measurement build: a plain store instead of the LDS atomic)
+#else
                 if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * BWD_LD + j], tot);
+#endif
             }
         }
 

@@ -108,6 +108,44 @@ __device__ __forceinline__ float wave_reduce12(float (&x)[12]) {
     return u;
 }
 
+// The same twelve sums with the within-row stages FIRST.  A DPP add issues at 1.4x a plain VALU instruction, a permlane
+// swap at 2.7x (profiles/microbench/valu_rates.hip), and a merge stage needs one DPP add per input register whatever the
+// register count -- so the two stages that halve the register count inside a 16-lane row (row_mirror, row_half_mirror,
+// written through bank masks: 12 -> 6 -> 3 registers, 18 DPP adds) run on all twelve registers, and the two cross-row
+// stages, which only the swaps can do, run on the three that are left: 3 swaps instead of 9.
+//   value held by lane l afterwards:  4 min(l >> 4, 2) + {0, 2, 1, 3}[(l >> 2) & 3]   (rows 2 and 3 both hold values 8..11)
+__device__ __forceinline__ int wave_reduce12d_comp(int lane) {
+    const int r = lane >> 4, b = (lane >> 2) & 3;
+    return 4 * (r < 2 ? r : 2) + ((b == 1) ? 2 : (b == 2) ? 1 : b);
+}
+#define DGR_MERGE(d, s, ctrl, m0, m1) \
+    "v_add_f32_dpp %" #d ", %" #d ", %" #d " " ctrl " row_mask:0xf bank_mask:" m0 "\n\t" \
+    "v_add_f32_dpp %" #d ", %" #s ", %" #s " " ctrl " row_mask:0xf bank_mask:" m1 "\n\t"
+__device__ __forceinline__ float wave_reduce12d(float (&x)[12]) {
+    // stage 1 (in place, span 16 -> 8 inside every row): lanes 0-7 of x[2k] <- x[2k], lanes 8-15 <- x[2k+1];
+    // stage 2 (span 8 -> 4): banks {0, 2} of x[4m] <- x[4m] (values 4m, 4m+1), banks {1, 3} <- x[4m+2] (values 4m+2, 4m+3).
+    // A DPP read needs its source written >= 2 instructions earlier: the order below guarantees it after the leading nop.
+    asm volatile("s_nop 1\n\t"
+                 DGR_MERGE(0, 1, "row_mirror", "0x3", "0xc") DGR_MERGE(2, 3, "row_mirror", "0x3", "0xc")
+                 DGR_MERGE(4, 5, "row_mirror", "0x3", "0xc") DGR_MERGE(6, 7, "row_mirror", "0x3", "0xc")
+                 DGR_MERGE(8, 9, "row_mirror", "0x3", "0xc") DGR_MERGE(10, 11, "row_mirror", "0x3", "0xc")
+                 DGR_MERGE(0, 2, "row_half_mirror", "0x5", "0xa") DGR_MERGE(4, 6, "row_half_mirror", "0x5", "0xa")
+                 DGR_MERGE(8, 10, "row_half_mirror", "0x5", "0xa")
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                   "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]));
+    // stage 3 (rows 0+1, 2+3): the swap exchanges the odd rows of its first operand with the even rows of its second
+    float z0 = x[0], z1 = x[4], z2 = x[8], z3 = x[8];
+    asm volatile("s_nop 1\n\t" DGR_SWAP16(0, 1) DGR_SWAP16(2, 3) : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
+    float u0 = z0 + z1;  // rows 0, 2: values 0..3 ; rows 1, 3: values 4..7
+    float u1 = z2 + z3;  // every row: values 8..11 (rows 0, 1: rows 0+1 ; rows 2, 3: rows 2+3)
+    // stage 4 (halves): afterwards u0 + u1 holds values 0..3 in row 0, 4..7 in row 1, 8..11 in rows 2 and 3
+    asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) : "+v"(u0), "+v"(u1));
+    float f = u0 + u1;
+    f += dpp_mov<DPP_QUAD_XOR1>(f);
+    f += dpp_mov<DPP_QUAD_XOR2>(f);
+    return f;
+}
+
 // x[0..3] per lane -> total of value {0,2,1,3}[lane >> 4] in every lane of that 16-lane row (10 instructions).
 __device__ __forceinline__ int wave_reduce4_comp(int lane) {
     const int r = lane >> 4;

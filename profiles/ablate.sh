@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/../diff-gaussian-rasterization_amd"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -fno-slp-vectorize"
 if [ "$1" = build ]; then
-  for a in 1 2; do
+  for a in 1 2 3; do
     hipcc $FLAGS -DDGR_ABLATE=$a -c csrc/render_light.hip -o build/render_light_ablate$a.o
     hipcc $FLAGS -DDGR_ABLATE=$a -c csrc/render_light_rows.hip -o build/render_light_rows_ablate$a.o
     hipcc --offload-arch=gfx950 -shared -o lib/libdgr_hip_ablate$a.so build/api.o build/preprocess.o build/binning.o build/render_light_ablate$a.o build/render_light_rows_ablate$a.o build/render_full.o build/optim.o build/slam.o
@@ -14,6 +14,6 @@ if [ "$1" = build ]; then
 fi
 cd ..
 P='import sys,json; d=json.loads(sys.stdin.read()); print({k: round(v*1e3,1) for k,v in d["config"]["stage_ms"].items() if k.startswith("render")})'
-for a in "" _ablate1 _ablate2; do
+for a in "" _ablate1 _ablate2 _ablate3; do
   echo "lib$a:"; DGR_HIP_LIB=$PWD/diff-gaussian-rasterization_amd/lib/libdgr_hip$a.so python bench.py --no-cpu-baseline --steps 20 --views-in-flight 1 2>/dev/null | tail -1 | python -c "$P"
 done
