@@ -187,7 +187,9 @@ int zero_outputs(const FwdCommon& c, hipStream_t st) {
 // counters; scan_blocks and count_rank disappear.
 // Presized path, counting mode: COUNT_LDS = per-workgroup LDS histograms after preprocess (binning.hip; frames whose tile
 // histogram fits LDS), COUNT_FUSED = returning global atomics inside preprocess_fwd.
-enum { COUNT_CALLBACK = 0, COUNT_FUSED = 1, COUNT_LDS = 2 };
+// Callback path (the binning buffer is sized after a host read of num_rendered): COUNT_LDS_CALLBACK = the same LDS count
+// behind scan_blocks, COUNT_CALLBACK = the count_rank kernel on global tile counters (R = 0, or a frame too large for LDS).
+enum { COUNT_CALLBACK = 0, COUNT_FUSED = 1, COUNT_LDS = 2, COUNT_LDS_CALLBACK = 3 };
 int presized_count_mode(int W, int H) {
     return (g_lds_count.load() && dgr::count_lds_fits(dgr::tiles_x(W) * dgr::tiles_y(H))) ? COUNT_LDS : COUNT_FUSED;
 }
@@ -237,11 +239,12 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
 int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, int capacity,
                    hipStream_t st, int mode = COUNT_CALLBACK, char* binning_base = nullptr) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
-    if (mode == COUNT_LDS) {
+    if (mode == COUNT_LDS || mode == COUNT_LDS_CALLBACK) {
+        const bool cb = mode == COUNT_LDS_CALLBACK;
         const dgr::CountTable ct = dgr::carve_count_table(binning_base + bin.bytes, c.W, c.H);
-        { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_lds(c.P, geom, bin, ct, gx, tiles, capacity, st)); }
-        { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_table(c.P, geom, img, ct, tiles, capacity, st)); }
-        { const int rc = early_status_post(img.status, st); if (rc) return rc; }
+        { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_lds(c.P, geom, bin, ct, gx, tiles, capacity, cb, st)); }
+        { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_table(c.P, geom, img, ct, tiles, capacity, cb, st)); }
+        if (!cb) { const int rc = early_status_post(img.status, st); if (rc) return rc; }
         { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st, ct.table, tiles, dgr::count_lds_workgroups(c.P))); }
         { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
         return DGR_OK;
@@ -427,7 +430,9 @@ int dgr_light_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bi
         binningBuffer(0, alloc_user);
     }
     dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
-    if ((rc = binning_stages(c, geom, img, bin, R, st))) return rc;  // also with R == 0: it writes the (empty) range table
+    // (also with R == 0: it writes the (empty) range table)
+    const int mode = (R > 0 && presized_count_mode(width, height) == COUNT_LDS) ? COUNT_LDS_CALLBACK : COUNT_CALLBACK;
+    if ((rc = binning_stages(c, geom, img, bin, R, st, mode, bptr))) return rc;
     if ((rc = forward_back(c, geom, img, bin, st))) return rc;
     if (debug) HIP_TRY(hipStreamSynchronize(st));  // CHECK_CUDA(..., debug): L/cuda_rasterizer/auxiliary.h:166-173
     return R;
@@ -556,7 +561,9 @@ int dgr_full_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bin
         binningBuffer(0, alloc_user);
     }
     dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
-    if ((rc = binning_stages(c, geom, img, bin, R, st))) return rc;  // also with R == 0: it writes the (empty) range table
+    // (also with R == 0: it writes the (empty) range table)
+    const int mode = (R > 0 && presized_count_mode(width, height) == COUNT_LDS) ? COUNT_LDS_CALLBACK : COUNT_CALLBACK;
+    if ((rc = binning_stages(c, geom, img, bin, R, st, mode, bptr))) return rc;
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
     if (num_related_primitives) {  // second blocking read of the reference (:498)
         HIP_TRY(hipMemcpyAsync(status, img.status, sizeof(status), hipMemcpyDeviceToHost, st));

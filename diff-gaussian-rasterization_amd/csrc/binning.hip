@@ -217,7 +217,8 @@ constexpr int SEG_TILES = 64;
 
 __global__ void __launch_bounds__(CL_THREADS) count_lds_kernel(int P, GeometryView geom, uint32_t* __restrict__ ranks,
                                                                uint32_t* __restrict__ table, uint32_t* __restrict__ seg,
-                                                               int grid_x, int tiles, int nseg, int capacity) {
+                                                               int grid_x, int tiles, int nseg, int capacity, int prefixed) {
+    // `prefixed`: geom.block_tiles holds the exclusive prefix of the 256-block totals already (callback path: scan_blocks ran)
     extern __shared__ uint32_t hist[];  // [tiles]
     __shared__ uint32_t wsum[CL_THREADS / 64], psum[CL_THREADS / 64];
     __shared__ uint32_t segsum[(DGR_COUNT_LDS_MAX_TILES + SEG_TILES - 1) / SEG_TILES];
@@ -231,7 +232,8 @@ __global__ void __launch_bounds__(CL_THREADS) count_lds_kernel(int P, GeometryVi
         // instances of the chunks between the previous one of this workgroup and this one
         const int first = 4 * chunk;
         uint32_t part = 0;
-        for (int b = next_block + tid; b < first; b += CL_THREADS) part += geom.block_tiles[b] & 0x7fffffffu;
+        if (!prefixed)
+            for (int b = next_block + tid; b < first; b += CL_THREADS) part += geom.block_tiles[b] & 0x7fffffffu;
         const int idx = chunk * CL_THREADS + tid;
         ushort4 r = make_ushort4(0, 0, 0, 0);
         if (idx < P) r = geom.rect[idx];
@@ -257,6 +259,7 @@ __global__ void __launch_bounds__(CL_THREADS) count_lds_kernel(int P, GeometryVi
             skipped += psum[ww];
         }
         __syncthreads();  // (wsum / psum are rewritten by the next chunk)
+        if (prefixed) run = geom.block_tiles[first];
         const uint32_t off0 = run + skipped + before + incl - n;
         run += skipped + chunk_total;
         next_block = min(first + 4, nblocks);
@@ -305,7 +308,7 @@ constexpr int ST_ROWS_MAX = 16;
 __global__ void __launch_bounds__(CL_THREADS) scan_table_kernel(ImageView img, uint32_t* __restrict__ table,
                                                                 const uint32_t* __restrict__ seg,
                                                                 const uint32_t* __restrict__ block_tiles, int nblocks,
-                                                                int tiles, int nwg, int capacity) {
+                                                                int tiles, int nwg, int capacity, int prefixed) {
     __shared__ uint32_t grp[CL_THREADS / 64][SEG_TILES];
     __shared__ uint32_t red[3][CL_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -330,7 +333,7 @@ __global__ void __launch_bounds__(CL_THREADS) scan_table_kernel(ImageView img, u
         if (sgm > 0) before_seg += seg[(size_t)(sgm - 1) * nwg + i];
         total += seg[(size_t)(nseg - 1) * nwg + i];
     }
-    if (sgm == 0)
+    if (sgm == 0 && !prefixed)  // (callback path: scan_blocks has moved the flag into status[2] already)
         for (int i = tid; i < nblocks; i += CL_THREADS) flag |= block_tiles[i] >> 31;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -369,8 +372,10 @@ __global__ void __launch_bounds__(CL_THREADS) scan_table_kernel(ImageView img, u
     if (sgm == 0 && tid == 0) {
         img.status[0] = (int)total;
         img.status[1] = overflow ? 1 : 0;
-        img.status[2] = (int)flag;  // prefiltered violation
-        img.status[3] = 0;          // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
+        if (!prefixed) {
+            img.status[2] = (int)flag;  // prefiltered violation
+            img.status[3] = 0;          // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
+        }
         img.cursor[2] = (uint32_t)capacity;
     }
 }
@@ -509,7 +514,7 @@ hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, Binnin
 int count_lds_workgroups(int P) { return max(1, min(DGR_COUNT_WGS, (P + CL_THREADS - 1) / CL_THREADS)); }
 bool count_lds_fits(int tiles) { return tiles > 0 && tiles <= DGR_COUNT_LDS_MAX_TILES; }
 hipError_t launch_count_lds(int P, GeometryView geom, BinningView bin, CountTable ct, int grid_x, int tiles, int capacity,
-                            hipStream_t stream) {
+                            bool prefixed, hipStream_t stream) {
     static std::once_flag once;
     static hipError_t attr_rc = hipSuccess;
     std::call_once(once, [] {
@@ -519,13 +524,14 @@ hipError_t launch_count_lds(int P, GeometryView geom, BinningView bin, CountTabl
     if (attr_rc != hipSuccess) return attr_rc;
     const int nwg = count_lds_workgroups(P), nseg = (tiles + SEG_TILES - 1) / SEG_TILES;
     launch_shmem(count_lds_kernel, dim3(nwg), dim3(CL_THREADS), (size_t)tiles * 4, stream, P, geom, bin.ranks, ct.table, ct.seg,
-                 grid_x, tiles, nseg, capacity);
+                 grid_x, tiles, nseg, capacity, prefixed ? 1 : 0);
     return hipGetLastError();
 }
-hipError_t launch_scan_table(int P, GeometryView geom, ImageView img, CountTable ct, int tiles, int capacity, hipStream_t stream) {
+hipError_t launch_scan_table(int P, GeometryView geom, ImageView img, CountTable ct, int tiles, int capacity, bool prefixed,
+                             hipStream_t stream) {
     const int nwg = count_lds_workgroups(P), nseg = (tiles + SEG_TILES - 1) / SEG_TILES;
     launch(scan_table_kernel, dim3(nseg), dim3(CL_THREADS), stream, img, ct.table, ct.seg, geom.block_tiles, (P + 255) / 256,
-           tiles, nwg, capacity);
+           tiles, nwg, capacity, prefixed ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream) {

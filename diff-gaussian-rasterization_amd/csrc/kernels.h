@@ -218,9 +218,12 @@ hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, Binnin
 // counting in LDS (binning.hip): presized path, frames of at most DGR_COUNT_LDS_MAX_TILES tiles
 bool count_lds_fits(int tiles);
 int count_lds_workgroups(int P);
+// `prefixed`: geom.block_tiles is already the exclusive prefix of the block totals and the status word is initialised
+// (callback path, after scan_blocks)
 hipError_t launch_count_lds(int P, GeometryView geom, BinningView bin, CountTable ct, int grid_x, int tiles, int capacity,
-                            hipStream_t stream);
-hipError_t launch_scan_table(int P, GeometryView geom, ImageView img, CountTable ct, int tiles, int capacity, hipStream_t stream);
+                            bool prefixed, hipStream_t stream);
+hipError_t launch_scan_table(int P, GeometryView geom, ImageView img, CountTable ct, int tiles, int capacity, bool prefixed,
+                             hipStream_t stream);
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);
 
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream);

@@ -703,3 +703,36 @@ def test_callback_entry_points_match_the_presized_path(monkeypatch, oracle, bind
     gr = hh.oracle_backward(oracle, st, s, 3, ref["opacity_map"])
     for i, k in ((3, "dL_dmeans3D"), (5, "dL_dsh"), (6, "dL_dscales"), (7, "dL_drotations")):
         assert_grad_close(g[i].cpu().numpy(), gr[k], k, rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=2e-3, outlier_rows=2)
+
+
+@pytest.mark.parametrize("variant", ["light", "full"])
+@pytest.mark.parametrize("P,W,H,sm", [(20000, 320, 240, 1.0), (3000, 97, 61, 4.0), (70000, 640, 480, 1.0), (1500, 16, 16, 6.0)])
+def test_lds_count_and_global_atomic_count_agree(variant, P, W, H, sm):
+    """Round 3: the forward counts tile instances in per-workgroup LDS histograms (count_lds / scan_table,
+    csrc/binning.hip); dgr_set_option("lds_count", 0) selects round 2's returning global atomics (inside preprocess_fwd on
+    the presized path), which also serve frames whose histogram does not fit LDS.  Both place every instance in its
+    tile's segment and the per-tile sort orders it, so num_rendered, ranges, point_list, keys and every output must be
+    identical bit for bit.  Shapes: 69 counting chunks (workgroups with one chunk and, at 70 000, none with two), a ragged
+    frame with large splats (one Gaussian covering many tiles), a single tile."""
+    from dgr_amd import _capi
+    s = make_scene(P, W, H, 5)
+    res = {}
+    for mode in (1, 0):
+        _capi.set_option("lds_count", mode)
+        try:
+            assert _capi.get_option("lds_count") == mode
+            out, d = hh.hip_forward(s, 3, scale_modifier=sm) if variant == "light" else hh.hip_full_forward(s, 3)
+            res[mode] = (d, {k: hh.hip_state(k, s, d) for k in ("point_list", "ranges", "keys")})
+        finally:
+            _capi.set_option("lds_count", 1)
+    (d1, st1), (d0, st0) = res[1], res[0]
+    assert d1["num_rendered"] == d0["num_rendered"] and d1["num_rendered"] > 0
+    for k in st1:
+        assert np.array_equal(st1[k], st0[k]), k
+    for k in d1:
+        if not isinstance(d1[k], np.ndarray):
+            continue
+        if k == "gau_uncertainty":  # a sum of float atomics: its order varies from run to run of the SAME path
+            assert_grad_close(d1[k], d0[k], k, rel_to_max=1e-6)
+        else:
+            assert np.array_equal(d1[k], d0[k]), k
