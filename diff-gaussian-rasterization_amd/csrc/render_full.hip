@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
 
     if (tid == 0) {
         sb.max_last = 0;
-        write_sentinel(s);
+        write_sentinel<true>(s);
     }
     __syncthreads();
     {
@@ -180,8 +180,8 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
     const float dunc2 = 2.f * dL_dunc;
     // Linear recurrences instead of the reference's five accum_rec_* (see render_light.hip): the full variant needs
     // the colour part and the depth part of dL/dalpha separately (pose terms), hence three scalars:
-    //   Xc = <rgb_j, dL/dpixel>, Xd = depth_j, Xu = (depth_j - gt)^2 ; S* <- alpha_last X*_last + (1 - alpha_last) S*
-    float Sc = 0.f, Sd = 0.f, Su = 0.f, Xc_last = 0.f, Xd_last = 0.f, Xu_last = 0.f, last_alpha = 0.f, last_om = 1.f;
+    //   Xc = <rgb_j, dL/dpixel>, Xd = depth_j, Xu = (depth_j - gt)^2 ; S* <- alpha X* + (1 - alpha) S* after the pair used S*
+    float Sc = 0.f, Sd = 0.f, Su = 0.f;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     const int c16 = wave_reduce16_comp(lane);
     const int my_comp = ((lane & 3) == 0 && c16 < NACC_FULL) ? c16 : -1;
@@ -211,35 +211,35 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
                 const float oG = alpha_raw(q1[u].y, p2);  // o G: alpha before the 0.99 clamp
                 const float alpha = fminf(0.99f, oG);
                 const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
-
-                // per-lane scalars (0 on lanes the Gaussian does not reach): w = alpha T, qq = o G dL/dalpha,
-                // qc = o G * (colour-only part of dL/dalpha), and the front-most-pair depth terms
-                float w = 0.f, qq = 0.f, qc = 0.f, e = 0.f, fw = 0.f, fq = 0.f;
-                const float4 cd = s.rgbd[j];
-                if (valid) {
-                    const float om_now = 1.f - alpha;
-                    const float inv = recip(om_now);
-                    T = T * inv;
-                    w = alpha * T;  // dchannel_dcolor
-                    e = cd.w - gt_px;
-                    const float Xc = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2, Xd = cd.w, Xu = e * e;
-                    const float om = last_om;
-                    Sc = last_alpha * Xc_last + om * Sc; Xc_last = Xc;
-                    Sd = last_alpha * Xd_last + om * Sd; Xd_last = Xd;
-                    Su = last_alpha * Xu_last + om * Su; Xu_last = Xu;
-                    last_om = om_now;
-                    const float dcol = Xc - Sc;
-                    float dL_dalpha = dcol + (Xd - Sd) * dL_depth + (Xu - Su) * dL_dunc;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += bg_term * inv;
-                    qq = oG * dL_dalpha;
-                    qc = oG * (T * dcol);  // sum_ch dL_dpixel[ch] * dpixel_dalpha[ch] = T * dcol (backward.cu:693)
-                    if (j == rel_first) {  // the pair ComputePG matches last: its dd_dvK survive (backward.cu:1278-1289)
-                        fw = dL_depth * w;
-                        fq = oG * (dL_depth * (T * (Xd - Sd)));  // dL_depth * ddepth_dalpha * o * G
-                    }
-                }
+                // No branch (see render_light.hip): a lane the Gaussian does not reach runs the same instructions with
+                // alpha = 0 and o G = 0 -- 1 / (1 - 0) is exactly 1 and S = 0 X + 1 S keeps its bits, so its state is
+                // untouched and all of its contributions are 0; valid lanes execute the reference's operations unchanged.
+                // Per-lane scalars: w = alpha T, qq = o G dL/dalpha, qc = o G * (colour-only part of dL/dalpha), and the
+                // front-most-pair depth terms fw, fq.
+                const float am = valid ? alpha : 0.f;
+                const float oGm = valid ? oG : 0.f;
+                const float4 cd = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rgbd) + __float_as_int(q1[u].w));
+                const float om = 1.f - am;
+                const float inv = recip(om);
+                T = T * inv;
+                const float w = am * T;  // dchannel_dcolor
+                const float e = cd.w - gt_px;
+                const float Xc = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2, Xd = cd.w, Xu = e * e;
+                const float dcol = Xc - Sc;
+                const float ddep = Xd - Sd;
+                float dL_dalpha = dcol + ddep * dL_depth + (Xu - Su) * dL_dunc;
+                dL_dalpha *= T;
+                dL_dalpha += bg_term * inv;
+                // what the NEXT valid pair (towards the front) subtracts: S <- alpha X + (1 - alpha) S
+                Sc = am * Xc + om * Sc;
+                Sd = am * Xd + om * Sd;
+                Su = am * Xu + om * Su;
+                const float qq = oGm * dL_dalpha;
+                const float qc = oGm * (T * dcol);  // sum_ch dL_dpixel[ch] * dpixel_dalpha[ch] = T * dcol (backward.cu:693)
+                // the pair ComputePG matches last: its dd_dvK survive (backward.cu:1278-1289)
+                const bool front = valid & (j == rel_first);
+                const float fw = front ? dL_depth * w : 0.f;
+                const float fq = front ? oG * (dL_depth * (T * ddep)) : 0.f;  // dL_depth * ddepth_dalpha * o * G
                 const float dx = dxy.x, dy = dxy.y;
                 const float qdx = qq * dx, qdy = qq * dy;
                 float g[16];
