@@ -118,9 +118,17 @@ std::atomic<int> g_tight_cull{0};
 // slower on the forward that has to produce the 16-bit tags: off by default, kept for A/B runs.
 // Set it before the forward whose backward should use it.
 std::atomic<int> g_bwd_rows{0};
-// dgr_set_option("lds_count", 0): presized forward counts tile instances with returning global atomics inside
-// preprocess_fwd (round 2's fused count) instead of in per-workgroup LDS histograms (binning.hip: count_lds); for A/B runs
-std::atomic<int> g_lds_count{1};
+// dgr_set_option("lds_count", v): how the forward counts tile instances (csrc/binning.hip).
+//   1 (default) = in per-workgroup LDS histograms when the frame's histogram fits LDS and the binning buffer holds at most
+//       DGR_LDS_COUNT_AUTO_MAX instances; larger jobs count with returning global atomics on per-tile counters (round 2's
+//       path: inside preprocess_fwd when presized).  The split is a measured one: the LDS count is faster on an otherwise
+//       idle GPU at every size (one view at a time: 0.545 -> 0.51 ms at config 3, 1.74 -> 1.69 ms at config 4), but the
+//       global atomics WAIT on the memory-side atomic unit with the CUs idle, and under several views in flight another
+//       view's kernels fill that wait -- three views in flight: equal at config 3 (R = 1.65 M), LDS 6 % slower at config 4
+//       (R = 6.6 M), 4 % at config 5 (profiles/count_ab.sh);
+//   2 = LDS whenever the histogram fits;  0 = never (global atomics).  Initial value from DGR_LDS_COUNT (for A/B runs).
+constexpr int DGR_LDS_COUNT_AUTO_MAX = 4 << 20;
+std::atomic<int> g_lds_count{[] { const char* e = getenv("DGR_LDS_COUNT"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }()};
 
 // A kernel stage hands its two events to the stage's first kernel launch (dgr::launch, kernels.h): they then hold
 // that kernel's start and end.  A stage without a kernel (the scratch memset) is bracketed with hipEventRecord.
@@ -190,8 +198,10 @@ int zero_outputs(const FwdCommon& c, hipStream_t st) {
 // Callback path (the binning buffer is sized after a host read of num_rendered): COUNT_LDS_CALLBACK = the same LDS count
 // behind scan_blocks, COUNT_CALLBACK = the count_rank kernel on global tile counters (R = 0, or a frame too large for LDS).
 enum { COUNT_CALLBACK = 0, COUNT_FUSED = 1, COUNT_LDS = 2, COUNT_LDS_CALLBACK = 3 };
-int presized_count_mode(int W, int H) {
-    return (g_lds_count.load() && dgr::count_lds_fits(dgr::tiles_x(W) * dgr::tiles_y(H))) ? COUNT_LDS : COUNT_FUSED;
+int presized_count_mode(int W, int H, int capacity) {
+    const int v = g_lds_count.load();
+    const bool lds = v != 0 && dgr::count_lds_fits(dgr::tiles_x(W) * dgr::tiles_y(H)) && (v == 2 || capacity <= DGR_LDS_COUNT_AUTO_MAX);
+    return lds ? COUNT_LDS : COUNT_FUSED;
 }
 int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, hipStream_t st,
                   const dgr::BinningView* bin = nullptr, int capacity = 0, char* image_base = nullptr,
@@ -387,7 +397,7 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
-    const int mode = presized_count_mode(width, height);
+    const int mode = presized_count_mode(width, height, binning_capacity);
     if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer, mode))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer))) return rc;
     if ((rc = forward_back(c, geom, img, bin, st))) return rc;
@@ -431,7 +441,7 @@ int dgr_light_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bi
     }
     dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
     // (also with R == 0: it writes the (empty) range table)
-    const int mode = (R > 0 && presized_count_mode(width, height) == COUNT_LDS) ? COUNT_LDS_CALLBACK : COUNT_CALLBACK;
+    const int mode = (R > 0 && presized_count_mode(width, height, R) == COUNT_LDS) ? COUNT_LDS_CALLBACK : COUNT_CALLBACK;
     if ((rc = binning_stages(c, geom, img, bin, R, st, mode, bptr))) return rc;
     if ((rc = forward_back(c, geom, img, bin, st))) return rc;
     if (debug) HIP_TRY(hipStreamSynchronize(st));  // CHECK_CUDA(..., debug): L/cuda_rasterizer/auxiliary.h:166-173
@@ -520,7 +530,7 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     if (status) img.status = status;  // the kernels write the caller's status word directly
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
-    const int mode = presized_count_mode(width, height);
+    const int mode = presized_count_mode(width, height, binning_capacity);
     if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer, mode))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer))) return rc;
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
@@ -562,7 +572,7 @@ int dgr_full_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bin
     }
     dgr::BinningView bin = dgr::carve_binning(bptr, (size_t)R);
     // (also with R == 0: it writes the (empty) range table)
-    const int mode = (R > 0 && presized_count_mode(width, height) == COUNT_LDS) ? COUNT_LDS_CALLBACK : COUNT_CALLBACK;
+    const int mode = (R > 0 && presized_count_mode(width, height, R) == COUNT_LDS) ? COUNT_LDS_CALLBACK : COUNT_CALLBACK;
     if ((rc = binning_stages(c, geom, img, bin, R, st, mode, bptr))) return rc;
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
     if (num_related_primitives) {  // second blocking read of the reference (:498)
@@ -800,7 +810,7 @@ int dgr_set_option(const char* name, int value) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }
     if (n == "bwd_rows") { g_bwd_rows.store(value ? 1 : 0); return DGR_OK; }
-    if (n == "lds_count") { g_lds_count.store(value ? 1 : 0); return DGR_OK; }
+    if (n == "lds_count") { g_lds_count.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
     if (n == "profile_every") { g_profile_every.store(value > 0 ? value : 1); return DGR_OK; }
     g_last_error = "unknown option: " + n;
     return DGR_ERR_BAD_ARGUMENT;

@@ -228,10 +228,13 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle
  *     is cut down to the box where alpha can reach 15/255.  Images and gradients are unchanged, but num_rendered, the
  *     tile lists and n_contrib are NOT the reference's any more -- hence opt-in.
- *  "lds_count" (default 1): the forward counts a frame's tile instances in per-workgroup LDS histograms (no global atomics,
- *     no cleared counters) whenever the histogram of the frame fits LDS (up to 40 000 tiles, i.e. beyond 3840x2160);
- *     0 = always count with returning global atomics on per-tile counters (round 2's path; kept for larger frames and A/B
- *     runs).  Results are identical bit for bit.  dgr_binning_bytes() includes the count's forward-only workspace.
+ *  "lds_count" (default 1): how the forward counts a frame's tile instances.  1 = in per-workgroup LDS histograms (no
+ *     global atomics, no cleared counters) when the frame's histogram fits LDS (up to 40 000 tiles, i.e. beyond 3840x2160)
+ *     and the binning buffer holds at most 4 Mi instances, else with returning global atomics on per-tile counters (round
+ *     2's path) -- the LDS count is faster on an otherwise idle GPU at every size, the atomics' wait is filled by other
+ *     views' kernels when several views are in flight, and the measured break-even lies between 1.65 M and 6.6 M instances;
+ *     2 = LDS whenever the histogram fits; 0 = never.  Results are identical bit for bit.  dgr_binning_bytes() includes the
+ *     LDS count's forward-only workspace.
  *  "profile_every": n >= 1 = dgr_profile_* brackets every n-th launch of the selected stage only (default 1). */
 int dgr_set_option(const char* name, int value);
 int dgr_get_option(const char* name);

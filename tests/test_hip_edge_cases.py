@@ -717,7 +717,7 @@ def test_lds_count_and_global_atomic_count_agree(variant, P, W, H, sm):
     from dgr_amd import _capi
     s = make_scene(P, W, H, 5)
     res = {}
-    for mode in (1, 0):
+    for mode in (2, 0):  # 2 = LDS whenever the histogram fits LDS (1, the default, also looks at the size of the job)
         _capi.set_option("lds_count", mode)
         try:
             assert _capi.get_option("lds_count") == mode
@@ -725,7 +725,7 @@ def test_lds_count_and_global_atomic_count_agree(variant, P, W, H, sm):
             res[mode] = (d, {k: hh.hip_state(k, s, d) for k in ("point_list", "ranges", "keys")})
         finally:
             _capi.set_option("lds_count", 1)
-    (d1, st1), (d0, st0) = res[1], res[0]
+    (d1, st1), (d0, st0) = res[2], res[0]
     assert d1["num_rendered"] == d0["num_rendered"] and d1["num_rendered"] > 0
     for k in st1:
         assert np.array_equal(st1[k], st0[k]), k
