@@ -652,7 +652,11 @@ int dgr_cov3d_backward(void* stream, int P, const float* scales, const float* ro
 }
 
 int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4) {
-    HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out4, comp16, comp4, (hipStream_t)stream));
+    HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out4, comp16, comp4, false, (hipStream_t)stream));
+    return DGR_OK;
+}
+int dgr_debug_wave_reduce_d(void* stream, const float* in, float* out16, float* out12, int* comp16, int* comp12) {
+    HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out12, comp16, comp12, true, (hipStream_t)stream));
     return DGR_OK;
 }
 int dgr_debug_row_reduce(void* stream, const float* in, float* out, int* comp) {

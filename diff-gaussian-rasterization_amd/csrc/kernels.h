@@ -233,6 +233,7 @@ hipError_t launch_render_bwd_light_rows(const RenderBwdLightArgs& a, hipStream_t
 hipError_t launch_row_reduce_test(const float* in, float* out, int* comp, hipStream_t stream);
 hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, hipStream_t stream);
 hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, hipStream_t stream);
-hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, hipStream_t stream);
+hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, bool with_d,
+                                   hipStream_t stream);
 
 }  // namespace dgr

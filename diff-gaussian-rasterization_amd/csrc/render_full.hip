@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
     //   Xc = <rgb_j, dL/dpixel>, Xd = depth_j, Xu = (depth_j - gt)^2 ; S* <- alpha X* + (1 - alpha) S* after the pair used S*
     float Sc = 0.f, Sd = 0.f, Su = 0.f;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
-    const int c16 = wave_reduce16_comp(lane);
+    const int c16 = wave_reduce16d_comp(lane);
     const int my_comp = ((lane & 3) == 0 && c16 < NACC_FULL) ? c16 : -1;
 
     for (int hi = total; hi > 0; hi -= BWD_NB) {
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullAr
                 g[13] = fq * dx;  // front-most depth sums
                 g[14] = fq * dy;
                 g[15] = 0.f;
-                const float tot = wave_reduce16(g);
+                const float tot = wave_reduce16d(g);  // (within-row stages first: wave_reduce.h)
                 if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * BWD_LD + j], tot);
             }
         }

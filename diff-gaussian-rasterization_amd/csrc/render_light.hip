@@ -28,7 +28,7 @@
 #include "render_common.h"
 
 #ifndef DGR_REDUCE_DPP
-#define DGR_REDUCE_DPP 0  // 1: the twelve-value reduction with its within-row stages first (wave_reduce12d)
+#define DGR_REDUCE_DPP 1  // the twelve-value reduction with its within-row stages first (wave_reduce12d: render_bwd 212 -> 205 us); 0 = swap-first
 #endif
 #ifndef DGR_ABLATE
 #define DGR_ABLATE 0  // 1 / 2: measurement builds (profiles/ablate.sh), never shipped
@@ -393,17 +393,21 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     }
 }
 
-// self-test of the butterflies: in[c * 64 + lane] -> out16[lane], out4[lane] (see dgr_debug_wave_reduce)
+// self-test of the butterflies: in[c * 64 + lane] -> out16[lane], out4[lane] (see dgr_debug_wave_reduce); the networks with
+// the within-row stages first go to out16[64 + lane] (16 values) and out4[64 + lane] (12 values), their value maps to
+// comp16[64 + lane], comp4[64 + lane]
 __global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, float* out16, float* out4, int* comp16,
-                                                             int* comp4) {
+                                                             int* comp4, int with_d) {
     const int lane = threadIdx.x;
     float g[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) g[k] = in[k * 64 + lane];
     float g4[4] = {g[0], g[1], g[2], g[3]};
-    float g12[12];
+    float g12[12], g12d[12], g16d[16];
 #pragma unroll
-    for (int k = 0; k < 12; k++) g12[k] = g[k];
+    for (int k = 0; k < 12; k++) g12[k] = g12d[k] = g[k];
+#pragma unroll
+    for (int k = 0; k < 16; k++) g16d[k] = g[k];
     const float r12 = wave_reduce12(g12);
     const float r16 = wave_reduce16(g);
     // out16: lanes whose component is < 12 must agree between the 12- and 16-value networks; report a mismatch as NaN
@@ -411,6 +415,12 @@ __global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, f
     out4[lane] = wave_reduce4(g4);
     comp16[lane] = wave_reduce16_comp(lane);
     comp4[lane] = wave_reduce4_comp(lane);
+    if (with_d) {
+        out16[64 + lane] = wave_reduce16d(g16d);
+        out4[64 + lane] = wave_reduce12d(g12d);
+        comp16[64 + lane] = wave_reduce16d_comp(lane);
+        comp4[64 + lane] = wave_reduce12d_comp(lane);
+    }
 }
 
 }  // namespace
@@ -433,8 +443,9 @@ hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stre
         launch((render_bwd_light_kernel<false, true>), dim3(tiles), dim3(256), stream, a);
     return hipGetLastError();
 }
-hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, hipStream_t stream) {
-    launch(wave_reduce_test_kernel, dim3(1), dim3(64), stream, in, out16, out4, comp16, comp4);
+hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, bool with_d,
+                                   hipStream_t stream) {
+    launch(wave_reduce_test_kernel, dim3(1), dim3(64), stream, in, out16, out4, comp16, comp4, with_d ? 1 : 0);
     return hipGetLastError();
 }
 

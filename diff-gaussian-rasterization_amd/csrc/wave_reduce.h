@@ -8,6 +8,10 @@
 //     quad q = lane >> 2 holds value  kWaveReduce16Comp[q]
 // so a single store / atomic with 16 (here 14) active lanes scatters all totals at once.
 //
+// Round 3: the networks the blend kernels use are wave_reduce12d / wave_reduce16d further down -- the same sums with the
+// within-row stages first (measured issue costs: a DPP add 4.2 cycles, a permlane swap 8.1, a plain add 2.5; the swap-first
+// networks here are kept as the reference for the self-test and the 4-value case).
+//
 // The permlane swaps are emitted as inline asm: __builtin_amdgcn_permlane{16,32}_swap returns a pair whose
 // second element this ROCm's compiler aliases to the first.  A VALU write of an operand must be >= 2 wait
 // states ahead of the swap that reads it, hence the leading s_nop 1 of each asm block.
@@ -141,6 +145,33 @@ __device__ __forceinline__ float wave_reduce12d(float (&x)[12]) {
     // stage 4 (halves): afterwards u0 + u1 holds values 0..3 in row 0, 4..7 in row 1, 8..11 in rows 2 and 3
     asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) : "+v"(u0), "+v"(u1));
     float f = u0 + u1;
+    f += dpp_mov<DPP_QUAD_XOR1>(f);
+    f += dpp_mov<DPP_QUAD_XOR2>(f);
+    return f;
+}
+
+// Sixteen values, within-row stages first: 16 -> 8 -> 4 registers with 24 DPP adds, two swaps + one swap across rows.
+//   value held by lane l afterwards:  4 (l >> 4) + {0, 2, 1, 3}[(l >> 2) & 3]
+__device__ __forceinline__ int wave_reduce16d_comp(int lane) {
+    const int b = (lane >> 2) & 3;
+    return 4 * (lane >> 4) + ((b == 1) ? 2 : (b == 2) ? 1 : b);
+}
+__device__ __forceinline__ float wave_reduce16d(float (&x)[16]) {
+    asm volatile("s_nop 1\n\t"
+                 DGR_MERGE(0, 1, "row_mirror", "0x3", "0xc") DGR_MERGE(2, 3, "row_mirror", "0x3", "0xc")
+                 DGR_MERGE(4, 5, "row_mirror", "0x3", "0xc") DGR_MERGE(6, 7, "row_mirror", "0x3", "0xc")
+                 DGR_MERGE(8, 9, "row_mirror", "0x3", "0xc") DGR_MERGE(10, 11, "row_mirror", "0x3", "0xc")
+                 DGR_MERGE(12, 13, "row_mirror", "0x3", "0xc") DGR_MERGE(14, 15, "row_mirror", "0x3", "0xc")
+                 DGR_MERGE(0, 2, "row_half_mirror", "0x5", "0xa") DGR_MERGE(4, 6, "row_half_mirror", "0x5", "0xa")
+                 DGR_MERGE(8, 10, "row_half_mirror", "0x5", "0xa") DGR_MERGE(12, 14, "row_half_mirror", "0x5", "0xa")
+                 : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]),
+                   "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
+    float z0 = x[0], z1 = x[4], z2 = x[8], z3 = x[12];
+    asm volatile("s_nop 1\n\t" DGR_SWAP16(0, 1) DGR_SWAP16(2, 3) : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
+    float u0 = z0 + z1;  // rows 0, 2: values 0..3 ; rows 1, 3: values 4..7
+    float u1 = z2 + z3;  // rows 0, 2: values 8..11 ; rows 1, 3: values 12..15
+    asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) : "+v"(u0), "+v"(u1));
+    float f = u0 + u1;   // row r: values 4 r .. 4 r + 3
     f += dpp_mov<DPP_QUAD_XOR1>(f);
     f += dpp_mov<DPP_QUAD_XOR2>(f);
     return f;

@@ -252,6 +252,11 @@ int dgr_cov3d_backward(void* stream, int P, const float* scales, const float* ro
  * values per lane as in[c * 64 + lane]; out16[lane] / out4[lane] receive what each lane holds after the
  * 16-value / 4-value reduction, comp16[lane] / comp4[lane] the index of the value that lane's total belongs to. */
 int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4);
+/* The same self-test including the networks the blend kernels use since round 3 (within-row DPP stages first, csrc/wave_reduce.h:
+ * wave_reduce16d / wave_reduce12d).  All four arrays hold 128 entries: [0, 64) as dgr_debug_wave_reduce fills them,
+ * out16[64 + lane] / comp16[64 + lane] the 16-value network, out12[64 + lane] / comp12[64 + lane] the 12-value one (which
+ * reads in[0 .. 12 * 64)). */
+int dgr_debug_wave_reduce_d(void* stream, const float* in, float* out16, float* out12, int* comp16, int* comp12);
 /* The same for the 16-lane row reduction of the rows backward (render_light_rows.hip): in[c * 64 + lane], c < 12;
  * out[lane] = what the lane holds afterwards, comp[lane] = the value it belongs to (-1: a duplicate lane). */
 int dgr_debug_row_reduce(void* stream, const float* in, float* out, int* comp);
