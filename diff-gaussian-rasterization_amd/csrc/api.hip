@@ -885,7 +885,11 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
     const std::string n(name);
     if (n == "depths") return copy(g.depths, 4 * (size_t)P) ? -1 : P;
     if (n == "radii") return copy(g.radii, 4 * (size_t)P) ? -1 : P;
-    if (n == "cov3D") return copy(g.cov3D, 24 * (size_t)P) ? -1 : 6L * P;
+    if (n == "cov3D") {  // two planes (float4 {c0..c3}, float2 {c4, c5}) -> the reference's [P, 6]
+        if (hipMemcpy2DAsync(dst, 24, g.cov3D, 16, 16, (size_t)P, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+        if (hipMemcpy2DAsync((char*)dst + 16, 24, g.cov3D + 4 * (size_t)P, 8, 8, (size_t)P, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+        return 6L * P;
+    }
     if (n == "means2D") return geomk(EX_MEANS2D) ? -1 : 2L * P;
     if (n == "conic_opacity") return geomk(EX_CONIC_OPACITY) ? -1 : 4L * P;
     if (n == "rgb") return geomk(EX_RGB) ? -1 : 3L * P;

@@ -34,13 +34,16 @@ struct GeometryView {
     float4* rec;        // [3P]
     float* depths;      // [P]
     int* radii;         // [P] internal copy (the caller's `radii` may be NULL)
-    float* cov3D;       // [6P]
+    float* cov3D;       // [4P] + [2P]: plane {c0, c1, c2, c3} (float4 per Gaussian), then plane {c4, c5} (float2)
     ushort4* rect;      // [P] {xmin, ymin, xmax, ymax} in tiles; all-zero when culled
     uint8_t* clamped;   // [P] bit c set <=> channel c was clamped at 0
     uint32_t* goff;     // [P] index of the Gaussian's first instance in Gaussian-major order (the reference's
                         //     point_offsets, exclusive form); written by count_rank
     uint32_t* block_tiles;  // [ceil(P/256)] instances produced by each 256-Gaussian block of preprocess; turned into its
                             //     exclusive prefix in place by scan_blocks
+    float4* shd;        // [3][P] (three planes) d(colour)/d(view direction x, y, z) of the SH evaluation ({r, g, b, -} each), written by
+                        //     preprocess_fwd for the Gaussians whose colour it evaluates: the backward needs the 45 higher SH
+                        //     coefficients only through these nine numbers, so it reads 48 bytes instead of the 192-byte row
     size_t bytes;
 };
 __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
@@ -54,6 +57,7 @@ __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
     g.clamped = (uint8_t*)(base + o); o = align_up(o + (size_t)P, 256);
     g.goff = (uint32_t*)(base + o);   o = align_up(o + sizeof(uint32_t) * (size_t)P, 256);
     g.block_tiles = (uint32_t*)(base + o); o = align_up(o + sizeof(uint32_t) * (((size_t)P + 255) / 256), 256);
+    g.shd = (float4*)(base + o);      o = align_up(o + sizeof(float4) * 3 * (size_t)P, 256);
     g.bytes = o;
     return g;
 }

@@ -17,6 +17,9 @@
 
 #include "kernels.h"
 #include "count_rank.h"
+#ifndef DGR_ABLATE_SHD
+#define DGR_ABLATE_SHD 0  // 1 / 2: measurement builds (derivatives not stored / not computed)
+#endif
 
 #pragma clang fp contract(off)
 
@@ -243,6 +246,36 @@ __device__ __forceinline__ void lanes_to_sh_rows_scaled(const float (&coef)[16],
     }
 }
 
+// d(colour)/d(unit view direction) of computeColorFromSH, term by term as the reference's backward writes it
+// (L/cuda_rasterizer/backward.cu:50-133)
+__device__ __forceinline__ void sh_direction_derivatives(const SHCoeffs& s, int D, float3 dir, float3& dRGBdx, float3& dRGBdy,
+                                                         float3& dRGBdz) {
+    const float x = dir.x, y = dir.y, z = dir.z;
+    if (D > 0) {
+        dRGBdx = -SH_C1 * s.c[3];
+        dRGBdy = -SH_C1 * s.c[1];
+        dRGBdz = SH_C1 * s.c[2];
+        if (D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            dRGBdx = dRGBdx + (SH_C2[0] * y * s.c[4] + SH_C2[2] * 2.f * -x * s.c[6] + SH_C2[3] * z * s.c[7] + SH_C2[4] * 2.f * x * s.c[8]);
+            dRGBdy = dRGBdy + (SH_C2[0] * x * s.c[4] + SH_C2[1] * z * s.c[5] + SH_C2[2] * 2.f * -y * s.c[6] + SH_C2[4] * 2.f * -y * s.c[8]);
+            dRGBdz = dRGBdz + (SH_C2[1] * y * s.c[5] + SH_C2[2] * 2.f * 2.f * z * s.c[6] + SH_C2[3] * x * s.c[7]);
+            if (D > 2) {
+                dRGBdx = dRGBdx + (SH_C3[0] * s.c[9] * 3.f * 2.f * xy + SH_C3[1] * s.c[10] * yz + SH_C3[2] * s.c[11] * -2.f * xy +
+                                   SH_C3[3] * s.c[12] * -3.f * 2.f * xz + SH_C3[4] * s.c[13] * (-3.f * xx + 4.f * zz - yy) +
+                                   SH_C3[5] * s.c[14] * 2.f * xz + SH_C3[6] * s.c[15] * 3.f * (xx - yy));
+                dRGBdy = dRGBdy + (SH_C3[0] * s.c[9] * 3.f * (xx - yy) + SH_C3[1] * s.c[10] * xz +
+                                   SH_C3[2] * s.c[11] * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s.c[12] * -3.f * 2.f * yz +
+                                   SH_C3[4] * s.c[13] * -2.f * xy + SH_C3[5] * s.c[14] * -2.f * yz +
+                                   SH_C3[6] * s.c[15] * -3.f * 2.f * xy);
+                dRGBdz = dRGBdz + (SH_C3[1] * s.c[10] * xy + SH_C3[2] * s.c[11] * 4.f * 2.f * yz +
+                                   SH_C3[3] * s.c[12] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s.c[13] * 4.f * 2.f * xz +
+                                   SH_C3[5] * s.c[14] * (xx - yy));
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -288,8 +321,10 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
             const M3 Sigma = mul(transpose(Mm), Mm);
             c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
             c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
-#pragma unroll
-            for (int i = 0; i < 6; i++) a.geom.cov3D[6 * (size_t)idx + i] = c3[i];
+            // two planes, {c0..c3} as float4 and {c4, c5} as float2: consecutive lanes store consecutive pieces (six 4-byte
+            // stores at a 24-byte lane stride touch 24 cache lines per wave instruction)
+            reinterpret_cast<float4*>(a.geom.cov3D)[idx] = make_float4(c3[0], c3[1], c3[2], c3[3]);
+            reinterpret_cast<float2*>(a.geom.cov3D + 4 * (size_t)a.P)[idx] = make_float2(c3[4], c3[5]);
         }
         Cov2D c;
         cov2d_common(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.view, c);
@@ -393,6 +428,25 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
                 }
             }
             res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+            {
+                // d(colour)/d(direction) (L/cuda_rasterizer/backward.cu:50-133), kept for the backward: it is all the
+                // backward needs of the SH coefficients beyond the basis values, which depend on the direction alone
+                float3 dRGBdx = make_float3(0, 0, 0), dRGBdy = make_float3(0, 0, 0), dRGBdz = make_float3(0, 0, 0);
+#if DGR_ABLATE_SHD != 2
+                sh_direction_derivatives(s, a.D, dir, dRGBdx, dRGBdy, dRGBdz);
+#endif
+#if DGR_ABLATE_SHD == 1
+                float4* shd = a.geom.shd + (size_t)(a.P < 0 ? idx : 0);
+                if (dRGBdx.x == 12345.f)
+#else
+                float4* shd = a.geom.shd + (size_t)idx;  // three planes of P float4: consecutive lanes store consecutive 16-byte pieces
+#endif
+                {
+                    shd[0] = make_float4(dRGBdx.x, dRGBdx.y, dRGBdx.z, 0.0f);
+                    shd[(size_t)a.P] = make_float4(dRGBdy.x, dRGBdy.y, dRGBdy.z, 0.0f);
+                    shd[2 * (size_t)a.P] = make_float4(dRGBdz.x, dRGBdz.y, dRGBdz.z, 0.0f);
+                }
+            }
             a.geom.clamped[idx] = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
             rgb = make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
             a.geom.rec[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
@@ -466,9 +520,15 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
         const float3 m = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
         float c3[6];
         {
-            const float* c3p = a.cov3D_precomp ? a.cov3D_precomp + 6 * (size_t)idx : a.geom.cov3D + 6 * (size_t)idx;
+            if (a.cov3D_precomp) {
+                const float* c3p = a.cov3D_precomp + 6 * (size_t)idx;
 #pragma unroll
-            for (int i = 0; i < 6; i++) c3[i] = c3p[i];
+                for (int i = 0; i < 6; i++) c3[i] = c3p[i];
+            } else {  // the forward's two planes
+                const float4 ca = reinterpret_cast<const float4*>(a.geom.cov3D)[idx];
+                const float2 cb = reinterpret_cast<const float2*>(a.geom.cov3D + 4 * (size_t)a.P)[idx];
+                c3[0] = ca.x; c3[1] = ca.y; c3[2] = ca.z; c3[3] = ca.w; c3[4] = cb.x; c3[5] = cb.y;
+            }
         }
         float3 sc_in = make_float3(0.f, 0.f, 0.f);
         float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -477,6 +537,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
             q_in = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
         }
         const uint8_t cl_in = a.geom.clamped[idx];
+        const float4 shd0 = a.geom.shd[idx], shd1 = a.geom.shd[(size_t)a.P + idx], shd2 = a.geom.shd[2 * (size_t)a.P + idx];
         float4 r0_in = make_float4(0.f, 0.f, 0.f, 1.f), r1_in = make_float4(0.f, 0.f, 0.f, 0.f);
         if (a.acc_raw) {
             r0_in = a.geom.rec[3 * (size_t)idx];
@@ -629,21 +690,12 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
             // whole block in range, 16 coefficients, 16-byte aligned rows: SH rows move through LDS (block-uniform)
             __shared__ float sht[4 * SHT_ROWS * SHT_LD];
             const bool blk_fast = a.sh_vec_ok && ncoef_out == 16 && a.shs != nullptr && (size_t)blockIdx.x * 256 + 256 <= (size_t)a.P;
-            float shf[48];
-            if (blk_fast) sh_rows_to_lanes(a.shs, (size_t)blockIdx.x * 256, sht, shf);
             // dL_dsh[k] = coef[k] * dRGB (backward.cu:46-133): the scalars, not the 48 products, stay in registers
             float coef[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) coef[k] = 0.0f;
             float3 dRGB = make_float3(0.f, 0.f, 0.f);
             if (do_map && a.shs) {
-                SHCoeffs s;
-                if (blk_fast) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) s.c[k] = make_float3(shf[3 * k], shf[3 * k + 1], shf[3 * k + 2]);
-                } else {
-                    load_sh(a.shs, idx, a.D, a.M, a.sh_vec_ok, s);
-                }
                 const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
                 const float3 dir_orig = m - cam;
                 const float len = sqrtf(dot3(dir_orig, dir_orig));
@@ -653,16 +705,17 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
                 dRGB.x *= (cl & 1) ? 0 : 1;
                 dRGB.y *= (cl & 2) ? 0 : 1;
                 dRGB.z *= (cl & 4) ? 0 : 1;
-                float3 dRGBdx = make_float3(0, 0, 0), dRGBdy = make_float3(0, 0, 0), dRGBdz = make_float3(0, 0, 0);
+                // d(colour)/d(direction): the forward evaluated it from the SH row it had in registers (geom.shd, requested
+                // with the other inputs above) -- the basis values below need the direction only, so the 192-byte rows are
+                // not read again
+                const float3 dRGBdx = make_float3(shd0.x, shd0.y, shd0.z), dRGBdy = make_float3(shd1.x, shd1.y, shd1.z),
+                             dRGBdz = make_float3(shd2.x, shd2.y, shd2.z);
                 const float x = dir.x, y = dir.y, z = dir.z;
                 coef[0] = SH_C0;
                 if (a.D > 0) {
                     coef[1] = -SH_C1 * y;
                     coef[2] = SH_C1 * z;
                     coef[3] = -SH_C1 * x;
-                    dRGBdx = -SH_C1 * s.c[3];
-                    dRGBdy = -SH_C1 * s.c[1];
-                    dRGBdz = SH_C1 * s.c[2];
                     if (a.D > 1) {
                         const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                         coef[4] = SH_C2[0] * xy;
@@ -670,9 +723,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
                         coef[6] = SH_C2[2] * (2.f * zz - xx - yy);
                         coef[7] = SH_C2[3] * xz;
                         coef[8] = SH_C2[4] * (xx - yy);
-                        dRGBdx = dRGBdx + (SH_C2[0] * y * s.c[4] + SH_C2[2] * 2.f * -x * s.c[6] + SH_C2[3] * z * s.c[7] + SH_C2[4] * 2.f * x * s.c[8]);
-                        dRGBdy = dRGBdy + (SH_C2[0] * x * s.c[4] + SH_C2[1] * z * s.c[5] + SH_C2[2] * 2.f * -y * s.c[6] + SH_C2[4] * 2.f * -y * s.c[8]);
-                        dRGBdz = dRGBdz + (SH_C2[1] * y * s.c[5] + SH_C2[2] * 2.f * 2.f * z * s.c[6] + SH_C2[3] * x * s.c[7]);
                         if (a.D > 2) {
                             coef[9] = SH_C3[0] * y * (3.f * xx - yy);
                             coef[10] = SH_C3[1] * xy * z;
@@ -681,16 +731,6 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
                             coef[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
                             coef[14] = SH_C3[5] * z * (xx - yy);
                             coef[15] = SH_C3[6] * x * (xx - 3.f * yy);
-                            dRGBdx = dRGBdx + (SH_C3[0] * s.c[9] * 3.f * 2.f * xy + SH_C3[1] * s.c[10] * yz + SH_C3[2] * s.c[11] * -2.f * xy +
-                                               SH_C3[3] * s.c[12] * -3.f * 2.f * xz + SH_C3[4] * s.c[13] * (-3.f * xx + 4.f * zz - yy) +
-                                               SH_C3[5] * s.c[14] * 2.f * xz + SH_C3[6] * s.c[15] * 3.f * (xx - yy));
-                            dRGBdy = dRGBdy + (SH_C3[0] * s.c[9] * 3.f * (xx - yy) + SH_C3[1] * s.c[10] * xz +
-                                               SH_C3[2] * s.c[11] * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * s.c[12] * -3.f * 2.f * yz +
-                                               SH_C3[4] * s.c[13] * -2.f * xy + SH_C3[5] * s.c[14] * -2.f * yz +
-                                               SH_C3[6] * s.c[15] * -3.f * 2.f * xy);
-                            dRGBdz = dRGBdz + (SH_C3[1] * s.c[10] * xy + SH_C3[2] * s.c[11] * 4.f * 2.f * yz +
-                                               SH_C3[3] * s.c[12] * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * s.c[13] * 4.f * 2.f * xz +
-                                               SH_C3[5] * s.c[14] * (xx - yy));
                         }
                     }
                 }
