@@ -11,7 +11,8 @@ import sys
 STAGE = {"count_rank_kernel": "count_rank", "emit_instances_kernel": "emit_instances", "preprocess_bwd_kernel": "preprocess_bwd",
          "preprocess_fwd_kernel": "preprocess_fwd", "render_bwd_light_kernel": "render_bwd", "render_bwd_light_rows_kernel": "render_bwd_rows", "render_fwd_light_kernel": "render_fwd",
          "scan_blocks_kernel": "scan_blocks", "scan_tiles_kernel": "scan_tiles", "sort_tiles_kernel": "sort_tiles",
-         "zero_fill_kernel": "zero_scratch", "pose_reduce_kernel": "pose_reduce"}
+         "zero_fill_kernel": "zero_scratch", "pose_reduce_kernel": "pose_reduce", "count_lds_kernel": "count_lds",
+         "scan_table_kernel": "scan_table"}
 src = sys.argv[1]
 vals = {}
 for line in open(src):
@@ -21,12 +22,13 @@ for line in open(src):
 P, TILES = 500000, 8160
 # zero_fill_kernel runs twice per view since round 2 (the backward's accumulator rows + pose buckets, and the forward's
 # padded tile counters): the per-dispatch average of the counter is compared with the average of the two known sizes
-zero_expected = ((64.0 * P + 256 + 6144) + (256 + 64.0 * TILES)) / 2.0
+# Round 3 (the LDS count: a count_lds_kernel line is present) clears nothing in front of the forward: one launch per view.
+zero_expected = (64.0 * P + 256 + 6144) if "count_lds" in vals else ((64.0 * P + 256 + 6144) + (256 + 64.0 * TILES)) / 2.0
 write_cal = vals["zero_scratch"]["WRITE_SIZE"] / zero_expected
 out = {"_comment": f"HBM bytes per launch at config3 (light), from {src} (one view at a time, separate FETCH_SIZE / WRITE_SIZE "
                    "passes): 2 * FETCH_SIZE + WRITE_SIZE, in bytes.  FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM) "
-                   "prescribes for wide reads on gfx950; WRITE_SIZE needs no correction: zero_fill_kernel writes 64 * P = "
-                   f"{zero_expected / 1e6:.1f} MB per launch on average (two launches of known size) and the counter reads {write_cal:.3f} of that.  'config3_detail' keeps the raw parts.",
+                   "prescribes for wide reads on gfx950; WRITE_SIZE needs no correction: zero_fill_kernel writes "
+                   f"{zero_expected / 1e6:.1f} MB per launch on average (launches of known size) and the counter reads {write_cal:.3f} of that.  'config3_detail' keeps the raw parts.",
        "write_calibration": write_cal, "config3": {}, "config3_detail": {}}
 for k, v in sorted(vals.items()):
     f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
