@@ -338,6 +338,10 @@ def main():
                                    + (" -- TRACKING step: pose gradient only (map_off), not the headline mapping step" if args.tracking else ""), "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
                        "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "hipgraph_replay": bool(args.graph),
+                       "tile_count": ("global atomics while several views are in flight (dgr_amd.multiview.ViewStreams; their wait "
+                                      "is filled by the other views), LDS histograms for ms_per_view_one_stream, stage_ms and the "
+                                      "roofline's isolated figure" if (views is not None and not captured) else
+                                      "library default (LDS histograms up to 4 Mi instances)"),
                        "pair_evals_per_view": pair_evals,
                        "pair_evals_per_s": None if pair_evals is None else pair_evals * views_per_s / world, "tight_cull": bool(args.tight_cull),
                        "view_hbm_frac_one_stream": None if not serial_ms else

@@ -736,3 +736,24 @@ def test_lds_count_and_global_atomic_count_agree(variant, P, W, H, sm):
             assert_grad_close(d1[k], d0[k], k, rel_to_max=1e-6)
         else:
             assert np.array_equal(d1[k], d0[k]), k
+
+
+def test_view_streams_count_with_atomics_while_views_are_in_flight():
+    """dgr_amd.multiview.ViewStreams: from the first next() to join() the library option lds_count is 0 (the global
+    atomics' wait is filled by the other views' kernels), afterwards the caller's value is back; a
+    one-stream ViewStreams and count_with_atomics=False leave it alone."""
+    from dgr_amd import _capi
+    from dgr_amd.multiview import ViewStreams
+    before = _capi.get_option("lds_count")
+    vs = ViewStreams(3, hh.dev())
+    assert _capi.get_option("lds_count") == before
+    with vs.next():
+        assert _capi.get_option("lds_count") == 0
+    with vs.next():
+        assert _capi.get_option("lds_count") == 0
+    vs.join()
+    assert _capi.get_option("lds_count") == before
+    for other in (ViewStreams(1, hh.dev()), ViewStreams(3, hh.dev(), count_with_atomics=False)):
+        with other.next():
+            assert _capi.get_option("lds_count") == before
+        other.join()
