@@ -317,11 +317,27 @@ __global__ void __launch_bounds__(CL_THREADS) scan_table_kernel(ImageView img, u
     const bool live = tile < tiles;
     const int rows_per = (nwg + CL_THREADS / 64 - 1) / (CL_THREADS / 64);
     const int r0 = wave * rows_per;
+    // Order of the workgroups' runs inside a tile's segment: XCD-major.  Counting workgroup w ran on XCD w % 8 and emit
+    // hands its Gaussians to the same XCD, so with the runs of one XCD adjacent every cache line of the key array is
+    // written by ONE XCD's L2 and leaves it complete -- with the runs in plain w order each line collected 8-byte pieces
+    // in eight L2s and went to memory eight times (emit: 57 MB written for 13 MB of keys).  Position p of the order is
+    // workgroup (p % (nwg / 8)) * 8 + p / (nwg / 8); any order is a valid placement.
+    const int per_xcd = nwg >> 3;
+    const bool xcd_major = (nwg & 7) == 0;
+    int rows[ST_ROWS_MAX];  // (one division per wave, then incremental: the positions of a wave are consecutive)
+    {
+        int q = xcd_major ? r0 % per_xcd : 0, x = xcd_major ? r0 / per_xcd : 0;
+#pragma unroll
+        for (int i = 0; i < ST_ROWS_MAX; i++) {
+            rows[i] = xcd_major ? q * 8 + x : r0 + i;
+            if (++q == per_xcd) { q = 0; x++; }
+        }
+    }
     uint32_t c[ST_ROWS_MAX];
     uint32_t mine = 0;
 #pragma unroll
     for (int i = 0; i < ST_ROWS_MAX; i++) {
-        c[i] = (live && i < rows_per && r0 + i < nwg) ? table[(size_t)(r0 + i) * tiles + tile] : 0u;
+        c[i] = (live && i < rows_per && r0 + i < nwg) ? table[(size_t)rows[i] * tiles + tile] : 0u;
         mine += c[i];
     }
     grp[wave][lane] = mine;
@@ -364,7 +380,7 @@ __global__ void __launch_bounds__(CL_THREADS) scan_table_kernel(ImageView img, u
     uint32_t base = start + above;
 #pragma unroll
     for (int i = 0; i < ST_ROWS_MAX; i++) {
-        if (live && i < rows_per && r0 + i < nwg) table[(size_t)(r0 + i) * tiles + tile] = base;
+        if (live && i < rows_per && r0 + i < nwg) table[(size_t)rows[i] * tiles + tile] = base;
         base += c[i];
     }
     // (empty tiles keep {0, 0}: the reference clears the table and writes only tiles that own instances)
