@@ -129,8 +129,8 @@ class ViewStreams:
         k = self._i % len(self.streams)
         st = self.streams[k]
         self._i += 1
-        if self._atomics and self._saved_count_mode is None:
-            self._saved_count_mode = _capi.get_option("lds_count")
+        if self._atomics and self._saved_count_mode is None and _capi.get_option("lds_count") == 1:
+            self._saved_count_mode = 1  # (only the default "by job size" is overridden: a forced 0 / 2 stays)
             _capi.set_option("lds_count", 0)
         if k not in self._fresh:
             st.wait_stream(torch.cuda.current_stream(self.device))
