@@ -99,6 +99,15 @@ def main():
                     help="N>1: blocking = the view's stream waits for its gradient all-reduce (with several views in "
                          "flight the other streams keep rendering under it); overlap = additionally defer the wait to "
                          "the next view issued (for --views-in-flight 1)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="not the headline workload: a step renders this many camera views (2..8) of the same Gaussians through "
+                         "the batched entry points (dgr_amd.batch: one per-Gaussian launch each way for the whole batch, the "
+                         "Gaussians' gradients summed over the views in registers); value still counts views.  N>1: one fused "
+                         "all-reduce per batch (BASELINE config 5's pattern)")
+    ap.add_argument("--group", type=int, default=0,
+                    help="the comparison for --batch: the same views one call at a time, .grad accumulating over this many "
+                         "views (autograd's `+=`) before it is reset -- what a mapping iteration over a keyframe batch does "
+                         "on the one-view surface; implies --views-in-flight 1")
     ap.add_argument("--sync-mode", default="lazy", choices=["lazy", "strict"],
                     help="lazy: forward's status word is checked one step late (no host sync in the step); "
                          "strict: one blocking status read per forward, like the reference")
@@ -164,15 +173,48 @@ def main():
         settings = make_settings(s, deg, dev, map_off=args.tracking)
     rast = GaussianRasterizer(settings)
     params = [means3D, means2D, shs, opac, scales, rots]
-    arena = GradientArena(params) if dist is not None else None
+    Vb = max(0, args.batch)
+    if Vb:
+        if args.variant != "light" or args.tracking or args.graph:
+            raise SystemExit("--batch: light variant, mapping step, eager")
+        from dgr_amd import batch as Bm
+        from dgr_amd.synth import camera
+        # rank r renders views r*Vb .. r*Vb + Vb - 1 of the same Gaussians (view k: the camera at angle 0.05 (k + 1))
+        cams = [camera(W, H, 0.05 * (rank * Vb + k + 1)) for k in range(Vb)]
+        views_b = t(np.stack([c_[4] for c_ in cams])).requires_grad_(True)
+        projs_b, campos_b = t(np.stack([c_[5] for c_ in cams])), t(np.stack([c_[7] for c_ in cams]))
+        gts_b = gt[None].expand(Vb, -1, -1).contiguous()
+        gCb, gDb, gMb, gVb = (g_[None].expand(Vb, *g_.shape).contiguous() for g_ in (gC, gD, gM, gV))
+        means2D = torch.zeros((Vb, P, 3), device=dev, requires_grad=True)
+        params = [means3D, means2D, shs, opac, scales, rots]
+        rast_b = Bm.GaussianRasterizerBatch(Bm.BatchRasterizationSettings(
+            s.H, s.W, s.tanfovx, s.tanfovy, settings.bg, 1.0, views_b, projs_b, deg, campos_b, False, False,
+            settings.perspec_matrix, False, False))
+    # the fused all-reduce span is found through the gradients (the batch's per-view means2D gradient is not part of it)
+    arena = GradientArena([means3D, shs, opac, scales, rots] if Vb else params) if dist is not None else None
+    group_i = [0]
 
     pending = [None]
     G = max(1, args.views_per_allreduce)
     grouped = GroupedReduce(arena, dist, G) if (arena is not None and G > 1) else None
 
-    def step():
-        for p_ in params + [view]:
+    def step_batch():
+        for p_ in params + [views_b]:
             p_.grad = None
+        color, radii, depth, median, var, alpha, unc, px = rast_b(
+            means3D, means2D, opac, shs=shs, scales=scales, rotations=rots, viewmatrices=views_b, gt_depths=gts_b)
+        torch.autograd.backward([color, depth, median, var], [gCb, gDb, gMb, gVb])
+        if arena is not None:  # one fused RCCL all-reduce of the batch's summed per-Gaussian gradients
+            arena.all_reduce(dist)
+        return radii[0]
+
+    def step():
+        if Vb:
+            return step_batch()
+        if args.group <= 1 or group_i[0] % args.group == 0:
+            for p_ in params + [view]:
+                p_.grad = None
+        group_i[0] += 1
         outs = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots,
                     viewmatrix=view, gt_depth=gt)
         if args.variant == "full":
@@ -204,7 +246,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    K = max(1, args.views_in_flight)
+    K = 1 if (Vb or args.group > 1) else max(1, args.views_in_flight)  # (a batch spreads its views over streams itself)
     views = ViewStreams(K, dev) if K > 1 else None  # dgr_amd.multiview: independent views on K HIP streams
 
     captured = []
@@ -301,7 +343,7 @@ def main():
             if lib_.dgr_state_export(_capi.stream_handle(), b"n_contrib", P, W, H, int(st_[0]), cap_, st_[7].data_ptr(),
                                      st_[8].data_ptr(), st_[9].data_ptr(), nc.data_ptr()) >= 0:
                 pair_evals = 2 * int(nc.to(torch.int64).sum().item())
-        views_per_s = world * args.steps / elapsed
+        views_per_s = world * args.steps * max(1, Vb) / elapsed
         dom_ms = dom_tot / max(dom_n, 1)
         live = dom_n > 0
         if not live:  # hipGraph replay: the launches are inside the graphs, nothing is bracketed live
@@ -331,13 +373,18 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
-                                   f"fwd+bwd incl. viewmatrix gradient, one view per step, {K} independent views in flight per GPU"
+                                   f"fwd+bwd incl. viewmatrix gradient, "
+                                   + (f"one view per step, {K} independent views in flight per GPU" if not Vb else
+                                      f"NOT the headline step: {Vb} camera views of the same Gaussians per step through the batched entry "
+                                      f"points (gradients of the Gaussians summed over the batch)")
+                                   + (f"; .grad accumulates over groups of {args.group} views" if args.group > 1 else "")
                                    + ("" if dist is None else f"; {world} GPUs, rank r renders view r of the same Gaussians (weak scaling, the "
                                       f"per-GPU view is the N=1 workload), exchange pattern of BASELINE config "
                                       f"{'4: one fused all-reduce of the Gaussian gradients after every view' if G == 1 else '5: one fused all-reduce per ' + str(G) + ' local views'}")
                                    + (" -- TRACKING step: pose gradient only (map_off), not the headline mapping step" if args.tracking else ""), "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
-                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "hipgraph_replay": bool(args.graph),
+                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "views_per_step": max(1, Vb),
+                       "ms_per_view": 1e3 * elapsed / args.steps / max(1, Vb), "hipgraph_replay": bool(args.graph),
                        "tile_count": ("global atomics while several views are in flight (dgr_amd.multiview.ViewStreams; their wait "
                                       "is filled by the other views), LDS histograms for ms_per_view_one_stream, stage_ms and the "
                                       "roofline's isolated figure" if (views is not None and not captured) else

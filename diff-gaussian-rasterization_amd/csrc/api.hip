@@ -303,6 +303,52 @@ int check_common(const FwdCommon& c) {
     return DGR_OK;
 }
 
+// ---- batched views (dgr_light_forward_batch / dgr_light_backward_batch) ----
+// The per-Gaussian kernels of a batch run ONCE for all views on the caller's stream; the per-view stages in between
+// (binning + blend, blend backward) are independent and mix kernels that leave the chip idle (count, scan, emit, sort) with
+// kernels bound by VALU issue (blend), so view v runs them on stream v mod K -- the caller's stream and K - 1 helper
+// streams of this thread -- forked and joined with events: what DESIGN.md s7 measured for "views in flight", inside one call
+// and capturable into one hipGraph.  dgr_set_option("batch_streams", K), K = 1..3 (default 3).
+std::atomic<int> g_batch_streams{3};
+constexpr int DGR_BATCH_MAX_STREAMS = 3;
+struct BatchStreams {
+    int device = -1;
+    hipStream_t helper[DGR_BATCH_MAX_STREAMS - 1] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr;
+    hipEvent_t join[DGR_BATCH_MAX_STREAMS - 1] = {nullptr, nullptr};
+};
+thread_local BatchStreams g_batch;
+int batch_streams_ready() {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (g_batch.device == dev) return DGR_OK;
+    // (streams and events belong to the device that was current when they were created; a thread that moves to another
+    //  device gets new ones, the old ones stay with their device)
+    g_batch = BatchStreams{};
+    for (int i = 0; i < DGR_BATCH_MAX_STREAMS - 1; i++) {
+        HIP_TRY(hipStreamCreateWithFlags(&g_batch.helper[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g_batch.join[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventCreateWithFlags(&g_batch.fork, hipEventDisableTiming));
+    g_batch.device = dev;
+    return DGR_OK;
+}
+// stream of view v among K; fork: the helpers wait for what the caller's stream has enqueued so far
+inline hipStream_t batch_stream(hipStream_t main, int v, int K) { return (v % K == 0) ? main : g_batch.helper[v % K - 1]; }
+int batch_fork(hipStream_t main, int K) {
+    if (K <= 1) return DGR_OK;
+    HIP_TRY(hipEventRecord(g_batch.fork, main));
+    for (int i = 0; i < K - 1; i++) HIP_TRY(hipStreamWaitEvent(g_batch.helper[i], g_batch.fork, 0));
+    return DGR_OK;
+}
+int batch_join(hipStream_t main, int K) {
+    for (int i = 0; i < K - 1; i++) {
+        HIP_TRY(hipEventRecord(g_batch.join[i], g_batch.helper[i]));
+        HIP_TRY(hipStreamWaitEvent(main, g_batch.join[i], 0));
+    }
+    return DGR_OK;
+}
+
 // ---- state export (tests / profiling) ----
 enum ExportKind { EX_MEANS2D, EX_CONIC_OPACITY, EX_RGB, EX_CLAMPED, EX_TILES_TOUCHED, EX_KEYS };
 
@@ -636,6 +682,152 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     return DGR_OK;
 }
 
+int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* views, int P, int D, int M,
+                            const float* background, int width, int height, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cov3D_precomp, float tan_fovx, float tan_fovy, int prefiltered) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n_views < 1 || n_views > DGR_MAX_BATCH_VIEWS || !views) { g_last_error = "1 .. DGR_MAX_BATCH_VIEWS views per batch"; return DGR_ERR_BAD_ARGUMENT; }
+    FwdCommon cv[DGR_MAX_BATCH_VIEWS];
+    for (int v = 0; v < n_views; v++) {
+        const dgr_light_view& w = views[v];
+        cv[v] = FwdCommon{P, D, M, width, height, background, means3D, shs, colors_precomp, opacities, scales, rotations,
+                          cov3D_precomp, scale_modifier, w.viewmatrix, w.projmatrix, w.cam_pos, tan_fovx, tan_fovy, prefiltered,
+                          w.out_color, w.out_depth, w.out_median_depth, w.out_alpha, w.gt_depth, w.out_depth_var,
+                          w.gau_uncertainty, w.gau_related_pixels, w.radii};
+        if (!w.viewmatrix || !w.projmatrix || !w.cam_pos || !w.out_color || !w.out_depth) { g_last_error = "view without camera or outputs"; return DGR_ERR_BAD_ARGUMENT; }
+        if (P > 0 && (!w.geometry_buffer || !w.image_buffer || (!w.binning_buffer && w.binning_capacity > 0) || w.binning_capacity < 0)) {
+            g_last_error = "view without state buffers";
+            return DGR_ERR_BAD_ARGUMENT;
+        }
+    }
+    int rc = check_common(cv[0]);
+    if (rc) return rc;
+    if (P == 0) {
+        for (int v = 0; v < n_views; v++) {
+            if (views[v].status) HIP_TRY(hipMemsetAsync(views[v].status, 0, 16, st));
+            if ((rc = zero_outputs(cv[v], st))) return rc;
+        }
+        return DGR_OK;
+    }
+    if ((rc = batch_streams_ready())) return rc;
+    dgr::GeometryView geom[DGR_MAX_BATCH_VIEWS];
+    dgr::ImageView img[DGR_MAX_BATCH_VIEWS];
+    dgr::BinningView bin[DGR_MAX_BATCH_VIEWS];
+    for (int v = 0; v < n_views; v++) {
+        geom[v] = dgr::carve_geometry(views[v].geometry_buffer, P);
+        img[v] = dgr::carve_image(views[v].image_buffer, width, height);
+        if (views[v].status) img[v].status = views[v].status;
+        bin[v] = dgr::carve_binning(views[v].binning_buffer, (size_t)views[v].binning_capacity);
+    }
+    const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
+    // One preprocess launch for all views needs the LDS count behind it (its epilogue leaves per-block instance totals);
+    // frames whose tile histogram does not fit LDS, or "lds_count" = 0, take the one-view front end per view.
+    const bool shared_front = g_lds_count.load() != 0 && dgr::count_lds_fits(gx * gy);
+    if (shared_front) {
+        dgr::PreprocessFwdBatchArgs b{};
+        dgr::PreprocessFwdArgs& a = b.base;
+        a.P = P; a.D = D; a.M = M; a.W = width; a.H = height; a.grid_x = gx; a.grid_y = gy;
+        a.means3D = means3D; a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations;
+        a.opacities = opacities; a.shs = shs; a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
+        a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+        a.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:228-229
+        a.focal_x = width / (2.0f * tan_fovx);
+        a.prefiltered = prefiltered;
+        a.tight_cull = g_tight_cull.load();
+        a.sh_vec_ok = aligned16(shs);
+        b.V = n_views;
+        for (int v = 0; v < n_views; v++) {
+            b.v[v].view = views[v].viewmatrix; b.v[v].proj = views[v].projmatrix; b.v[v].campos = views[v].cam_pos;
+            b.v[v].geom = geom[v]; b.v[v].radii_out = views[v].radii; b.v[v].gau_uncertainty = views[v].gau_uncertainty;
+            b.v[v].gau_related_pixels = views[v].gau_related_pixels;
+        }
+        { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd_batch(b, st)); }
+    }
+    const int K = std::max(1, std::min({n_views, g_batch_streams.load(), DGR_BATCH_MAX_STREAMS}));
+    if ((rc = batch_fork(st, K))) return rc;
+    for (int v = 0; v < n_views; v++) {
+        hipStream_t sv = batch_stream(st, v, K);
+        const int cap = views[v].binning_capacity;
+        int mode = COUNT_LDS;
+        if (!shared_front) {
+            mode = presized_count_mode(width, height, cap);
+            if ((rc = forward_front(cv[v], geom[v], img[v], sv, &bin[v], cap, views[v].image_buffer, mode))) return rc;
+        }
+        if ((rc = binning_stages(cv[v], geom[v], img[v], bin[v], cap, sv, mode, views[v].binning_buffer))) return rc;
+        if ((rc = forward_back(cv[v], geom[v], img[v], bin[v], sv))) return rc;
+    }
+    return batch_join(st, K);
+}
+
+int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_grad* views, int P, int D, int M,
+                             const float* background, int width, int height, const float* means3D, const float* shs,
+                             const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                             const float* cov3D_precomp, float tan_fovx, float tan_fovy, float* dL_dopacity, float* dL_dcolor,
+                             float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                             int track_off, int map_off) {
+    (void)colors_precomp;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_views < 1 || n_views > DGR_MAX_BATCH_VIEWS || !views) { g_last_error = "1 .. DGR_MAX_BATCH_VIEWS views per batch"; return DGR_ERR_BAD_ARGUMENT; }
+    if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
+    for (int v = 0; v < n_views; v++)
+        if (!views[v].dL_dview) { g_last_error = "view without dL_dview"; return DGR_ERR_BAD_ARGUMENT; }
+    if (P == 0) {  // L/rasterize_points.cu:188: nothing runs, gradients stay zero
+        for (int v = 0; v < n_views; v++) HIP_TRY(hipMemsetAsync(views[v].dL_dview, 0, 16 * 4, st));
+        return DGR_OK;
+    }
+    const size_t need = dgr_light_backward_scratch_bytes(P, width, height);
+    for (int v = 0; v < n_views; v++) {
+        const dgr_light_view_grad& w = views[v];
+        if (!w.scratch || w.scratch_bytes < need) { g_last_error = "backward scratch too small"; return DGR_ERR_BAD_ARGUMENT; }
+        if (!w.geometry_buffer || !w.image_buffer || !w.viewmatrix || !w.projmatrix || !w.cam_pos || !w.perspec_matrix || !w.alphas ||
+            !w.dL_dpix || !w.dL_dpix_depth || !w.dL_dpix_median_depth || !w.dL_dpix_depth_var) {
+            g_last_error = "view with a missing state buffer, camera or gradient image";
+            return DGR_ERR_BAD_ARGUMENT;
+        }
+    }
+    int rc;
+    if ((rc = batch_streams_ready())) return rc;
+    const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
+    const int K = std::max(1, std::min({n_views, g_batch_streams.load(), DGR_BATCH_MAX_STREAMS}));
+    dgr::PreprocessBwdBatchArgs bb{};
+    if ((rc = batch_fork(st, K))) return rc;
+    for (int v = 0; v < n_views; v++) {
+        const dgr_light_view_grad& w = views[v];
+        hipStream_t sv = batch_stream(st, v, K);
+        dgr::GeometryView geom = dgr::carve_geometry(w.geometry_buffer, P);
+        dgr::ImageView img = dgr::carve_image(w.image_buffer, width, height);
+        dgr::BackwardScratch sc = dgr::carve_backward_scratch(w.scratch, P);
+        { ScopedStage t(ST_ZERO, sv); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, sv)); }
+        dgr::RenderBwdLightArgs r{};
+        r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
+        r.ranges = img.ranges; r.point_list = (const uint32_t*)w.binning_buffer; r.rec = geom.rec; r.bg = background;
+        r.gt_depth = w.gt_depth; r.alphas = w.alphas; r.n_contrib = img.n_contrib; r.dL_dpix = w.dL_dpix;
+        r.dL_dpix_depth = w.dL_dpix_depth; r.dL_dpix_median = w.dL_dpix_median_depth; r.dL_dpix_var = w.dL_dpix_depth_var;
+        r.means3D = means3D; r.view = w.viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
+        r.binning_base = w.binning_buffer; r.capacity = img.cursor + 2;
+        { ScopedStage t(ST_RENDER_BWD, sv); HIP_TRY(dgr::launch_render_bwd_light(r, sv)); }
+        dgr::BwdViewPart& q = bb.v[v];
+        q.view = w.viewmatrix; q.proj = w.projmatrix; q.campos = w.cam_pos; q.perspec = w.perspec_matrix;
+        q.radii = w.radii ? w.radii : geom.radii; q.geom = geom; q.acc = sc.acc; q.dL_dmean2D = w.dL_dmean2D;
+        q.pose_part = sc.pose_part; q.ticket = sc.ticket; q.dL_dview = w.dL_dview;
+    }
+    if ((rc = batch_join(st, K))) return rc;
+    dgr::PreprocessBwdArgs& b = bb.base;
+    b.P = P; b.D = D; b.M = M; b.W = width; b.H = height; b.means3D = means3D; b.shs = shs; b.scales = scales;
+    b.rotations = rotations; b.scale_modifier = scale_modifier; b.cov3D_precomp = cov3D_precomp;
+    b.tan_fovx = tan_fovx; b.tan_fovy = tan_fovy;
+    b.focal_y = height / (2.0f * tan_fovy);
+    b.focal_x = width / (2.0f * tan_fovx);
+    b.sh_vec_ok = aligned16(shs) && aligned16(dL_dsh);
+    b.track_off = track_off; b.map_off = map_off;
+    b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
+    b.dL_dscale = dL_dscale; b.dL_drot = dL_drot;
+    bb.V = n_views;
+    { ScopedStage t(ST_PRE_BWD, st); HIP_TRY(dgr::launch_preprocess_bwd_batch(bb, st)); }
+    return DGR_OK;
+}
+
 int dgr_cov3d_forward(void* stream, int P, const float* scales, const float* rotations, float scale_modifier, float* cov3D) {
     if (P < 0 || (P > 0 && (!scales || !rotations || !cov3D))) { g_last_error = "dgr_cov3d_forward: bad argument"; return DGR_ERR_BAD_ARGUMENT; }
     HIP_TRY(dgr::launch_cov3d_forward(P, scales, rotations, scale_modifier, cov3D, (hipStream_t)stream));
@@ -816,6 +1008,7 @@ int dgr_set_option(const char* name, int value) {
     if (n == "bwd_rows") { g_bwd_rows.store(value ? 1 : 0); return DGR_OK; }
     if (n == "lds_count") { g_lds_count.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
     if (n == "profile_every") { g_profile_every.store(value > 0 ? value : 1); return DGR_OK; }
+    if (n == "batch_streams") { g_batch_streams.store(value < 1 ? 1 : value > DGR_BATCH_MAX_STREAMS ? DGR_BATCH_MAX_STREAMS : value); return DGR_OK; }
     g_last_error = "unknown option: " + n;
     return DGR_ERR_BAD_ARGUMENT;
 }
@@ -825,6 +1018,7 @@ int dgr_get_option(const char* name) {
     if (n == "bwd_rows") return g_bwd_rows.load();
     if (n == "lds_count") return g_lds_count.load();
     if (n == "profile_every") return g_profile_every.load();
+    if (n == "batch_streams") return g_batch_streams.load();
     return DGR_ERR_BAD_ARGUMENT;
 }
 

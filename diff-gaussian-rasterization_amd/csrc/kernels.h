@@ -71,6 +71,25 @@ struct PreprocessFwdArgs {
     int capacity;
 };
 
+// ---- batched views: what differs between the views of a batch; everything else is in `base`
+#ifndef DGR_MAX_BATCH_VIEWS
+#define DGR_MAX_BATCH_VIEWS 8  // (also in include/dgr_hip.h)
+#endif
+struct FwdViewPart {
+    const float* view;
+    const float* proj;
+    const float* campos;
+    GeometryView geom;
+    int* radii_out;
+    float* gau_uncertainty;
+    int* gau_related_pixels;
+};
+struct PreprocessFwdBatchArgs {
+    PreprocessFwdArgs base;  // view / proj / campos / geom / radii_out / gau_* unused
+    int V;
+    FwdViewPart v[DGR_MAX_BATCH_VIEWS];
+};
+
 struct PreprocessBwdArgs {
     int P, D, M, W, H;
     const float* means3D;
@@ -106,6 +125,25 @@ struct PreprocessBwdArgs {
     double* pose_part;  // [DGR_POSE_BUCKETS,12], zero on entry
     uint32_t* ticket;   // zero on entry
     float* dL_dview;    // [16] written by the last block to deliver its pose partial
+};
+
+struct BwdViewPart {
+    const float* view;
+    const float* proj;
+    const float* campos;
+    const float* perspec;
+    const int* radii;
+    GeometryView geom;
+    const float* acc;     // this view's accumulator rows (its backward scratch)
+    float* dL_dmean2D;    // [P,3] per view (densification statistics are per view); may be NULL
+    double* pose_part;
+    uint32_t* ticket;
+    float* dL_dview;      // [16]
+};
+struct PreprocessBwdBatchArgs {
+    PreprocessBwdArgs base;  // the per-view members unused; the dense outputs receive the SUM over the views
+    int V;
+    BwdViewPart v[DGR_MAX_BATCH_VIEWS];
 };
 
 struct RenderFwdLightArgs {
@@ -182,6 +220,8 @@ struct RenderBwdFullArgs {
 // ---- launchers (each enqueues on `stream` and returns the hipError_t of the launch) ----
 hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream);
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream);
+hipError_t launch_preprocess_fwd_batch(const PreprocessFwdBatchArgs& b, hipStream_t stream);
+hipError_t launch_preprocess_bwd_batch(const PreprocessBwdBatchArgs& b, hipStream_t stream);
 // zero-fill of a 16-byte aligned buffer whose size is a multiple of 16 (a kernel rather than hipMemsetAsync: memset nodes of a
 // captured hipGraph were seen to re-execute with corrupted parameters on this ROCm)
 hipError_t launch_zero_fill(void* dst, size_t bytes, hipStream_t stream);

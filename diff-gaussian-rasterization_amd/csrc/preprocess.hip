@@ -22,6 +22,9 @@
 #endif
 
 #pragma clang fp contract(off)
+#ifndef DGR_BWD_BATCH_WAVES
+#define DGR_BWD_BATCH_WAVES 2  // waves per SIMD the batched backward is compiled for (48 dL_dsh sums live across its view loop)
+#endif
 
 namespace dgr {
 namespace {
@@ -153,6 +156,20 @@ __device__ __forceinline__ M3 diag3(float a, float b, float c) {
     return S;
 }
 
+// computeCov3D (forward.cu:118-152): M = S*R, Sigma = M^T M
+__device__ __forceinline__ void compute_cov3d(const float* __restrict__ scales, const float* __restrict__ rotations, float mod, int idx,
+                                              float (&c3)[6]) {
+    const float3 sc = make_float3(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2]);
+    const float4 q = make_float4(rotations[4 * idx], rotations[4 * idx + 1], rotations[4 * idx + 2], rotations[4 * idx + 3]);
+    M3 R;
+    quat_to_R(q, R);
+    const M3 S = diag3(mod * sc.x, mod * sc.y, mod * sc.z);
+    const M3 Mm = mul(S, R);
+    const M3 Sigma = mul(transpose(Mm), Mm);
+    c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
+    c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+}
+
 }  // namespace
 
 // ---- SH rows <-> lanes through LDS
@@ -276,26 +293,23 @@ __device__ __forceinline__ void sh_direction_derivatives(const SHCoeffs& s, int 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+// ---- per-view pieces of preprocessCUDA, shared by the one-view kernel and the batched one ----
+struct FwdGeom {
+    int radius;
+    ushort4 rect;
+    bool violation, need_sh;
+};
+// Frustum test, covariance projection, radius, tile rectangle and the first two pieces of the render record of Gaussian
+// idx for the camera in `a` (forward.cu:155-256 up to the colour).  C3_GIVEN: the 3D covariance -- it depends on scale
+// and rotation only -- was formed by the caller (the batched kernel evaluates it once for all views of the batch; same
+// expression, same bits) and is only stored here.
+template <bool C3_GIVEN>
+__device__ __forceinline__ FwdGeom fwd_view_geometry(const PreprocessFwdArgs& a, int idx, float3 p_orig, const float (&c3_in)[6]) {
     int radius = 0;
     ushort4 rect = make_ushort4(0, 0, 0, 0);
-    bool violation = false;
-    float3 p_sh = make_float3(0.f, 0.f, 0.f);  // position of a Gaussian whose colour still has to be evaluated from SH
-    bool need_sh = false;
-    // LDS: the SH transposition buffer and, afterwards, the rank stage of the fused count share one pool
-    constexpr int POOL_WORDS = (4 * SHT_ROWS * SHT_LD > COUNT_STAGE) ? 4 * SHT_ROWS * SHT_LD : COUNT_STAGE;
-    __shared__ float pool[POOL_WORDS];
-    // Zeroing that would otherwise be stream memsets (one launch each): the tile counters count_rank increments
-    // (callback path only -- the fused count needs them cleared before this kernel starts) and the two per-Gaussian
-    // median statistics the forward blend accumulates into.
-    for (int i = idx; i < a.n_zero_words; i += gridDim.x * 256) a.zero_words[i] = 0u;
-    if (idx < a.P) {
+    bool violation = false, need_sh = false;
     if (a.gau_uncertainty) a.gau_uncertainty[idx] = 0.0f;
     if (a.gau_related_pixels) a.gau_related_pixels[idx] = 0;
-    const float3 p_orig = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
-
     // in_frustum (cuda_rasterizer/auxiliary.h:139-164)
     const float4 p_hom = xform4x4(p_orig, a.proj);
     const float p_w = 1.0f / (p_hom.w + 0.0000001f);
@@ -306,21 +320,18 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
 
     if (live) {
         float c3[6];
-        if (a.cov3D_precomp) {
+        if (C3_GIVEN) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = c3_in[i];
+            if (!a.cov3D_precomp) {
+                reinterpret_cast<float4*>(a.geom.cov3D)[idx] = make_float4(c3[0], c3[1], c3[2], c3[3]);
+                reinterpret_cast<float2*>(a.geom.cov3D + 4 * (size_t)a.P)[idx] = make_float2(c3[4], c3[5]);
+            }
+        } else if (a.cov3D_precomp) {
 #pragma unroll
             for (int i = 0; i < 6; i++) c3[i] = a.cov3D_precomp[6 * (size_t)idx + i];
         } else {
-            // computeCov3D (forward.cu:118-152): M = S*R, Sigma = M^T M
-            const float3 sc = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
-            const float4 q = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2],
-                                         a.rotations[4 * idx + 3]);
-            M3 R;
-            quat_to_R(q, R);
-            const M3 S = diag3(a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z);
-            const M3 Mm = mul(S, R);
-            const M3 Sigma = mul(transpose(Mm), Mm);
-            c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
-            c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+            compute_cov3d(a.scales, a.rotations, a.scale_modifier, idx, c3);
             // two planes, {c0..c3} as float4 and {c4, c5} as float2: consecutive lanes store consecutive pieces (six 4-byte
             // stores at a 24-byte lane stride touch 24 cache lines per wave instruction)
             reinterpret_cast<float4*>(a.geom.cov3D)[idx] = make_float4(c3[0], c3[1], c3[2], c3[3]);
@@ -347,7 +358,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
                                       a.colors_precomp[3 * (size_t)idx + 2]);
                 } else {
                     need_sh = true;  // evaluated below, after the geometry: a whole block then fetches its SH rows together
-                    p_sh = p_orig;
                     rgb = make_float3(0.f, 0.f, 0.f);
                 }
                 radius = (int)my_radius;
@@ -385,7 +395,79 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
     a.geom.radii[idx] = radius;
     if (a.radii_out) a.radii_out[idx] = radius;
     a.geom.rect[idx] = rect;
-    }  // idx < P
+    return FwdGeom{radius, rect, violation, need_sh};
+}
+
+// computeColorFromSH (forward.cu:20-71) for the camera in `a`, plus what the backward keeps of it; writes the third piece
+// of the render record
+__device__ __forceinline__ void fwd_view_colour(const PreprocessFwdArgs& a, int idx, float3 p_orig, const SHCoeffs& s) {
+    float3 rgb;
+    const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
+    float3 dir = p_orig - cam;
+    const float len = sqrtf(dot3(dir, dir));
+    dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
+    float3 res = SH_C0 * s.c[0];
+    if (a.D > 0) {
+        const float x = dir.x, y = dir.y, z = dir.z;
+        res = res - SH_C1 * y * s.c[1] + SH_C1 * z * s.c[2] - SH_C1 * x * s.c[3];
+        if (a.D > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = res + SH_C2[0] * xy * s.c[4] + SH_C2[1] * yz * s.c[5] +
+                  SH_C2[2] * (2.0f * zz - xx - yy) * s.c[6] + SH_C2[3] * xz * s.c[7] +
+                  SH_C2[4] * (xx - yy) * s.c[8];
+            if (a.D > 2) {
+                res = res + SH_C3[0] * y * (3.0f * xx - yy) * s.c[9] + SH_C3[1] * xy * z * s.c[10] +
+                      SH_C3[2] * y * (4.0f * zz - xx - yy) * s.c[11] +
+                      SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * s.c[12] +
+                      SH_C3[4] * x * (4.0f * zz - xx - yy) * s.c[13] +
+                      SH_C3[5] * z * (xx - yy) * s.c[14] + SH_C3[6] * x * (xx - 3.0f * yy) * s.c[15];
+            }
+        }
+    }
+    res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+    {
+        // d(colour)/d(direction) (L/cuda_rasterizer/backward.cu:50-133), kept for the backward: it is all the
+        // backward needs of the SH coefficients beyond the basis values, which depend on the direction alone
+        float3 dRGBdx = make_float3(0, 0, 0), dRGBdy = make_float3(0, 0, 0), dRGBdz = make_float3(0, 0, 0);
+#if DGR_ABLATE_SHD != 2
+        sh_direction_derivatives(s, a.D, dir, dRGBdx, dRGBdy, dRGBdz);
+#endif
+#if DGR_ABLATE_SHD == 1
+        float4* shd = a.geom.shd + (size_t)(a.P < 0 ? idx : 0);
+        if (dRGBdx.x == 12345.f)
+#else
+        float4* shd = a.geom.shd + (size_t)idx;  // three planes of P float4: consecutive lanes store consecutive 16-byte pieces
+#endif
+        {
+            shd[0] = make_float4(dRGBdx.x, dRGBdx.y, dRGBdx.z, 0.0f);
+            shd[(size_t)a.P] = make_float4(dRGBdy.x, dRGBdy.y, dRGBdy.z, 0.0f);
+            shd[2 * (size_t)a.P] = make_float4(dRGBdz.x, dRGBdz.y, dRGBdz.z, 0.0f);
+        }
+    }
+    a.geom.clamped[idx] = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
+    rgb = make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
+    a.geom.rec[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    FwdGeom g{0, make_ushort4(0, 0, 0, 0), false, false};
+    float3 p_orig = make_float3(0.f, 0.f, 0.f);
+    // LDS: the SH transposition buffer and, afterwards, the rank stage of the fused count share one pool
+    constexpr int POOL_WORDS = (4 * SHT_ROWS * SHT_LD > COUNT_STAGE) ? 4 * SHT_ROWS * SHT_LD : COUNT_STAGE;
+    __shared__ float pool[POOL_WORDS];
+    // Zeroing that would otherwise be stream memsets (one launch each): the tile counters count_rank increments
+    // (callback path only -- the fused count needs them cleared before this kernel starts) and the two per-Gaussian
+    // median statistics the forward blend accumulates into.
+    for (int i = idx; i < a.n_zero_words; i += gridDim.x * 256) a.zero_words[i] = 0u;
+    if (idx < a.P) {
+        p_orig = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
+        const float no_c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        g = fwd_view_geometry<false>(a, idx, p_orig, no_c3);
+    }
+    const bool need_sh = g.need_sh, violation = g.violation;
+    const ushort4 rect = g.rect;
 
     // computeColorFromSH (forward.cu:20-71) for the Gaussians that survived
     if (a.shs && !a.colors_precomp) {  // uniform
@@ -396,7 +478,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
         float shf[48];
         if (blk_fast) sh_rows_to_lanes(a.shs, (size_t)blockIdx.x * 256, sht, shf);
         if (need_sh) {
-            const float3 p_orig = p_sh;
             SHCoeffs s;
             if (blk_fast) {
 #pragma unroll
@@ -404,52 +485,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
             } else {
                 load_sh(a.shs, idx, a.D, a.M, a.sh_vec_ok, s);
             }
-            float3 rgb;
-            const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
-            float3 dir = p_orig - cam;
-            const float len = sqrtf(dot3(dir, dir));
-            dir = make_float3(dir.x / len, dir.y / len, dir.z / len);
-            float3 res = SH_C0 * s.c[0];
-            if (a.D > 0) {
-                const float x = dir.x, y = dir.y, z = dir.z;
-                res = res - SH_C1 * y * s.c[1] + SH_C1 * z * s.c[2] - SH_C1 * x * s.c[3];
-                if (a.D > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                    res = res + SH_C2[0] * xy * s.c[4] + SH_C2[1] * yz * s.c[5] +
-                          SH_C2[2] * (2.0f * zz - xx - yy) * s.c[6] + SH_C2[3] * xz * s.c[7] +
-                          SH_C2[4] * (xx - yy) * s.c[8];
-                    if (a.D > 2) {
-                        res = res + SH_C3[0] * y * (3.0f * xx - yy) * s.c[9] + SH_C3[1] * xy * z * s.c[10] +
-                              SH_C3[2] * y * (4.0f * zz - xx - yy) * s.c[11] +
-                              SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * s.c[12] +
-                              SH_C3[4] * x * (4.0f * zz - xx - yy) * s.c[13] +
-                              SH_C3[5] * z * (xx - yy) * s.c[14] + SH_C3[6] * x * (xx - 3.0f * yy) * s.c[15];
-                    }
-                }
-            }
-            res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
-            {
-                // d(colour)/d(direction) (L/cuda_rasterizer/backward.cu:50-133), kept for the backward: it is all the
-                // backward needs of the SH coefficients beyond the basis values, which depend on the direction alone
-                float3 dRGBdx = make_float3(0, 0, 0), dRGBdy = make_float3(0, 0, 0), dRGBdz = make_float3(0, 0, 0);
-#if DGR_ABLATE_SHD != 2
-                sh_direction_derivatives(s, a.D, dir, dRGBdx, dRGBdy, dRGBdz);
-#endif
-#if DGR_ABLATE_SHD == 1
-                float4* shd = a.geom.shd + (size_t)(a.P < 0 ? idx : 0);
-                if (dRGBdx.x == 12345.f)
-#else
-                float4* shd = a.geom.shd + (size_t)idx;  // three planes of P float4: consecutive lanes store consecutive 16-byte pieces
-#endif
-                {
-                    shd[0] = make_float4(dRGBdx.x, dRGBdx.y, dRGBdx.z, 0.0f);
-                    shd[(size_t)a.P] = make_float4(dRGBdy.x, dRGBdy.y, dRGBdy.z, 0.0f);
-                    shd[2 * (size_t)a.P] = make_float4(dRGBdz.x, dRGBdz.y, dRGBdz.z, 0.0f);
-                }
-            }
-            a.geom.clamped[idx] = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
-            rgb = make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
-            a.geom.rec[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
+            fwd_view_colour(a, idx, p_orig, s);
         }
     }
 
@@ -492,6 +528,76 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a
 }
 
 // ------------------------------------------------------------------------------------------------
+// Batched forward preprocess: the V views of a batch in ONE launch.  A Gaussian's position, opacity and
+// 3D covariance are fetched / formed once, its 192-byte SH row is fetched once -- when at least one view sees it -- and
+// evaluated for every camera that does; per view the lane runs exactly the code of the one-view kernel
+// (fwd_view_geometry / fwd_view_colour), so every view's state buffers are bit-identical to a one-view call.  Only the
+// LDS-count form of the epilogue exists here (per-block instance totals in each view's geom.block_tiles).
+__device__ __forceinline__ PreprocessFwdArgs batch_view_args(const PreprocessFwdBatchArgs& b, int v) {
+    PreprocessFwdArgs a = b.base;
+    const FwdViewPart& p = b.v[v];
+    a.view = p.view; a.proj = p.proj; a.campos = p.campos; a.geom = p.geom; a.radii_out = p.radii_out;
+    a.gau_uncertainty = p.gau_uncertainty; a.gau_related_pixels = p.gau_related_pixels;
+    return a;
+}
+__global__ void __launch_bounds__(256) preprocess_fwd_batch_kernel(PreprocessFwdBatchArgs b) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int P = b.base.P, V = b.V;
+    __shared__ float pool[4 * SHT_ROWS * SHT_LD];
+    __shared__ uint32_t wsum[DGR_MAX_BATCH_VIEWS][4];
+    float3 p_orig = make_float3(0.f, 0.f, 0.f);
+    float c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (idx < P) {
+        p_orig = make_float3(b.base.means3D[3 * idx], b.base.means3D[3 * idx + 1], b.base.means3D[3 * idx + 2]);
+        if (b.base.cov3D_precomp) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = b.base.cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+            compute_cov3d(b.base.scales, b.base.rotations, b.base.scale_modifier, idx, c3);
+        }
+    }
+    uint32_t need_mask = 0u;
+#pragma unroll 1
+    for (int v = 0; v < V; v++) {
+        const PreprocessFwdArgs a = batch_view_args(b, v);
+        FwdGeom g{0, make_ushort4(0, 0, 0, 0), false, false};
+        if (idx < P) g = fwd_view_geometry<true>(a, idx, p_orig, c3);
+        if (g.need_sh) need_mask |= 1u << v;
+        // instances (tiles_touched) of this block in view v, as the one-view kernel leaves them for count_lds / scan_table
+        uint32_t n = (uint32_t)(g.rect.z - g.rect.x) * (uint32_t)(g.rect.w - g.rect.y);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+        if (__builtin_amdgcn_ballot_w64(g.violation) != 0ull) n |= 0x80000000u;
+        if ((threadIdx.x & 63) == 0) wsum[v][threadIdx.x >> 6] = n;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < V) {
+        const uint32_t* w = wsum[threadIdx.x];
+        const uint32_t flag = (w[0] | w[1] | w[2] | w[3]) & 0x80000000u;
+        b.v[threadIdx.x].geom.block_tiles[blockIdx.x] =
+            ((w[0] & 0x7fffffffu) + (w[1] & 0x7fffffffu) + (w[2] & 0x7fffffffu) + (w[3] & 0x7fffffffu)) | flag;
+    }
+    if (b.base.shs && !b.base.colors_precomp) {  // uniform
+        const bool blk_fast = b.base.sh_vec_ok && b.base.M == 16 && (size_t)blockIdx.x * 256 + 256 <= (size_t)P &&
+                              __syncthreads_or(need_mask != 0u);
+        float shf[48];
+        if (blk_fast) sh_rows_to_lanes(b.base.shs, (size_t)blockIdx.x * 256, pool, shf);
+        if (need_mask != 0u) {
+            SHCoeffs s;
+            if (blk_fast) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) s.c[k] = make_float3(shf[3 * k], shf[3 * k + 1], shf[3 * k + 2]);
+            } else {
+                load_sh(b.base.shs, idx, b.base.D, b.base.M, b.base.sh_vec_ok, s);
+            }
+#pragma unroll 1
+            for (int v = 0; v < V; v++)
+                if ((need_mask >> v) & 1u) fwd_view_colour(batch_view_args(b, v), idx, p_orig, s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means,
                                                            const float* __restrict__ view, uint8_t* present) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -501,6 +607,285 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// ---- per-view terms of the fused per-Gaussian backward, shared by the one-view kernel and the batched one ----
+// Everything that depends on the camera: the median-depth term, computeCov2DCUDA, preprocessCUDA, the SH backward up to
+// the scalars coef[k] and the masked colour gradient (dL_dsh[k] = coef[k] * dRGB), the pose-gradient terms.  `acc` = the
+// blend backward's sums for this Gaussian in this view (zeros when it was not visible).
+__device__ __forceinline__ void bwd_view_terms(const PreprocessBwdArgs& a, const bool full, float3 m, const float (&c3)[6],
+                                               const float (&acc)[16], bool vis, uint8_t cl_in, float4 shd0, float4 shd1,
+                                               float4 shd2, float3& dmean_out, float (&dcov)[6], float (&coef)[16],
+                                               float3& dRGB, float (&pose)[12]) {
+    // light: the blend kernel's median-depth term; full: computeCov2DCUDA ASSIGNS (F/cuda_rasterizer/backward.cu:383)
+    float3 dmean = make_float3(0.f, 0.f, 0.f);
+    if (!full) {
+        // light: the blend kernel's median-depth term (L/cuda_rasterizer/backward.cu:654-664), whose pixel sum of
+        // dL/dmedian arrives in acc[10]; the per-Gaussian factors are applied here
+        const float* v = a.view;
+        const float mul3 = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
+        dmean = make_float3((v[2] - v[3] * mul3) * acc[10], (v[6] - v[7] * mul3) * acc[10], (v[10] - v[11] * mul3) * acc[10]);
+    }
+    float3 s_cam = make_float3(0.f, 0.f, 0.f);  // full: sum_ch dL_dcolor[ch] * d(rgb[ch])/d(campos.{x,y,z})
+    const bool do_map = vis && !a.map_off;
+#pragma unroll
+    for (int i = 0; i < 6; i++) dcov[i] = 0.0f;
+    if (do_map) {
+        // ---------------- computeCov2DCUDA (L/cuda_rasterizer/backward.cu:144-276)
+        const float3 dconic = make_float3(acc[6], acc[7], acc[8]);
+        Cov2D c;
+        cov2d_common(m, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.view, c);
+        const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+        const float x_grad_mul = (c.txtz < -limx || c.txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (c.tytz < -limy || c.tytz > limy) ? 0.f : 1.f;
+        const float h_x = a.focal_x, h_y = a.focal_y;
+        const M3& T = c.T; const M3& Vrk = c.Vrk; const M3& W = c.W; const float3 t = c.t;
+        const float ca = c.cov.m[0][0] + 0.3f, cb = c.cov.m[0][1], cc = c.cov.m[1][1] + 0.3f;
+        const float denom = ca * cc - cb * cb;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-cc * cc * dconic.x + 2 * cb * cc * dconic.y + (denom - ca * cc) * dconic.z);
+            dL_dc = denom2inv * (-ca * ca * dconic.z + 2 * ca * cb * dconic.y + (denom - ca * cc) * dconic.x);
+            dL_db = denom2inv * 2 * (cb * cc * dconic.x - (denom + 2 * cb * cb) * dconic.y + ca * cb * dconic.z);
+            dcov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
+            dcov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
+            dcov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
+            dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
+            dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
+            dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
+        }
+        const float dL_dT00 = 2 * (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_da +
+                              (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_db;
+        const float dL_dT01 = 2 * (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_da +
+                              (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_db;
+        const float dL_dT02 = 2 * (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_da +
+                              (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_db;
+        const float dL_dT10 = 2 * (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc +
+                              (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_db;
+        const float dL_dT11 = 2 * (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc +
+                              (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_db;
+        const float dL_dT12 = 2 * (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc +
+                              (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_db;
+        const float dL_dJ00 = W.m[0][0] * dL_dT00 + W.m[0][1] * dL_dT01 + W.m[0][2] * dL_dT02;
+        const float dL_dJ02 = W.m[2][0] * dL_dT00 + W.m[2][1] * dL_dT01 + W.m[2][2] * dL_dT02;
+        const float dL_dJ11 = W.m[1][0] * dL_dT10 + W.m[1][1] * dL_dT11 + W.m[1][2] * dL_dT12;
+        const float dL_dJ12 = W.m[2][0] * dL_dT10 + W.m[2][1] * dL_dT11 + W.m[2][2] * dL_dT12;
+        const float tz = 1.f / t.z;
+        const float tz2 = tz * tz;
+        const float tz3 = tz2 * tz;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
+        const float* v = a.view;
+        dmean.x += v[0] * dL_dtx + v[1] * dL_dty + v[2] * dL_dtz;
+        dmean.y += v[4] * dL_dtx + v[5] * dL_dty + v[6] * dL_dtz;
+        dmean.z += v[8] * dL_dtx + v[9] * dL_dty + v[10] * dL_dtz;
+        if (full) {  // depth -> mean term inside computeCov2DCUDA (F/cuda_rasterizer/backward.cu:385-386)
+            const float mul3f = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
+            dmean.x = dmean.x + acc[3] * (v[2] - v[3] * mul3f);
+            dmean.y = dmean.y + acc[3] * (v[6] - v[7] * mul3f);
+            dmean.z = dmean.z + acc[3] * (v[10] - v[11] * mul3f);
+        }
+
+        // ---------------- preprocessCUDA (L/cuda_rasterizer/backward.cu:348-416)
+        const float* pj = a.proj;
+        const float4 m_hom = xform4x4(m, pj);
+        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+        const float mul1 = (pj[0] * m.x + pj[4] * m.y + pj[8] * m.z + pj[12]) * m_w * m_w;
+        const float mul2 = (pj[1] * m.x + pj[5] * m.y + pj[9] * m.z + pj[13]) * m_w * m_w;
+        const float g2x = acc[4], g2y = acc[5];
+        float3 d1;
+        d1.x = (pj[0] * m_w - pj[3] * mul1) * g2x + (pj[1] * m_w - pj[3] * mul2) * g2y;
+        d1.y = (pj[4] * m_w - pj[7] * mul1) * g2x + (pj[5] * m_w - pj[7] * mul2) * g2y;
+        d1.z = (pj[8] * m_w - pj[11] * mul1) * g2x + (pj[9] * m_w - pj[11] * mul2) * g2y;
+        dmean.x += d1.x; dmean.y += d1.y; dmean.z += d1.z;
+        if (!full) {  // light: depth -> mean term inside preprocessCUDA (L/cuda_rasterizer/backward.cu:396-407)
+            const float mul3 = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
+            float3 d2;
+            d2.x = (v[2] - v[3] * mul3) * acc[3];
+            d2.y = (v[6] - v[7] * mul3) * acc[3];
+            d2.z = (v[10] - v[11] * mul3) * acc[3];
+            dmean.x += d2.x; dmean.y += d2.y; dmean.z += d2.z;
+        }
+    }
+    // ---------------- SH backward (L/cuda_rasterizer/backward.cu:20-139): the scalars and the masked colour gradient
+#pragma unroll
+    for (int k = 0; k < 16; k++) coef[k] = 0.0f;
+    dRGB = make_float3(0.f, 0.f, 0.f);
+    if (a.dL_dsh && a.M > 0 && do_map && a.shs) {
+        const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
+        const float3 dir_orig = m - cam;
+        const float len = sqrtf(dot3(dir_orig, dir_orig));
+        const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
+        const uint8_t cl = cl_in;
+        dRGB = make_float3(acc[0], acc[1], acc[2]);
+        dRGB.x *= (cl & 1) ? 0 : 1;
+        dRGB.y *= (cl & 2) ? 0 : 1;
+        dRGB.z *= (cl & 4) ? 0 : 1;
+        // d(colour)/d(direction): the forward evaluated it from the SH row it had in registers (geom.shd, requested
+        // with the other inputs above) -- the basis values below need the direction only, so the 192-byte rows are
+        // not read again
+        const float3 dRGBdx = make_float3(shd0.x, shd0.y, shd0.z), dRGBdy = make_float3(shd1.x, shd1.y, shd1.z),
+                     dRGBdz = make_float3(shd2.x, shd2.y, shd2.z);
+        const float x = dir.x, y = dir.y, z = dir.z;
+        coef[0] = SH_C0;
+        if (a.D > 0) {
+            coef[1] = -SH_C1 * y;
+            coef[2] = SH_C1 * z;
+            coef[3] = -SH_C1 * x;
+            if (a.D > 1) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                coef[4] = SH_C2[0] * xy;
+                coef[5] = SH_C2[1] * yz;
+                coef[6] = SH_C2[2] * (2.f * zz - xx - yy);
+                coef[7] = SH_C2[3] * xz;
+                coef[8] = SH_C2[4] * (xx - yy);
+                if (a.D > 2) {
+                    coef[9] = SH_C3[0] * y * (3.f * xx - yy);
+                    coef[10] = SH_C3[1] * xy * z;
+                    coef[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+                    coef[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                    coef[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+                    coef[14] = SH_C3[5] * z * (xx - yy);
+                    coef[15] = SH_C3[6] * x * (xx - 3.f * yy);
+                }
+            }
+        }
+        if (full) {
+            // dgc_dCampos (F/cuda_rasterizer/backward.cu:27-43,159-166; not clamp-masked) contracted with the
+            // raw colour gradient: all ComputePG's part 1 needs of this Gaussian (:990-1022, 1313-1324)
+            const float len3 = len * len * len;
+            const float i3 = 1.0f / len3, i1 = 1.0f / len;
+            const float3 o = dir_orig;
+            const float3 raw = make_float3(acc[0], acc[1], acc[2]);
+            const float3 cx = dRGBdx * (o.x * o.x * i3 - i1) + dRGBdy * (o.x * o.y * i3) + dRGBdz * (o.x * o.z * i3);
+            const float3 cy = dRGBdx * (o.x * o.y * i3) + dRGBdy * (o.y * o.y * i3 - i1) + dRGBdz * (o.y * o.z * i3);
+            const float3 cz = dRGBdx * (o.x * o.z * i3) + dRGBdy * (o.y * o.z * i3) + dRGBdz * (o.z * o.z * i3 - i1);
+            s_cam = make_float3(dot3(raw, cx), dot3(raw, cy), dot3(raw, cz));
+        }
+        const float3 dL_ddir = make_float3(dot3(dRGBdx, dRGB), dot3(dRGBdy, dRGB), dot3(dRGBdz, dRGB));
+        // dnormvdv (cuda_rasterizer/auxiliary.h:109-119)
+        {
+            const float3 vv = dir_orig, dv = dL_ddir;
+            const float sum2 = vv.x * vv.x + vv.y * vv.y + vv.z * vv.z;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            dmean.x += ((+sum2 - vv.x * vv.x) * dv.x - vv.y * vv.x * dv.y - vv.z * vv.x * dv.z) * invsum32;
+            dmean.y += (-vv.x * vv.y * dv.x + (sum2 - vv.y * vv.y) * dv.y - vv.z * vv.y * dv.z) * invsum32;
+            dmean.z += (-vv.x * vv.z * dv.x - vv.y * vv.z * dv.y + (sum2 - vv.z * vv.z) * dv.z) * invsum32;
+        }
+    }
+    // ---------------- pose gradient: sum over Gaussians of Jacobian x (sum over pixels)
+    // L/cuda_rasterizer/backward.cu:633-651 accumulates J_k(g) * {nx, ny, dL_ddepth} per pixel; J_k
+    // depends on the Gaussian only, so the pixel sums are taken first (acc[4], acc[5], acc[13]).
+    if (vis && !a.track_off) {
+        const float4 m_hom = xform4x4(m, a.proj);
+        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+        const float mm[4] = {m.x, m.y, m.z, 1.0f};
+        if (!full) {
+            const float A = acc[4], B = acc[5], Dd = acc[13];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                pose[3 * k + 0] = (m_w * a.perspec[0] * mm[k]) * A;
+                pose[3 * k + 1] = (m_w * a.perspec[5] * mm[k]) * B;
+                pose[3 * k + 2] = (m_hom.x * (-m_w * m_w) * mm[k]) * A + (m_hom.y * (-m_w * m_w) * mm[k]) * B + mm[k] * Dd;
+            }
+        } else {
+            // ComputePG (F/cuda_rasterizer/backward.cu:990-1072, 1247-1289, 1313-1324) summed per Gaussian:
+            // part 1 (colour -> campos -> view) + part 2-1 (ndc -> view, colour terms) + the depth terms of the
+            // pixels whose front-most valid Gaussian this is.
+            const float A = acc[10], B = acc[11], Dw = acc[12], Dx = acc[13], Dy = acc[14];
+            const float* v = a.view;
+            const float sc[3] = {s_cam.x, s_cam.y, s_cam.z};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float jx0 = m_w * a.perspec[0] * mm[k], jy1 = m_w * a.perspec[5] * mm[k];
+                const float jx2 = m_hom.x * (-m_w * m_w) * mm[k], jy2 = m_hom.y * (-m_w * m_w) * mm[k];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    float p1;
+                    if (k < 3) p1 = sc[k] * (-v[12 + j]);
+                    else p1 = sc[0] * (-v[j]) + sc[1] * (-v[4 + j]) + sc[2] * (-v[8 + j]);
+                    float p21, dpt;
+                    if (j == 0) { p21 = jx0 * A; dpt = jx0 * Dx; }
+                    else if (j == 1) { p21 = jy1 * B; dpt = jy1 * Dy; }
+                    else { p21 = jx2 * A + jy2 * B; dpt = mm[k] * Dw + (jx2 * Dx + jy2 * Dy); }
+                    pose[3 * k + j] = (p1 + p21) + dpt;
+                }
+            }
+        }
+    }
+    dmean_out = dmean;
+}
+
+// computeCov3D backward (L/cuda_rasterizer/backward.cu:280-343): linear in dL_dcov3D
+__device__ __forceinline__ void cov3d_backward_terms(float3 sc, float4 q, float mod, const float (&dcov)[6], float3& dscale, float4& drot) {
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    M3 R;
+    quat_to_R(q, R);
+    const float3 s = make_float3(mod * sc.x, mod * sc.y, mod * sc.z);
+    const M3 Mm = mul(diag3(s.x, s.y, s.z), R);
+    M3 dSigma;
+    dSigma.m[0][0] = dcov[0]; dSigma.m[0][1] = 0.5f * dcov[1]; dSigma.m[0][2] = 0.5f * dcov[2];
+    dSigma.m[1][0] = 0.5f * dcov[1]; dSigma.m[1][1] = dcov[3]; dSigma.m[1][2] = 0.5f * dcov[4];
+    dSigma.m[2][0] = 0.5f * dcov[2]; dSigma.m[2][1] = 0.5f * dcov[4]; dSigma.m[2][2] = dcov[5];
+    M3 M2;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) M2.m[c][rr] = Mm.m[c][rr] * 2.0f;
+    const M3 dL_dM = mul(M2, dSigma);
+    const M3 Rt = transpose(R);
+    M3 dMt = transpose(dL_dM);
+    dscale.x = dot3(make_float3(Rt.m[0][0], Rt.m[0][1], Rt.m[0][2]), make_float3(dMt.m[0][0], dMt.m[0][1], dMt.m[0][2]));
+    dscale.y = dot3(make_float3(Rt.m[1][0], Rt.m[1][1], Rt.m[1][2]), make_float3(dMt.m[1][0], dMt.m[1][1], dMt.m[1][2]));
+    dscale.z = dot3(make_float3(Rt.m[2][0], Rt.m[2][1], Rt.m[2][2]), make_float3(dMt.m[2][0], dMt.m[2][1], dMt.m[2][2]));
+#pragma unroll
+    for (int k = 0; k < 3; k++) { dMt.m[0][k] *= s.x; dMt.m[1][k] *= s.y; dMt.m[2][k] *= s.z; }
+    drot.x = 2 * z * (dMt.m[0][1] - dMt.m[1][0]) + 2 * y * (dMt.m[2][0] - dMt.m[0][2]) + 2 * x * (dMt.m[1][2] - dMt.m[2][1]);
+    drot.y = 2 * y * (dMt.m[1][0] + dMt.m[0][1]) + 2 * z * (dMt.m[2][0] + dMt.m[0][2]) + 2 * r * (dMt.m[1][2] - dMt.m[2][1]) - 4 * x * (dMt.m[2][2] + dMt.m[1][1]);
+    drot.z = 2 * x * (dMt.m[1][0] + dMt.m[0][1]) + 2 * r * (dMt.m[2][0] - dMt.m[0][2]) + 2 * z * (dMt.m[1][2] + dMt.m[2][1]) - 4 * y * (dMt.m[2][2] + dMt.m[0][0]);
+    drot.w = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
+}
+
+// Block reduction of the 12 pose terms and their delivery: wave64 butterfly, then the 4 waves through LDS.  In double: the sum
+// over 4e5 Gaussians cancels to ~1e-3 of its terms, so float partial sums would cost ~2e-5 of the result.
+// The block's partial goes into one of 64 bucket rows with double atomics performed at L2 (agent scope: no
+// cache to keep coherent), then the block takes a ticket; the block that draws the last ticket finds every
+// partial delivered and finishes the sum -- no separate reduction kernel, no fence that writes back an L2.
+__device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], double* pose_part, uint32_t* ticket, float* dL_dview,
+                                                  double (*red)[12], uint32_t* s_ticket) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        double v = (double)pose[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wv][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const double part = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        double* slot = pose_part + (size_t)(blockIdx.x % DGR_POSE_BUCKETS) * 12 + threadIdx.x;
+        __hip_atomic_fetch_add(slot, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the adds are acknowledged before the ticket is taken
+    __syncthreads();
+    if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*s_ticket != gridDim.x - 1) return;
+    if (threadIdx.x < 16) {
+        float out = 0.0f;
+        if (threadIdx.x < 12) {
+            double t = 0.0;
+            for (int g = 0; g < DGR_POSE_BUCKETS; g++)  // (agent-scope loads: served by L2, where the adds were performed)
+                t += __hip_atomic_load(pose_part + (size_t)g * 12 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out = (float)t;
+        }
+        // slot order v0,v1,v2,v4,v5,v6,v8,v9,v10,v12,v13,v14 (L/cuda_rasterizer/backward.cu:723)
+        if (threadIdx.x < 12) dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
+        if (threadIdx.x < 4) dL_dview[threadIdx.x * 4 + 3] = 0.0f;
+    }
+}
+
 // Fused per-Gaussian backward.  Order of the dL_dmean3D accumulation follows the reference's kernel
 // order: blend-kernel median term, computeCov2DCUDA, preprocessCUDA (2D mean, depth, SH).
 // (forcing more than 4 waves/SIMD spills: 5 -> 128 us, 6 -> 163 us against 87 us)
@@ -587,175 +972,22 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
             *o = make_float4(acc[6], acc[7], 0.0f, acc[8]);
         }
 
-        const bool full = a.full_variant != 0;
-        // light: the blend kernel's median-depth term; full: computeCov2DCUDA ASSIGNS (F/cuda_rasterizer/backward.cu:383)
-        float3 dmean = make_float3(0.f, 0.f, 0.f);
-        if (!full) {
-            // light: the blend kernel's median-depth term (L/cuda_rasterizer/backward.cu:654-664), whose pixel sum of
-            // dL/dmedian arrives in acc[10]; the per-Gaussian factors are applied here
-            const float* v = a.view;
-            const float mul3 = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
-            dmean = make_float3((v[2] - v[3] * mul3) * acc[10], (v[6] - v[7] * mul3) * acc[10], (v[10] - v[11] * mul3) * acc[10]);
-        }
-        float3 s_cam = make_float3(0.f, 0.f, 0.f);  // full: sum_ch dL_dcolor[ch] * d(rgb[ch])/d(campos.{x,y,z})
-        float dcov[6] = {0, 0, 0, 0, 0, 0};
+        float3 dmean;
+        float dcov[6], coef[16];
+        float3 dRGB;
+        bwd_view_terms(a, a.full_variant != 0, m, c3, acc, vis, cl_in, shd0, shd1, shd2, dmean, dcov, coef, dRGB, pose);
         float3 dscale = make_float3(0, 0, 0);
         float4 drot = make_float4(0, 0, 0, 0);
         const bool do_map = vis && !a.map_off;
         const int ncoef_out = a.M;
 
-        if (do_map) {
-            // ---------------- computeCov2DCUDA (L/cuda_rasterizer/backward.cu:144-276)
-            const float3 dconic = make_float3(acc[6], acc[7], acc[8]);
-            Cov2D c;
-            cov2d_common(m, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.view, c);
-            const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
-            const float x_grad_mul = (c.txtz < -limx || c.txtz > limx) ? 0.f : 1.f;
-            const float y_grad_mul = (c.tytz < -limy || c.tytz > limy) ? 0.f : 1.f;
-            const float h_x = a.focal_x, h_y = a.focal_y;
-            const M3& T = c.T; const M3& Vrk = c.Vrk; const M3& W = c.W; const float3 t = c.t;
-            const float ca = c.cov.m[0][0] + 0.3f, cb = c.cov.m[0][1], cc = c.cov.m[1][1] + 0.3f;
-            const float denom = ca * cc - cb * cb;
-            float dL_da = 0, dL_db = 0, dL_dc = 0;
-            const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-            if (denom2inv != 0) {
-                dL_da = denom2inv * (-cc * cc * dconic.x + 2 * cb * cc * dconic.y + (denom - ca * cc) * dconic.z);
-                dL_dc = denom2inv * (-ca * ca * dconic.z + 2 * ca * cb * dconic.y + (denom - ca * cc) * dconic.x);
-                dL_db = denom2inv * 2 * (cb * cc * dconic.x - (denom + 2 * cb * cb) * dconic.y + ca * cb * dconic.z);
-                dcov[0] = (T.m[0][0] * T.m[0][0] * dL_da + T.m[0][0] * T.m[1][0] * dL_db + T.m[1][0] * T.m[1][0] * dL_dc);
-                dcov[3] = (T.m[0][1] * T.m[0][1] * dL_da + T.m[0][1] * T.m[1][1] * dL_db + T.m[1][1] * T.m[1][1] * dL_dc);
-                dcov[5] = (T.m[0][2] * T.m[0][2] * dL_da + T.m[0][2] * T.m[1][2] * dL_db + T.m[1][2] * T.m[1][2] * dL_dc);
-                dcov[1] = 2 * T.m[0][0] * T.m[0][1] * dL_da + (T.m[0][0] * T.m[1][1] + T.m[0][1] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][1] * dL_dc;
-                dcov[2] = 2 * T.m[0][0] * T.m[0][2] * dL_da + (T.m[0][0] * T.m[1][2] + T.m[0][2] * T.m[1][0]) * dL_db + 2 * T.m[1][0] * T.m[1][2] * dL_dc;
-                dcov[4] = 2 * T.m[0][2] * T.m[0][1] * dL_da + (T.m[0][1] * T.m[1][2] + T.m[0][2] * T.m[1][1]) * dL_db + 2 * T.m[1][1] * T.m[1][2] * dL_dc;
-            }
-            const float dL_dT00 = 2 * (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_da +
-                                  (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_db;
-            const float dL_dT01 = 2 * (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_da +
-                                  (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_db;
-            const float dL_dT02 = 2 * (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_da +
-                                  (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_db;
-            const float dL_dT10 = 2 * (T.m[1][0] * Vrk.m[0][0] + T.m[1][1] * Vrk.m[0][1] + T.m[1][2] * Vrk.m[0][2]) * dL_dc +
-                                  (T.m[0][0] * Vrk.m[0][0] + T.m[0][1] * Vrk.m[0][1] + T.m[0][2] * Vrk.m[0][2]) * dL_db;
-            const float dL_dT11 = 2 * (T.m[1][0] * Vrk.m[1][0] + T.m[1][1] * Vrk.m[1][1] + T.m[1][2] * Vrk.m[1][2]) * dL_dc +
-                                  (T.m[0][0] * Vrk.m[1][0] + T.m[0][1] * Vrk.m[1][1] + T.m[0][2] * Vrk.m[1][2]) * dL_db;
-            const float dL_dT12 = 2 * (T.m[1][0] * Vrk.m[2][0] + T.m[1][1] * Vrk.m[2][1] + T.m[1][2] * Vrk.m[2][2]) * dL_dc +
-                                  (T.m[0][0] * Vrk.m[2][0] + T.m[0][1] * Vrk.m[2][1] + T.m[0][2] * Vrk.m[2][2]) * dL_db;
-            const float dL_dJ00 = W.m[0][0] * dL_dT00 + W.m[0][1] * dL_dT01 + W.m[0][2] * dL_dT02;
-            const float dL_dJ02 = W.m[2][0] * dL_dT00 + W.m[2][1] * dL_dT01 + W.m[2][2] * dL_dT02;
-            const float dL_dJ11 = W.m[1][0] * dL_dT10 + W.m[1][1] * dL_dT11 + W.m[1][2] * dL_dT12;
-            const float dL_dJ12 = W.m[2][0] * dL_dT10 + W.m[2][1] * dL_dT11 + W.m[2][2] * dL_dT12;
-            const float tz = 1.f / t.z;
-            const float tz2 = tz * tz;
-            const float tz3 = tz2 * tz;
-            const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
-            const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
-            const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 + (2 * h_y * t.y) * tz3 * dL_dJ12;
-            const float* v = a.view;
-            dmean.x += v[0] * dL_dtx + v[1] * dL_dty + v[2] * dL_dtz;
-            dmean.y += v[4] * dL_dtx + v[5] * dL_dty + v[6] * dL_dtz;
-            dmean.z += v[8] * dL_dtx + v[9] * dL_dty + v[10] * dL_dtz;
-            if (full) {  // depth -> mean term inside computeCov2DCUDA (F/cuda_rasterizer/backward.cu:385-386)
-                const float mul3f = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
-                dmean.x = dmean.x + acc[3] * (v[2] - v[3] * mul3f);
-                dmean.y = dmean.y + acc[3] * (v[6] - v[7] * mul3f);
-                dmean.z = dmean.z + acc[3] * (v[10] - v[11] * mul3f);
-            }
-
-            // ---------------- preprocessCUDA (L/cuda_rasterizer/backward.cu:348-416)
-            const float* pj = a.proj;
-            const float4 m_hom = xform4x4(m, pj);
-            const float m_w = 1.0f / (m_hom.w + 0.0000001f);
-            const float mul1 = (pj[0] * m.x + pj[4] * m.y + pj[8] * m.z + pj[12]) * m_w * m_w;
-            const float mul2 = (pj[1] * m.x + pj[5] * m.y + pj[9] * m.z + pj[13]) * m_w * m_w;
-            const float g2x = acc[4], g2y = acc[5];
-            float3 d1;
-            d1.x = (pj[0] * m_w - pj[3] * mul1) * g2x + (pj[1] * m_w - pj[3] * mul2) * g2y;
-            d1.y = (pj[4] * m_w - pj[7] * mul1) * g2x + (pj[5] * m_w - pj[7] * mul2) * g2y;
-            d1.z = (pj[8] * m_w - pj[11] * mul1) * g2x + (pj[9] * m_w - pj[11] * mul2) * g2y;
-            dmean.x += d1.x; dmean.y += d1.y; dmean.z += d1.z;
-            if (!full) {  // light: depth -> mean term inside preprocessCUDA (L/cuda_rasterizer/backward.cu:396-407)
-                const float mul3 = v[2] * m.x + v[6] * m.y + v[10] * m.z + v[14];
-                float3 d2;
-                d2.x = (v[2] - v[3] * mul3) * acc[3];
-                d2.y = (v[6] - v[7] * mul3) * acc[3];
-                d2.z = (v[10] - v[11] * mul3) * acc[3];
-                dmean.x += d2.x; dmean.y += d2.y; dmean.z += d2.z;
-            }
-        }
-
-        // ---------------- SH backward (L/cuda_rasterizer/backward.cu:20-139); writes the dense dL_dsh row
+        // ---------------- the dense dL_dsh row: dL_dsh[k] = coef[k] * dRGB (zeros for rows this view did not map)
         if (a.dL_dsh && ncoef_out > 0) {
             float3* out = reinterpret_cast<float3*>(a.dL_dsh) + (size_t)idx * ncoef_out;
             // whole block in range, 16 coefficients, 16-byte aligned rows: SH rows move through LDS (block-uniform)
             __shared__ float sht[4 * SHT_ROWS * SHT_LD];
             const bool blk_fast = a.sh_vec_ok && ncoef_out == 16 && a.shs != nullptr && (size_t)blockIdx.x * 256 + 256 <= (size_t)a.P;
-            // dL_dsh[k] = coef[k] * dRGB (backward.cu:46-133): the scalars, not the 48 products, stay in registers
-            float coef[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) coef[k] = 0.0f;
-            float3 dRGB = make_float3(0.f, 0.f, 0.f);
             if (do_map && a.shs) {
-                const float3 cam = make_float3(a.campos[0], a.campos[1], a.campos[2]);
-                const float3 dir_orig = m - cam;
-                const float len = sqrtf(dot3(dir_orig, dir_orig));
-                const float3 dir = make_float3(dir_orig.x / len, dir_orig.y / len, dir_orig.z / len);
-                const uint8_t cl = cl_in;
-                dRGB = make_float3(acc[0], acc[1], acc[2]);
-                dRGB.x *= (cl & 1) ? 0 : 1;
-                dRGB.y *= (cl & 2) ? 0 : 1;
-                dRGB.z *= (cl & 4) ? 0 : 1;
-                // d(colour)/d(direction): the forward evaluated it from the SH row it had in registers (geom.shd, requested
-                // with the other inputs above) -- the basis values below need the direction only, so the 192-byte rows are
-                // not read again
-                const float3 dRGBdx = make_float3(shd0.x, shd0.y, shd0.z), dRGBdy = make_float3(shd1.x, shd1.y, shd1.z),
-                             dRGBdz = make_float3(shd2.x, shd2.y, shd2.z);
-                const float x = dir.x, y = dir.y, z = dir.z;
-                coef[0] = SH_C0;
-                if (a.D > 0) {
-                    coef[1] = -SH_C1 * y;
-                    coef[2] = SH_C1 * z;
-                    coef[3] = -SH_C1 * x;
-                    if (a.D > 1) {
-                        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-                        coef[4] = SH_C2[0] * xy;
-                        coef[5] = SH_C2[1] * yz;
-                        coef[6] = SH_C2[2] * (2.f * zz - xx - yy);
-                        coef[7] = SH_C2[3] * xz;
-                        coef[8] = SH_C2[4] * (xx - yy);
-                        if (a.D > 2) {
-                            coef[9] = SH_C3[0] * y * (3.f * xx - yy);
-                            coef[10] = SH_C3[1] * xy * z;
-                            coef[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
-                            coef[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-                            coef[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
-                            coef[14] = SH_C3[5] * z * (xx - yy);
-                            coef[15] = SH_C3[6] * x * (xx - 3.f * yy);
-                        }
-                    }
-                }
-                if (full) {
-                    // dgc_dCampos (F/cuda_rasterizer/backward.cu:27-43,159-166; not clamp-masked) contracted with the
-                    // raw colour gradient: all ComputePG's part 1 needs of this Gaussian (:990-1022, 1313-1324)
-                    const float len3 = len * len * len;
-                    const float i3 = 1.0f / len3, i1 = 1.0f / len;
-                    const float3 o = dir_orig;
-                    const float3 raw = make_float3(acc[0], acc[1], acc[2]);
-                    const float3 cx = dRGBdx * (o.x * o.x * i3 - i1) + dRGBdy * (o.x * o.y * i3) + dRGBdz * (o.x * o.z * i3);
-                    const float3 cy = dRGBdx * (o.x * o.y * i3) + dRGBdy * (o.y * o.y * i3 - i1) + dRGBdz * (o.y * o.z * i3);
-                    const float3 cz = dRGBdx * (o.x * o.z * i3) + dRGBdy * (o.y * o.z * i3) + dRGBdz * (o.z * o.z * i3 - i1);
-                    s_cam = make_float3(dot3(raw, cx), dot3(raw, cy), dot3(raw, cz));
-                }
-                const float3 dL_ddir = make_float3(dot3(dRGBdx, dRGB), dot3(dRGBdy, dRGB), dot3(dRGBdz, dRGB));
-                // dnormvdv (cuda_rasterizer/auxiliary.h:109-119)
-                {
-                    const float3 vv = dir_orig, dv = dL_ddir;
-                    const float sum2 = vv.x * vv.x + vv.y * vv.y + vv.z * vv.z;
-                    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-                    dmean.x += ((+sum2 - vv.x * vv.x) * dv.x - vv.y * vv.x * dv.y - vv.z * vv.x * dv.z) * invsum32;
-                    dmean.y += (-vv.x * vv.y * dv.x + (sum2 - vv.y * vv.y) * dv.y - vv.z * vv.y * dv.z) * invsum32;
-                    dmean.z += (-vv.x * vv.z * dv.x - vv.y * vv.z * dv.y + (sum2 - vv.z * vv.z) * dv.z) * invsum32;
-                }
                 if (blk_fast) {
                     // (written below, through LDS)
                 } else if (a.sh_vec_ok && ncoef_out == 16) {
@@ -782,37 +1014,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
             if (blk_fast) lanes_to_sh_rows_scaled(coef, dRGB, a.dL_dsh, (size_t)blockIdx.x * 256, sht);
         }
 
-        // ---------------- computeCov3D backward (L/cuda_rasterizer/backward.cu:280-343)
-        if (do_map && a.scales) {
-            const float3 sc = sc_in;
-            const float4 q = q_in;
-            const float r = q.x, x = q.y, y = q.z, z = q.w;
-            M3 R;
-            quat_to_R(q, R);
-            const float3 s = make_float3(a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z);
-            const M3 Mm = mul(diag3(s.x, s.y, s.z), R);
-            M3 dSigma;
-            dSigma.m[0][0] = dcov[0]; dSigma.m[0][1] = 0.5f * dcov[1]; dSigma.m[0][2] = 0.5f * dcov[2];
-            dSigma.m[1][0] = 0.5f * dcov[1]; dSigma.m[1][1] = dcov[3]; dSigma.m[1][2] = 0.5f * dcov[4];
-            dSigma.m[2][0] = 0.5f * dcov[2]; dSigma.m[2][1] = 0.5f * dcov[4]; dSigma.m[2][2] = dcov[5];
-            M3 M2;
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-#pragma unroll
-                for (int rr = 0; rr < 3; rr++) M2.m[c][rr] = Mm.m[c][rr] * 2.0f;
-            const M3 dL_dM = mul(M2, dSigma);
-            const M3 Rt = transpose(R);
-            M3 dMt = transpose(dL_dM);
-            dscale.x = dot3(make_float3(Rt.m[0][0], Rt.m[0][1], Rt.m[0][2]), make_float3(dMt.m[0][0], dMt.m[0][1], dMt.m[0][2]));
-            dscale.y = dot3(make_float3(Rt.m[1][0], Rt.m[1][1], Rt.m[1][2]), make_float3(dMt.m[1][0], dMt.m[1][1], dMt.m[1][2]));
-            dscale.z = dot3(make_float3(Rt.m[2][0], Rt.m[2][1], Rt.m[2][2]), make_float3(dMt.m[2][0], dMt.m[2][1], dMt.m[2][2]));
-#pragma unroll
-            for (int k = 0; k < 3; k++) { dMt.m[0][k] *= s.x; dMt.m[1][k] *= s.y; dMt.m[2][k] *= s.z; }
-            drot.x = 2 * z * (dMt.m[0][1] - dMt.m[1][0]) + 2 * y * (dMt.m[2][0] - dMt.m[0][2]) + 2 * x * (dMt.m[1][2] - dMt.m[2][1]);
-            drot.y = 2 * y * (dMt.m[1][0] + dMt.m[0][1]) + 2 * z * (dMt.m[2][0] + dMt.m[0][2]) + 2 * r * (dMt.m[1][2] - dMt.m[2][1]) - 4 * x * (dMt.m[2][2] + dMt.m[1][1]);
-            drot.z = 2 * x * (dMt.m[1][0] + dMt.m[0][1]) + 2 * r * (dMt.m[2][0] - dMt.m[0][2]) + 2 * z * (dMt.m[1][2] + dMt.m[2][1]) - 4 * y * (dMt.m[2][2] + dMt.m[0][0]);
-            drot.w = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
-        }
+        if (do_map && a.scales) cov3d_backward_terms(sc_in, q_in, a.scale_modifier, dcov, dscale, drot);
 
         if (a.dL_dmean3D) {
             a.dL_dmean3D[3 * (size_t)idx + 0] = dmean.x;
@@ -829,91 +1031,147 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
             a.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
         }
         if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
-
-        // ---------------- pose gradient: sum over Gaussians of Jacobian x (sum over pixels)
-        // L/cuda_rasterizer/backward.cu:633-651 accumulates J_k(g) * {nx, ny, dL_ddepth} per pixel; J_k
-        // depends on the Gaussian only, so the pixel sums are taken first (acc[4], acc[5], acc[13]).
-        if (vis && !a.track_off) {
-            const float4 m_hom = xform4x4(m, a.proj);
-            const float m_w = 1.0f / (m_hom.w + 0.0000001f);
-            const float mm[4] = {m.x, m.y, m.z, 1.0f};
-            if (!full) {
-                const float A = acc[4], B = acc[5], Dd = acc[13];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    pose[3 * k + 0] = (m_w * a.perspec[0] * mm[k]) * A;
-                    pose[3 * k + 1] = (m_w * a.perspec[5] * mm[k]) * B;
-                    pose[3 * k + 2] = (m_hom.x * (-m_w * m_w) * mm[k]) * A + (m_hom.y * (-m_w * m_w) * mm[k]) * B + mm[k] * Dd;
-                }
-            } else {
-                // ComputePG (F/cuda_rasterizer/backward.cu:990-1072, 1247-1289, 1313-1324) summed per Gaussian:
-                // part 1 (colour -> campos -> view) + part 2-1 (ndc -> view, colour terms) + the depth terms of the
-                // pixels whose front-most valid Gaussian this is.
-                const float A = acc[10], B = acc[11], Dw = acc[12], Dx = acc[13], Dy = acc[14];
-                const float* v = a.view;
-                const float sc[3] = {s_cam.x, s_cam.y, s_cam.z};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const float jx0 = m_w * a.perspec[0] * mm[k], jy1 = m_w * a.perspec[5] * mm[k];
-                    const float jx2 = m_hom.x * (-m_w * m_w) * mm[k], jy2 = m_hom.y * (-m_w * m_w) * mm[k];
-#pragma unroll
-                    for (int j = 0; j < 3; j++) {
-                        float p1;
-                        if (k < 3) p1 = sc[k] * (-v[12 + j]);
-                        else p1 = sc[0] * (-v[j]) + sc[1] * (-v[4 + j]) + sc[2] * (-v[8 + j]);
-                        float p21, dpt;
-                        if (j == 0) { p21 = jx0 * A; dpt = jx0 * Dx; }
-                        else if (j == 1) { p21 = jy1 * B; dpt = jy1 * Dy; }
-                        else { p21 = jx2 * A + jy2 * B; dpt = mm[k] * Dw + (jx2 * Dx + jy2 * Dy); }
-                        pose[3 * k + j] = (p1 + p21) + dpt;
-                    }
-                }
-            }
-        }
     }
 
     if (a.track_off) {  // no pose gradient asked for: zeros (L/rasterize_points.cu:186)
         if (blockIdx.x == 0 && threadIdx.x < 16) a.dL_dview[threadIdx.x] = 0.0f;
         return;
     }
-    // block reduction of the 12 pose terms: wave64 butterfly, then the 4 waves through LDS.  In double: the sum
-    // over 4e5 Gaussians cancels to ~1e-3 of its terms, so float partial sums would cost ~2e-5 of the result.
     __shared__ double red[4][12];
     __shared__ uint32_t s_ticket;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red, &s_ticket);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched per-Gaussian backward: the V views of a batch in ONE launch, the gradients of the shared
+// Gaussians SUMMED OVER THE VIEWS in registers and written once.  Per view a lane reads that view's 64-byte accumulator row,
+// radius, clamp bits and SH direction derivatives and runs the code of the one-view kernel (bwd_view_terms); position,
+// covariance, scale and rotation are read once; the covariance backward -- linear in dL_dcov3D -- runs once on the summed
+// dL_dcov3D.  A view's terms are formed exactly as the one-view kernel forms them and added in view order with FMA
+// contraction off, so dL_dmeans3D / dL_dsh / dL_dopacity / dL_dcov3D equal, bit for bit, what accumulating the one-view
+// outputs view after view (autograd's `.grad +=`) gives -- without the V dense 248-byte rows per Gaussian that costs.
+// Pose gradients and dL_dmean2D (densification statistics) stay per view.  Light variant only.
+__device__ __forceinline__ PreprocessBwdArgs batch_view_args(const PreprocessBwdBatchArgs& b, int v) {
+    PreprocessBwdArgs a = b.base;
+    const BwdViewPart& p = b.v[v];
+    a.view = p.view; a.proj = p.proj; a.campos = p.campos; a.perspec = p.perspec; a.radii = p.radii; a.geom = p.geom;
+    a.acc = p.acc; a.dL_dmean2D = p.dL_dmean2D; a.pose_part = p.pose_part; a.ticket = p.ticket; a.dL_dview = p.dL_dview;
+    return a;
+}
+__global__ void __launch_bounds__(256, DGR_BWD_BATCH_WAVES) preprocess_bwd_batch_kernel(PreprocessBwdBatchArgs b) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int P = b.base.P, V = b.V;
+    const bool in = idx < P;
+    __shared__ float sht[4 * SHT_ROWS * SHT_LD];
+    __shared__ double red[4][12];
+    __shared__ uint32_t s_ticket;
+    float3 m = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
+    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    float c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (in) {
+        m = make_float3(b.base.means3D[3 * idx], b.base.means3D[3 * idx + 1], b.base.means3D[3 * idx + 2]);
+        if (b.base.cov3D_precomp) {
+            const float* c3p = b.base.cov3D_precomp + 6 * (size_t)idx;
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
-        double v = (double)pose[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) red[wv][i] = v;
-    }
-    __syncthreads();
-    // The block's partial goes into one of 64 bucket rows with double atomics performed at L2 (agent scope: no
-    // cache to keep coherent), then the block takes a ticket; the block that draws the last ticket finds every
-    // partial delivered and finishes the sum -- no separate reduction kernel, no fence that writes back an L2.
-    if (threadIdx.x < 12) {
-        const double part = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-        double* slot = a.pose_part + (size_t)(blockIdx.x % DGR_POSE_BUCKETS) * 12 + threadIdx.x;
-        __hip_atomic_fetch_add(slot, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the adds are acknowledged before the ticket is taken
-    __syncthreads();
-    if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
-    if (threadIdx.x < 16) {
-        float out = 0.0f;
-        if (threadIdx.x < 12) {
-            double t = 0.0;
-            for (int g = 0; g < DGR_POSE_BUCKETS; g++)  // (agent-scope loads: served by L2, where the adds were performed)
-                t += __hip_atomic_load(a.pose_part + (size_t)g * 12 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out = (float)t;
+            for (int i = 0; i < 6; i++) c3[i] = c3p[i];
+        } else if (b.base.scales) {
+            // the forward's value, re-formed from scale and rotation (same expression, same bits) instead of read back:
+            // a view that culled the Gaussian never stored it
+            compute_cov3d(b.base.scales, b.base.rotations, b.base.scale_modifier, idx, c3);
         }
-        // slot order v0,v1,v2,v4,v5,v6,v8,v9,v10,v12,v13,v14 (L/cuda_rasterizer/backward.cu:723)
-        if (threadIdx.x < 12) a.dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
-        if (threadIdx.x < 4) a.dL_dview[threadIdx.x * 4 + 3] = 0.0f;
+        if (b.base.scales) {
+            sc_in = make_float3(b.base.scales[3 * idx], b.base.scales[3 * idx + 1], b.base.scales[3 * idx + 2]);
+            q_in = make_float4(b.base.rotations[4 * idx], b.base.rotations[4 * idx + 1], b.base.rotations[4 * idx + 2],
+                               b.base.rotations[4 * idx + 3]);
+        }
     }
+    float3 dmean_s = make_float3(0.f, 0.f, 0.f), dcol_s = make_float3(0.f, 0.f, 0.f);
+    float dcov_s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dop_s = 0.0f;
+    float dsh[48];
+#pragma unroll
+    for (int e = 0; e < 48; e++) dsh[e] = 0.0f;
+    bool any_map = false;
+#pragma unroll 1
+    for (int v = 0; v < V; v++) {
+        const PreprocessBwdArgs a = batch_view_args(b, v);
+        float pose[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) pose[i] = 0.0f;
+        if (in) {
+            const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)idx * DGR_ACC_STRIDE);
+            const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+            const int rad = a.radii[idx];
+            const uint8_t cl_in = a.geom.clamped[idx];
+            const float4 shd0 = a.geom.shd[idx], shd1 = a.geom.shd[(size_t)P + idx], shd2 = a.geom.shd[2 * (size_t)P + idx];
+            const bool vis = rad > 0;
+            float acc[16];
+            if (vis) {
+                acc[0] = a0.x; acc[1] = a0.y; acc[2] = a0.z; acc[3] = a0.w; acc[4] = a1.x; acc[5] = a1.y; acc[6] = a1.z; acc[7] = a1.w;
+                acc[8] = a2.x; acc[9] = a2.y; acc[10] = a2.z; acc[11] = a2.w; acc[12] = a3.x; acc[13] = a3.y; acc[14] = a3.z; acc[15] = a3.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+            }
+            if (a.dL_dmean2D) {
+                a.dL_dmean2D[3 * (size_t)idx + 0] = a.map_off ? 0.0f : acc[4];
+                a.dL_dmean2D[3 * (size_t)idx + 1] = a.map_off ? 0.0f : acc[5];
+                a.dL_dmean2D[3 * (size_t)idx + 2] = 0.0f;
+            }
+            float3 dmean, dRGB;
+            float dcov[6], coef[16];
+            bwd_view_terms(a, false, m, c3, acc, vis, cl_in, shd0, shd1, shd2, dmean, dcov, coef, dRGB, pose);
+            any_map |= vis && !a.map_off;
+            dop_s += acc[9];
+            dcol_s.x += acc[0]; dcol_s.y += acc[1]; dcol_s.z += acc[2];
+            dmean_s.x += dmean.x; dmean_s.y += dmean.y; dmean_s.z += dmean.z;
+#pragma unroll
+            for (int i = 0; i < 6; i++) dcov_s[i] += dcov[i];
+            const float ch[3] = {dRGB.x, dRGB.y, dRGB.z};
+#pragma unroll
+            for (int e = 0; e < 48; e++) dsh[e] += coef[e / 3] * ch[e % 3];  // (contraction is off: product, then sum)
+        }
+        if (a.track_off) {
+            if (blockIdx.x == 0 && threadIdx.x < 16) a.dL_dview[threadIdx.x] = 0.0f;
+        } else {
+            pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red, &s_ticket);
+        }
+    }
+    const int M = b.base.M;
+    const bool blk_fast = b.base.dL_dsh && b.base.sh_vec_ok && M == 16 && (size_t)blockIdx.x * 256 + 256 <= (size_t)P;
+    if (in) {
+        float3 dscale = make_float3(0, 0, 0);
+        float4 drot = make_float4(0, 0, 0, 0);
+        if (any_map && b.base.scales) cov3d_backward_terms(sc_in, q_in, b.base.scale_modifier, dcov_s, dscale, drot);
+        if (b.base.dL_dopacity) b.base.dL_dopacity[idx] = dop_s;
+        if (b.base.dL_dcolor) {
+            b.base.dL_dcolor[3 * (size_t)idx + 0] = dcol_s.x;
+            b.base.dL_dcolor[3 * (size_t)idx + 1] = dcol_s.y;
+            b.base.dL_dcolor[3 * (size_t)idx + 2] = dcol_s.z;
+        }
+        if (b.base.dL_dmean3D) {
+            b.base.dL_dmean3D[3 * (size_t)idx + 0] = dmean_s.x;
+            b.base.dL_dmean3D[3 * (size_t)idx + 1] = dmean_s.y;
+            b.base.dL_dmean3D[3 * (size_t)idx + 2] = dmean_s.z;
+        }
+        if (b.base.dL_dcov3D) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) b.base.dL_dcov3D[6 * (size_t)idx + i] = dcov_s[i];
+        }
+        if (b.base.dL_dscale) {
+            b.base.dL_dscale[3 * (size_t)idx + 0] = dscale.x;
+            b.base.dL_dscale[3 * (size_t)idx + 1] = dscale.y;
+            b.base.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
+        }
+        if (b.base.dL_drot) reinterpret_cast<float4*>(b.base.dL_drot)[idx] = drot;
+        if (b.base.dL_dsh && M > 0 && !blk_fast) {
+            float* out = b.base.dL_dsh + (size_t)idx * M * 3;
+#pragma unroll
+            for (int e = 0; e < 48; e++)
+                if (e < 3 * M) out[e] = dsh[e];
+        }
+    }
+    if (blk_fast) lanes_to_sh_rows(dsh, b.base.dL_dsh, (size_t)blockIdx.x * 256, sht);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1012,10 +1270,20 @@ hipError_t launch_preprocess_fwd(const PreprocessFwdArgs& a, hipStream_t stream)
     launch(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), stream, a);
     return hipGetLastError();
 }
+hipError_t launch_preprocess_fwd_batch(const PreprocessFwdBatchArgs& b, hipStream_t stream) {
+    if (b.base.P <= 0 || b.V <= 0) return hipSuccess;
+    launch(preprocess_fwd_batch_kernel, dim3((b.base.P + 255) / 256), dim3(256), stream, b);
+    return hipGetLastError();
+}
 hipError_t launch_preprocess_bwd(const PreprocessBwdArgs& a, hipStream_t stream) {
     const int blocks = (a.P + 255) / 256;
     if (blocks <= 0) return hipSuccess;
     launch(preprocess_bwd_kernel, dim3(blocks), dim3(256), stream, a);
+    return hipGetLastError();
+}
+hipError_t launch_preprocess_bwd_batch(const PreprocessBwdBatchArgs& b, hipStream_t stream) {
+    if (b.base.P <= 0 || b.V <= 0) return hipSuccess;
+    launch(preprocess_bwd_batch_kernel, dim3((b.base.P + 255) / 256), dim3(256), stream, b);
     return hipGetLastError();
 }
 hipError_t launch_mark_visible(int P, const float* means, const float* view, uint8_t* present, hipStream_t stream) {

@@ -24,8 +24,31 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
+
+
+class LightView(C.Structure):  # dgr_light_view (include/dgr_hip.h): the per-camera arguments of a batched forward
+    _fields_ = [("geometry_buffer", _vp), ("binning_buffer", _vp), ("binning_capacity", _i), ("image_buffer", _vp),
+                ("status", _vp), ("viewmatrix", _vp), ("projmatrix", _vp), ("cam_pos", _vp), ("out_color", _vp),
+                ("out_depth", _vp), ("out_median_depth", _vp), ("out_alpha", _vp), ("gt_depth", _vp),
+                ("out_depth_var", _vp), ("gau_uncertainty", _vp), ("gau_related_pixels", _vp), ("radii", _vp)]
+
+
+class LightViewGrad(C.Structure):  # dgr_light_view_grad: the per-camera arguments of a batched backward
+    _fields_ = [("geometry_buffer", _vp), ("binning_buffer", _vp), ("image_buffer", _vp), ("viewmatrix", _vp),
+                ("projmatrix", _vp), ("cam_pos", _vp), ("perspec_matrix", _vp), ("alphas", _vp), ("gt_depth", _vp),
+                ("radii", _vp), ("dL_dpix", _vp), ("dL_dpix_depth", _vp), ("dL_dpix_median_depth", _vp),
+                ("dL_dpix_depth_var", _vp), ("dL_dmean2D", _vp), ("dL_dview", _vp), ("scratch", _vp),
+                ("scratch_bytes", _sz)]
+
+
+MAX_BATCH_VIEWS = 8  # DGR_MAX_BATCH_VIEWS
+
 # argument lists follow include/dgr_hip.h one to one
 _SIGS = {
+    "dgr_light_forward_batch": (_i, [_vp, _i, C.POINTER(LightView), _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp,
+                                     _vp, _f, _f, _i]),
+    "dgr_light_backward_batch": (_i, [_vp, _i, C.POINTER(LightViewGrad), _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _f, _vp,
+                                      _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     "dgr_last_error": (C.c_char_p, []),
     "dgr_status_post": (C.c_long, [_vp, _vp]),
     "dgr_status_poll": (_i, [C.c_long, _i, _vp]),

@@ -235,7 +235,8 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
  *     views' kernels when several views are in flight, and the measured break-even lies between 1.65 M and 6.6 M instances;
  *     2 = LDS whenever the histogram fits; 0 = never.  Results are identical bit for bit.  dgr_binning_bytes() includes the
  *     LDS count's forward-only workspace.
- *  "profile_every": n >= 1 = dgr_profile_* brackets every n-th launch of the selected stage only (default 1). */
+ *  "profile_every": n >= 1 = dgr_profile_* brackets every n-th launch of the selected stage only (default 1).
+ *  "batch_streams" (default 3): streams the batched entry points spread the per-view stages of a batch over (1..3). */
 int dgr_set_option(const char* name, int value);
 int dgr_get_option(const char* name);
 
@@ -247,6 +248,76 @@ int dgr_get_option(const char* name);
 int dgr_cov3d_forward(void* stream, int P, const float* scales, const float* rotations, float scale_modifier, float* cov3D);
 int dgr_cov3d_backward(void* stream, int P, const float* scales, const float* rotations, float scale_modifier,
                        const float* dL_dcov3D, float* dL_dscales, float* dL_drotations);
+
+/* ---- batched multi-view entry points (BASELINE configs 4 and 5: several cameras over ONE set of Gaussians) ----
+ * The reference renders a keyframe batch as V independent Rasterizer::forward / backward calls (L/cr/rasterizer.h:40-104) and
+ * lets autograd add the V dense gradient sets.  Here one call takes the V cameras; per view it does exactly what
+ * dgr_light_forward_presized / dgr_light_backward do (every view's outputs and state buffers are bit-identical to a one-view
+ * call, and usable by one), but the work that does not depend on the camera is shared:
+ *  - forward: ONE per-Gaussian launch for all views -- position, opacity, 3D covariance formed once, the 192-byte SH row
+ *    fetched once and evaluated for every camera that sees the Gaussian;
+ *  - backward: ONE per-Gaussian launch that sums the views' gradients of the shared Gaussians in registers and writes each
+ *    dense row (248 bytes per Gaussian at SH degree 3) once instead of V times plus V - 1 accumulation passes; the covariance
+ *    backward (linear in dL_dcov3D) runs once on the sum.  dL_dopacity / dL_dmean3D / dL_dsh / dL_dcov3D equal, bit for bit,
+ *    the one-view outputs accumulated in view order; dL_dscale / dL_drot agree to rounding (converted once, not V times);
+ *  - the per-view stages in between (binning and blend) are issued on up to three internal streams forked from and joined
+ *    to `stream` with events (option "batch_streams", 1..3, default 3), so that they overlap as independent views do;
+ *  - no host synchronisation (hipGraph-capturable after one warm-up call, which creates the internal streams).
+ * All views share the image size, tan_fovx / tan_fovy, background and the Gaussians; `views` is a HOST array of n_views
+ * (1 .. DGR_MAX_BATCH_VIEWS) structs of DEVICE pointers, read during the call only.  Light variant. */
+#define DGR_MAX_BATCH_VIEWS 8
+typedef struct dgr_light_view {        /* the per-camera arguments of dgr_light_forward_presized, same meaning */
+    char* geometry_buffer;
+    char* binning_buffer;
+    int binning_capacity;
+    char* image_buffer;
+    int* status;                        /* device int[4] or NULL */
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* cam_pos;
+    float* out_color;
+    float* out_depth;
+    float* out_median_depth;
+    float* out_alpha;
+    const float* gt_depth;
+    float* out_depth_var;
+    float* gau_uncertainty;
+    int* gau_related_pixels;
+    int* radii;                         /* may be NULL */
+} dgr_light_view;
+int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* views, int P, int D, int M,
+                            const float* background, int width, int height, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cov3D_precomp, float tan_fovx, float tan_fovy, int prefiltered);
+
+typedef struct dgr_light_view_grad {   /* the per-camera arguments of dgr_light_backward, same meaning */
+    char* geometry_buffer;
+    char* binning_buffer;
+    char* image_buffer;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* cam_pos;
+    const float* perspec_matrix;
+    const float* alphas;
+    const float* gt_depth;
+    const int* radii;                   /* may be NULL (internal copy is used) */
+    const float* dL_dpix;
+    const float* dL_dpix_depth;
+    const float* dL_dpix_median_depth;
+    const float* dL_dpix_depth_var;
+    float* dL_dmean2D;                  /* [P,3] of THIS view (densification statistics are per view); may be NULL */
+    float* dL_dview;                    /* [16] of this view */
+    char* scratch;                      /* dgr_light_backward_scratch_bytes(), one per view */
+    size_t scratch_bytes;
+} dgr_light_view_grad;
+/* dL_dopacity [P], dL_dcolor [P,3] (may be NULL), dL_dmean3D [P,3], dL_dcov3D [P,6] (may be NULL), dL_dsh [P,M,3] (NULL when
+ * M == 0), dL_dscale [P,3], dL_drot [P,4]: the SUM over the views.  Every one of them may be NULL (tracking: map_off = 1). */
+int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_grad* views, int P, int D, int M,
+                             const float* background, int width, int height, const float* means3D, const float* shs,
+                             const float* colors_precomp, const float* scales, float scale_modifier, const float* rotations,
+                             const float* cov3D_precomp, float tan_fovx, float tan_fovy, float* dL_dopacity, float* dL_dcolor,
+                             float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                             int track_off, int map_off);
 
 /* Self-test of the wave64 multi-value butterfly reductions the backward blend relies on.  `in` holds 16
  * values per lane as in[c * 64 + lane]; out16[lane] / out4[lane] receive what each lane holds after the

@@ -69,3 +69,20 @@ def test_early_status_without_a_forward_reports_nothing_posted():
     buf = (ctypes.c_int * 4)(7, 7, 7, 7)
     assert lib.dgr_early_status_arm() == 0
     assert lib.dgr_early_status_wait(buf) == 1 and list(buf) == [0, 0, 0, 0]
+
+
+def test_batch_entry_points_reject_bad_view_counts_before_touching_the_gpu():
+    lib = _capi.load()
+    views = (_capi.LightView * 1)()
+    args = (0, 3, 16, None, 64, 48, None, None, None, None, None, 1.0, None, None, 0.6, 0.45, 0)
+    assert lib.dgr_light_forward_batch(None, 0, views, *args) == _capi.DGR_ERR_BAD_ARGUMENT
+    assert lib.dgr_light_forward_batch(None, _capi.MAX_BATCH_VIEWS + 1, views, *args) == _capi.DGR_ERR_BAD_ARGUMENT
+    assert b"views per batch" in lib.dgr_last_error()
+    grads = (_capi.LightViewGrad * 1)()
+    assert lib.dgr_light_backward_batch(None, 0, grads, 0, 3, 16, None, 64, 48, None, None, None, None, 1.0, None, None, 0.6,
+                                        0.45, None, None, None, None, None, None, None, 0, 0) == _capi.DGR_ERR_BAD_ARGUMENT
+    # the ctypes structs mirror the C layout: 17 / 18 eight-byte slots (the int is padded to pointer alignment)
+    assert ctypes.sizeof(_capi.LightView) == 17 * 8 and ctypes.sizeof(_capi.LightViewGrad) == 18 * 8
+    assert lib.dgr_get_option(b"batch_streams") == 3
+    assert lib.dgr_set_option(b"batch_streams", 1) == 0 and lib.dgr_get_option(b"batch_streams") == 1
+    assert lib.dgr_set_option(b"batch_streams", 3) == 0
