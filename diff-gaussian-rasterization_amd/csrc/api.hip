@@ -308,14 +308,24 @@ int check_common(const FwdCommon& c) {
 // (binning + blend, blend backward) are independent and mix kernels that leave the chip idle (count, scan, emit, sort) with
 // kernels bound by VALU issue (blend), so view v runs them on stream v mod K -- the caller's stream and K - 1 helper
 // streams of this thread -- forked and joined with events: what DESIGN.md s7 measured for "views in flight", inside one call
-// and capturable into one hipGraph.  dgr_set_option("batch_streams", K), K = 1..3 (default 3).
-std::atomic<int> g_batch_streams{3};
-constexpr int DGR_BATCH_MAX_STREAMS = 3;
+// and capturable into one hipGraph.  dgr_set_option("batch_streams", K), K = 1..8: at most K streams; the views are dealt
+// out in rounds, and a batch uses the fewest streams that keep the number of rounds minimal, since the join waits for the
+// longest stream.  Default 2, measured (profiles/batch_streams.sh, config 3, ms per view for K = 1 / 2 / 3 / 4 / 8):
+// 3 views 0.459 / 0.434 / 0.436 / 0.438 / 0.444, 4 views 0.450 / 0.415 / 0.419 / 0.446 / 0.437, 8 views 0.425 / 0.377 /
+// 0.380 / 0.391 / 0.407 -- one view's binning under another view's blend is the whole gain; more blend kernels at once
+// only take each other's L2 and wave slots.
+std::atomic<int> g_batch_streams{2};
+constexpr int DGR_BATCH_MAX_STREAMS = 8;
+inline int batch_stream_count(int n_views) {
+    const int kmax = std::max(1, std::min(g_batch_streams.load(), DGR_BATCH_MAX_STREAMS));
+    const int rounds = (n_views + kmax - 1) / kmax;
+    return (n_views + rounds - 1) / rounds;
+}
 struct BatchStreams {
     int device = -1;
-    hipStream_t helper[DGR_BATCH_MAX_STREAMS - 1] = {nullptr, nullptr};
+    hipStream_t helper[DGR_BATCH_MAX_STREAMS - 1] = {};
     hipEvent_t fork = nullptr;
-    hipEvent_t join[DGR_BATCH_MAX_STREAMS - 1] = {nullptr, nullptr};
+    hipEvent_t join[DGR_BATCH_MAX_STREAMS - 1] = {};
 };
 thread_local BatchStreams g_batch;
 int batch_streams_ready() {
@@ -744,7 +754,7 @@ int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* vie
         }
         { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd_batch(b, st)); }
     }
-    const int K = std::max(1, std::min({n_views, g_batch_streams.load(), DGR_BATCH_MAX_STREAMS}));
+    const int K = batch_stream_count(n_views);
     if ((rc = batch_fork(st, K))) return rc;
     for (int v = 0; v < n_views; v++) {
         hipStream_t sv = batch_stream(st, v, K);
@@ -789,7 +799,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
     int rc;
     if ((rc = batch_streams_ready())) return rc;
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    const int K = std::max(1, std::min({n_views, g_batch_streams.load(), DGR_BATCH_MAX_STREAMS}));
+    const int K = batch_stream_count(n_views);
     dgr::PreprocessBwdBatchArgs bb{};
     if ((rc = batch_fork(st, K))) return rc;
     for (int v = 0; v < n_views; v++) {

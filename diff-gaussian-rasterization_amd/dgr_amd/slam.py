@@ -170,6 +170,21 @@ def _get(obj, name, default=None):
     return v() if callable(v) and not isinstance(v, torch.Tensor) else v
 
 
+def _matmul_fixed_order(a, b):
+    """a @ b for [..., n, 4] @ [4, m] with the four products of every entry added in index order by elementwise kernels
+    (see _campos: the result must not depend on whether `a` is one matrix or a slice of a stack)."""
+    return ((a[..., :, 0:1] * b[0] + a[..., :, 1:2] * b[1]) + a[..., :, 2:3] * b[2]) + a[..., :, 3:4] * b[3]
+
+
+def _campos(vm):
+    """Camera centre -(R^T t) from viewmatrix = W2C^T ([4,4] or [V,4,4]), with the three products added in a fixed order
+    by elementwise kernels: a `sum()` reduction picks its summation order from the tensor's layout and alignment, so the
+    same pose gave cameras one ulp apart as a [4,4] tensor and as a slice of a [V,4,4] one."""
+    r0, r1, r2 = vm[..., :3, 0], vm[..., :3, 1], vm[..., :3, 2]
+    t0, t1, t2 = vm[..., 3, 0:1], vm[..., 3, 1:2], vm[..., 3, 2:3]
+    return (-((r0 * t0 + r1 * t1) + r2 * t2)).contiguous()
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, viewmatrix=None, fov=None,
            HW=None, gt_depth=None, track_off=False, map_off=False, variant="light"):
     """CG-SLAM's `render()` (reference README.md:33,71).
@@ -195,9 +210,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
             perspec = projection_matrix(tanfovx, tanfovy, znear, zfar, device=dev).transpose(0, 1).contiguous()
         perspec = perspec.to(dev, torch.float32)
         vm = viewmatrix.detach()
-        projmatrix = _small_matmul(vm, perspec).contiguous()
-        w2c = vm.transpose(0, 1)
-        campos = (-(w2c[:3, :3] * w2c[:3, 3:4]).sum(0)).contiguous()  # -(R^T t)
+        projmatrix = _matmul_fixed_order(vm, perspec).contiguous()
+        campos = _campos(vm)
 
     means3D = pc.get_xyz
     # 3DGS keeps a zero tensor whose .grad receives the screen-space gradient (densification statistics).  A tracking
@@ -231,6 +245,78 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         res = {"render": color, "depth": depth, "opacity_map": uncertainty}
     res.update(viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii)
     return res
+
+
+def render_views(cameras, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, track_off=False, map_off=False):
+    """`render()` for the V cameras of a keyframe batch in ONE call of the batched entry points (`dgr_amd.batch`, SURVEY.md
+    s8(f) item 2; light variant): the cameras share `fov` and `HW` (one sensor, V poses), every per-view entry of `render()`'s
+    dict comes back with a leading view dimension, and one backward through it yields the Gaussians' gradients already summed
+    over the views, the pose gradient per `viewmatrix` and `viewspace_points.grad` ([V,P,3]) per view.
+    `cameras`: sequence of dicts with `viewmatrix` (W2C^T), `fov`, `HW` and optionally `gt_depth`, `viewpoint_camera`."""
+    from . import batch as _batch
+    cameras = list(cameras)
+    if not 1 <= len(cameras) <= _batch.MAX_VIEWS:
+        raise ValueError(f"1 .. {_batch.MAX_VIEWS} cameras per call")
+    c0 = cameras[0]
+    H, W = int(c0["HW"][0]), int(c0["HW"][1])
+    tanfovx, tanfovy = float(c0["fov"][0]), float(c0["fov"][1])
+    for c in cameras[1:]:
+        if (int(c["HW"][0]), int(c["HW"][1])) != (H, W) or (float(c["fov"][0]), float(c["fov"][1])) != (tanfovx, tanfovy):
+            raise ValueError("the cameras of a batch share fov and HW")
+    viewmatrices = torch.stack([c["viewmatrix"] for c in cameras])  # (differentiable: every pose keeps its gradient)
+    dev = viewmatrices.device
+    cam0 = c0.get("viewpoint_camera")
+    znear = float(_get(cam0, "znear", 0.01)) if cam0 is not None else 0.01
+    zfar = float(_get(cam0, "zfar", 100.0)) if cam0 is not None else 100.0
+    with torch.no_grad():
+        perspec = _get(cam0, "projection_matrix") if cam0 is not None else None
+        if perspec is None:
+            perspec = projection_matrix(tanfovx, tanfovy, znear, zfar, device=dev).transpose(0, 1).contiguous()
+        perspec = perspec.to(dev, torch.float32)
+        vm = viewmatrices.detach()
+        # (the operations of render(), in a fixed order: the cameras -- hence the images -- are those of the one-view path
+        #  bit for bit)
+        projmatrices = _matmul_fixed_order(vm, perspec).contiguous()
+        campos = _campos(vm)
+        gts = [c.get("gt_depth") for c in cameras]
+        if any(g is None for g in gts):
+            raise ValueError("the light variant needs gt_depth for every camera")
+        gt_depths = torch.stack([g.reshape(H, W) for g in gts])
+    means3D = pc.get_xyz
+    shs_or_colors = override_color if override_color is not None else pc.get_features
+    opacity, scaling, rotation = pc.get_opacity, pc.get_scaling, pc.get_rotation
+    mapping = not map_off and any(t.requires_grad for t in (means3D, shs_or_colors, opacity, scaling, rotation))
+    screenspace_points = torch.zeros((len(cameras),) + tuple(means3D.shape), dtype=means3D.dtype, device=dev, requires_grad=mapping)
+    debug = bool(getattr(pipe, "debug", False)) if pipe is not None else False
+    settings = _batch.BatchRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrices=vm, projmatrices=projmatrices, sh_degree=int(pc.active_sh_degree), campos=campos, prefiltered=False,
+        debug=debug, perspec_matrix=perspec, track_off=track_off, map_off=map_off)
+    shs, colors = (None, override_color) if override_color is not None else (shs_or_colors, None)
+    color, radii, depth, depth_median, depth_var, opacity_map, gau_uncertainty, gau_related_pixels = \
+        _batch.GaussianRasterizerBatch(settings)(means3D, screenspace_points, opacity, shs=shs, colors_precomp=colors,
+                                                 scales=scaling, rotations=rotation, viewmatrices=viewmatrices,
+                                                 gt_depths=gt_depths)
+    return {"render": color, "depth": depth, "depth_median": depth_median, "opacity_map": opacity_map, "depth_var": depth_var,
+            "gau_uncertainty": gau_uncertainty, "num_related_pixels": gau_related_pixels,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
+
+def render_batch_fused(cameras, pc, pipe, bg_color, loss_fn, **render_kwargs):
+    """`render_batch` through ONE batched forward and ONE batched backward (`render_views`): `loss_fn(out_k, k)` sees the
+    dict of view k (slices of the batched outputs), the losses are summed and back-propagated once.  Same gradients as
+    `render_batch` -- the sum over the keyframes in the Gaussians' `.grad`, one pose gradient per `viewmatrix` -- without V - 1
+    accumulation passes over the dense gradient rows and with the camera-independent per-Gaussian work done once."""
+    out = render_views(cameras, pc, pipe, bg_color, **render_kwargs)
+    per_view = ("render", "depth", "depth_median", "opacity_map", "depth_var", "gau_uncertainty", "num_related_pixels",
+                "visibility_filter", "radii")
+    losses = []
+    for k in range(out["render"].size(0)):
+        ok = {n: out[n][k] for n in per_view}
+        ok["viewspace_points"] = out["viewspace_points"]  # ([V,P,3]: one backward fills every view's slice)
+        losses.append(loss_fn(ok, k))
+    torch.stack(losses).sum().backward()
+    return [l_.detach() for l_ in losses], out
 
 
 def render_batch(cameras, pc, pipe, bg_color, loss_fn, views_in_flight=3, **render_kwargs):

@@ -7,9 +7,10 @@ A synthetic map rendered from K poses gives the keyframes' observed colour and d
                          no pose gradient), gradients summed into the parameters' .grad
   add_densification_stats 3DGS's per-view bookkeeping (screen-space gradient norm, view count, largest radius), one launch
   SparseAdam.step        fused Adam over the rows some keyframe saw, one launch per tensor
-all on the GPU, no host synchronisation inside the loop.
+all on the GPU, no host synchronisation inside the loop.  --fused renders the keyframe batch through the batched entry points
+instead (slam.render_batch_fused: one forward and one backward call for all keyframes, gradients summed in the kernels).
 
-  python examples/mapping.py [--graph] [--iters 100] [--keyframes 4] [--width 640 --height 480 --gaussians 100000]
+  python examples/mapping.py [--graph] [--fused] [--iters 100] [--keyframes 4] [--width 640 --height 480 --gaussians 100000]
 """
 import argparse
 import os
@@ -58,7 +59,7 @@ class MapModel:
                 {"params": [self._rotation], "lr": 1e-3}]
 
 
-def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None, graph=False):
+def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None, graph=False, fused=False):
     """Returns (losses of the first and last iteration, model, seconds per iteration).  graph=True records the whole
     iteration (renders, losses, backward passes, statistics, Adam) into one hipGraph after three eager iterations."""
     from dgr_amd import slam
@@ -89,7 +90,21 @@ def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None, gr
         outs[k] = out
         return slam.l1_loss(out["render"], out["depth"], obs[k][0], obs[k][1], 1.0, 0.5)  # one fused reduction
 
+    def iteration_fused():
+        # the keyframe batch through ONE batched forward and ONE batched backward (dgr_amd.batch): the Gaussians' gradients
+        # arrive summed over the keyframes, the screen-space gradients per view
+        opt.zero_grad(set_to_none=True)
+        losses, out = slam.render_batch_fused(cams, pc, None, bg, loss_fn, **kw)
+        pts = out["viewspace_points"].grad
+        for k in range(keyframes):
+            add_densification_stats(pts[k], out["radii"][k], pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)
+        torch.amax(out["radii"], dim=0, out=seen)
+        opt.step(visible=seen)
+        return torch.stack(losses).mean()
+
     def iteration():
+        if fused:
+            return iteration_fused()
         opt.zero_grad(set_to_none=True)
         if views_in_flight > 1:
             losses = slam.render_batch(cams, pc, None, bg, loss_fn, views_in_flight=views_in_flight, **kw)
@@ -140,6 +155,9 @@ def main():
     ap.add_argument("--keyframes", type=int, default=4)
     ap.add_argument("--views-in-flight", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="record the iteration into a hipGraph and replay it")
+    ap.add_argument("--fused", action="store_true",
+                    help="the keyframe batch through one batched forward + backward (slam.render_batch_fused) instead of one "
+                         "rasterizer call per keyframe")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--gaussians", type=int, default=100000)
@@ -148,7 +166,7 @@ def main():
         os.environ["DGR_SYNC_MODE"] = "lazy"  # a blocking status read cannot be captured
     dev = torch.device("cuda:0")
     (l0, l1), pc, dt = mapping_loop(dev, args.gaussians, args.width, args.height, args.keyframes, args.iters,
-                                    args.views_in_flight, log=None if args.graph else print, graph=args.graph)
+                                    args.views_in_flight, log=None if args.graph else print, graph=args.graph, fused=args.fused)
     n = float(pc.denom.sum())
     print(f"loss {l0:.4e} -> {l1:.4e}; {dt * 1e3:.3f} ms per mapping iteration over {args.keyframes} keyframes"
           f" ({dt / args.keyframes * 1e3:.3f} ms per keyframe); {int((pc.denom > 0).sum())} Gaussians seen,"

@@ -236,7 +236,7 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
  *     2 = LDS whenever the histogram fits; 0 = never.  Results are identical bit for bit.  dgr_binning_bytes() includes the
  *     LDS count's forward-only workspace.
  *  "profile_every": n >= 1 = dgr_profile_* brackets every n-th launch of the selected stage only (default 1).
- *  "batch_streams" (default 3): streams the batched entry points spread the per-view stages of a batch over (1..3). */
+ *  "batch_streams" (default 2): streams the batched entry points spread the per-view stages of a batch over (1..8). */
 int dgr_set_option(const char* name, int value);
 int dgr_get_option(const char* name);
 
@@ -260,8 +260,8 @@ int dgr_cov3d_backward(void* stream, int P, const float* scales, const float* ro
  *    dense row (248 bytes per Gaussian at SH degree 3) once instead of V times plus V - 1 accumulation passes; the covariance
  *    backward (linear in dL_dcov3D) runs once on the sum.  dL_dopacity / dL_dmean3D / dL_dsh / dL_dcov3D equal, bit for bit,
  *    the one-view outputs accumulated in view order; dL_dscale / dL_drot agree to rounding (converted once, not V times);
- *  - the per-view stages in between (binning and blend) are issued on up to three internal streams forked from and joined
- *    to `stream` with events (option "batch_streams", 1..3, default 3), so that they overlap as independent views do;
+ *  - the per-view stages in between (binning and blend) are issued on internal streams forked from and joined to `stream`
+ *    with events (option "batch_streams", 1..8, default 2: one view's binning runs under another view's blend);
  *  - no host synchronisation (hipGraph-capturable after one warm-up call, which creates the internal streams).
  * All views share the image size, tan_fovx / tan_fovy, background and the Gaussians; `views` is a HOST array of n_views
  * (1 .. DGR_MAX_BATCH_VIEWS) structs of DEVICE pointers, read during the call only.  Light variant. */

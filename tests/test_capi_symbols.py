@@ -83,6 +83,6 @@ def test_batch_entry_points_reject_bad_view_counts_before_touching_the_gpu():
                                         0.45, None, None, None, None, None, None, None, 0, 0) == _capi.DGR_ERR_BAD_ARGUMENT
     # the ctypes structs mirror the C layout: 17 / 18 eight-byte slots (the int is padded to pointer alignment)
     assert ctypes.sizeof(_capi.LightView) == 17 * 8 and ctypes.sizeof(_capi.LightViewGrad) == 18 * 8
-    assert lib.dgr_get_option(b"batch_streams") == 3
+    assert lib.dgr_get_option(b"batch_streams") == 2
     assert lib.dgr_set_option(b"batch_streams", 1) == 0 and lib.dgr_get_option(b"batch_streams") == 1
-    assert lib.dgr_set_option(b"batch_streams", 3) == 0
+    assert lib.dgr_set_option(b"batch_streams", 2) == 0

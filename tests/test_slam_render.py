@@ -130,6 +130,58 @@ def test_render_batch_accumulates_like_a_serial_loop():
 
 
 @pytest.mark.gpu
+def test_render_batch_fused_equals_the_serial_loop():
+    """slam.render_batch_fused (one batched forward + one batched backward, dgr_amd.batch) against rendering the keyframes one
+    after the other: losses, the summed gradients of the Gaussians, every pose gradient, the per-view screen-space gradients."""
+    dev = torch.device("cuda:0")
+    W, H = 160, 120
+    scenes = [make_scene(6000, W, H, 3, view_index=k) for k in range(4)]
+    s = scenes[0]
+    bg = torch.from_numpy(s.bg).to(dev)
+    gt = torch.from_numpy(s.gt).to(dev)
+    targets = [torch.rand((3, H, W), device=dev) for _ in scenes]
+
+    def model():
+        m = Model(s, dev)
+        for name in ("get_xyz", "get_opacity", "get_scaling", "get_rotation", "get_features"):
+            setattr(m, name, getattr(m, name).clone().requires_grad_())
+        return m
+
+    def cams():
+        return [dict(viewmatrix=torch.from_numpy(sc.view).to(dev).requires_grad_(), fov=(sc.tanfovx, sc.tanfovy), HW=(H, W),
+                     gt_depth=gt) for sc in scenes]
+
+    def loss_fn(out, k):
+        return (out["render"] - targets[k]).abs().mean() + 0.1 * out["depth"].mean() + 0.05 * out["depth_median"].mean()
+
+    a, ca = model(), cams()
+    la, out = slam.render_batch_fused(ca, a, None, bg, loss_fn)
+    assert out["render"].shape == (4, 3, H, W) and out["viewspace_points"].grad.shape == (4, 6000, 3)
+    b, cb = model(), cams()
+    lb, pts = [], []
+    for k, cam in enumerate(cb):
+        o = slam.render(None, b, None, bg, viewmatrix=cam["viewmatrix"], fov=cam["fov"], HW=cam["HW"], gt_depth=gt)
+        assert torch.equal(o["render"], out["render"][k]) and torch.equal(o["radii"], out["radii"][k])
+        loss = loss_fn(o, k)
+        loss.backward()
+        lb.append(loss.detach())
+        pts.append(o["viewspace_points"].grad)
+    torch.cuda.synchronize()
+    for x, y in zip(la, lb):
+        assert abs(float(x) - float(y)) <= 1e-6 * abs(float(y))
+
+    def close(x, y, tol, what):
+        x, y = x.detach().cpu().numpy(), y.detach().cpu().numpy()
+        assert np.abs(x - y).max() <= tol * np.abs(y).max(), what
+
+    for name in ("get_xyz", "get_opacity", "get_scaling", "get_rotation", "get_features"):
+        close(getattr(a, name).grad, getattr(b, name).grad, 2e-5, name)
+    for k in range(4):
+        close(ca[k]["viewmatrix"].grad, cb[k]["viewmatrix"].grad, 2e-5, f"pose {k}")
+        close(out["viewspace_points"].grad[k], pts[k], 2e-5, f"viewspace_points {k}")
+
+
+@pytest.mark.gpu
 def test_tracking_iteration_replayed_from_a_hipgraph(monkeypatch):
     """The whole tracking iteration -- pose -> camera matrices -> render -> loss -> backward -> Adam step -- recorded once
     (dgr_amd.multiview.CapturedStep) and replayed: the pose converges as in the eager loop (examples/tracking.py)."""
@@ -176,6 +228,28 @@ def test_tracking_iteration_replayed_from_a_hipgraph(monkeypatch):
     e1 = errors()
     assert float(last) < 0.3 * first
     assert e1[0] < 0.3 * e0[0] and e1[1] < 0.3 * e0[1], (e0, e1)
+
+
+@pytest.mark.gpu
+def test_fused_mapping_loop_follows_the_per_view_loop(monkeypatch):
+    """examples/mapping.py --fused (the keyframe batch through the batched entry points), eager and replayed from a hipGraph:
+    same loss trajectory and statistics as one rasterizer call per keyframe."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    from mapping import mapping_loop
+    iters, keyframes = 40, 3
+    dev = torch.device("cuda:0")
+    (a0, a1), pa, _ = mapping_loop(dev, 8000, 192, 144, keyframes, iters, views_in_flight=1)
+    (b0, b1), pb, _ = mapping_loop(dev, 8000, 192, 144, keyframes, iters, fused=True)
+    assert abs(a0 - b0) <= 1e-5 * a0 and abs(a1 - b1) <= 2e-3 * a1, ((a0, a1), (b0, b1))
+    assert torch.equal(pa.denom, pb.denom) and torch.equal(pa.max_radii2D, pb.max_radii2D)
+    # (40 Adam steps amplify the rounding noise of the blend backward's float atomics: two runs of the SAME loop differ
+    #  by this much too)
+    assert float((pa.xyz_gradient_accum - pb.xyz_gradient_accum).abs().max()) <= 2e-2 * float(pa.xyz_gradient_accum.abs().max())
+    monkeypatch.setenv("DGR_SYNC_MODE", "lazy")
+    (c0, c1), pc_, _ = mapping_loop(dev, 8000, 192, 144, keyframes, iters, fused=True, graph=True)
+    assert abs(c1 - a1) <= 2e-3 * a1 and float(pc_.denom.max()) == iters * keyframes
 
 
 @pytest.mark.gpu
