@@ -329,6 +329,128 @@ std::vector<Tensor> full_backward(const Tensor& background, const Tensor& means3
     return g;
 }
 
+// ------------------------------------------------------------------------------------------------ batched views
+// dgr_amd.batch over the C ABI's batched entry points (include/dgr_hip.h: dgr_light_forward_batch / _backward_batch): V
+// cameras over one set of Gaussians per call.  ONE attempt with the given binning capacity per view and no host
+// synchronisation; the capacity policy, the strict mode's status read and its retry stay in Python (dgr_amd/batch.py).
+// post_status: copy every view's status word to pinned memory behind an event (lazy mode) and return the tickets.
+// Returns ([V,4] status, color, depth, median, var, alpha, radii, geom, binning, img, unc, px) and the tickets.
+inline char* row_bytes(const Tensor& t, long v) { return t.numel() == 0 ? nullptr : reinterpret_cast<char*>(t.data_ptr()) + v * t.stride(0) * t.element_size(); }
+template <typename T>
+inline T* row(const Tensor& t, long v) { return reinterpret_cast<T*>(row_bytes(t, v)); }
+
+std::tuple<std::vector<Tensor>, std::vector<long>>
+light_forward_batch(const Tensor& background, const Tensor& means3D_, const Tensor& colors_, const Tensor& opacity_,
+                    const Tensor& scales_, const Tensor& rotations_, double scale_modifier, const Tensor& cov3D_,
+                    const Tensor& viewmatrices_, const Tensor& gt_depths_, const Tensor& projmatrices_, double tan_fovx,
+                    double tan_fovy, long H, long W, const Tensor& sh_, long degree, const Tensor& campos_, bool prefiltered,
+                    long capacity, bool post_status) {
+    if (means3D_.dim() != 2 || means3D_.size(1) != 3) throw std::runtime_error("means3D must have dimensions (num_points, 3)");
+    const c10::Device dev = means3D_.device();
+    if (!dev.is_cuda()) throw std::runtime_error("dgr_hip runs on the GPU only (no CPU path exists, as in the reference)");
+    const long V = viewmatrices_.dim() == 3 ? viewmatrices_.size(0) : 0;
+    if (V < 1 || V > DGR_MAX_BATCH_VIEWS) throw std::runtime_error("1 .. " + std::to_string(DGR_MAX_BATCH_VIEWS) + " views per batch");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    const int P = (int)means3D_.size(0);
+    const Tensor means3D = f32c(means3D_, dev), bg = f32c(background, dev), colors = f32c(colors_, dev),
+                 opacity = f32c(opacity_, dev), scales = f32c(scales_, dev), rotations = f32c(rotations_, dev),
+                 cov3D = f32c(cov3D_, dev), views = f32c(viewmatrices_, dev), projs = f32c(projmatrices_, dev),
+                 campos = f32c(campos_, dev), gts = f32c(gt_depths_, dev), sh = f32c(sh_, dev);
+    const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
+    const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+    const auto i32 = at::TensorOptions().dtype(at::kInt).device(dev);
+    const auto u8 = at::TensorOptions().dtype(at::kByte).device(dev);
+    Tensor color = at::empty({V, 3, H, W}, f32), depth = at::empty({V, 1, H, W}, f32), median = at::empty({V, 1, H, W}, f32),
+           var = at::empty({V, 1, H, W}, f32), alpha = at::empty({V, 1, H, W}, f32);
+    Tensor radii = P ? at::empty({V, P}, i32) : at::zeros({V, P}, i32);
+    Tensor unc = P ? at::empty({V, P, 1}, f32) : at::zeros({V, P, 1}, f32);
+    Tensor px = P ? at::empty({V, P, 1}, i32) : at::zeros({V, P, 1}, i32);
+    Tensor geom = at::empty({V, (long long)std::max<size_t>(dgr_geometry_bytes(P), 1)}, u8);
+    Tensor img = at::empty({V, (long long)std::max<size_t>(dgr_image_bytes((int)W, (int)H), 1)}, u8);
+    Tensor binning = at::empty({V, (long long)std::max<size_t>(dgr_binning_bytes((int)capacity, (int)W, (int)H), 1)}, u8);
+    Tensor status = at::zeros({V, 4}, i32);
+    dgr_light_view w[DGR_MAX_BATCH_VIEWS];
+    for (long v = 0; v < V; v++) {
+        w[v] = dgr_light_view{row_bytes(geom, v), row_bytes(binning, v), (int)capacity, row_bytes(img, v), row<int>(status, v),
+                              row<float>(views, v), row<float>(projs, v), row<float>(campos, v), row<float>(color, v),
+                              row<float>(depth, v), row<float>(median, v), row<float>(alpha, v), row<float>(gts, v),
+                              row<float>(var, v), row<float>(unc, v), row<int>(px, v), row<int>(radii, v)};
+    }
+    void* st = stream_of(dev);
+    check(dgr_light_forward_batch(st, (int)V, w, P, (int)degree, M, ptr<float>(bg), (int)W, (int)H, ptr<float>(means3D),
+                                  ptr<float>(sh), ptr<float>(colors), ptr<float>(opacity), ptr<float>(scales), (float)scale_modifier,
+                                  ptr<float>(rotations), ptr<float>(cov3D), (float)tan_fovx, (float)tan_fovy, prefiltered ? 1 : 0));
+    std::vector<long> tickets;
+    if (post_status && P > 0 && !dgr_stream_is_capturing(st)) {
+        for (long v = 0; v < V; v++) {
+            const long t = dgr_status_post(st, row<int>(status, v));
+            check(t);
+            tickets.push_back(t);
+        }
+    }
+    return {{status, color, depth, median, var, alpha, radii, geom, binning, img, unc, px}, tickets};
+}
+
+// Returns (dL_dmeans2D [V,P,3] or None, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations --
+// the SUMS over the views, views of one flat arena laid out as light_backward's -- and dL_dview [V,4,4]).
+std::vector<Tensor> light_backward_batch(const Tensor& background, const Tensor& means3D_, const Tensor& radii, const Tensor& colors_,
+                                         const Tensor& scales_, const Tensor& rotations_, double scale_modifier, const Tensor& cov3D_,
+                                         const Tensor& viewmatrices_, const Tensor& projmatrices_, double tan_fovx, double tan_fovy,
+                                         const Tensor& dL_dout_color, const Tensor& dL_dout_depth, const Tensor& dL_dout_median,
+                                         const Tensor& dL_dout_var, const Tensor& gt_depths_, const Tensor& sh_, long degree,
+                                         const Tensor& campos_, const Tensor& geom, const Tensor& binning, const Tensor& img,
+                                         const Tensor& alphas_, const Tensor& perspec_, bool track_off, bool map_off,
+                                         bool need_gaussian_grads, bool need_means2D) {
+    const c10::Device dev = means3D_.device();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    const int P = (int)means3D_.size(0);
+    const long V = viewmatrices_.size(0), H = dL_dout_color.size(2), W = dL_dout_color.size(3);
+    if (V < 1 || V > DGR_MAX_BATCH_VIEWS) throw std::runtime_error("1 .. " + std::to_string(DGR_MAX_BATCH_VIEWS) + " views per batch");
+    const Tensor means3D = f32c(means3D_, dev), bg = f32c(background, dev), colors = f32c(colors_, dev),
+                 scales = f32c(scales_, dev), rotations = f32c(rotations_, dev), cov3D = f32c(cov3D_, dev),
+                 views = f32c(viewmatrices_, dev), projs = f32c(projmatrices_, dev), campos = f32c(campos_, dev),
+                 gts = f32c(gt_depths_, dev), sh = f32c(sh_, dev), alphas = f32c(alphas_, dev), perspec = f32c(perspec_, dev),
+                 gC = f32c(dL_dout_color, dev), gD = f32c(dL_dout_depth, dev), gM = f32c(dL_dout_median, dev),
+                 gV = f32c(dL_dout_var, dev);
+    const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
+    const auto f32 = at::TensorOptions().dtype(at::kFloat).device(dev);
+    std::vector<Tensor> g(9);
+    float* gp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    Tensor d2;
+    if (need_gaussian_grads) {
+        const long long n[8] = {3LL * P, 3LL * P, 3LL * M * P, P, 3LL * P, 4LL * P, 6LL * P, 3LL * P};
+        long long off[8], o = 0;
+        for (int i = 0; i < 8; i++) { off[i] = o; o += (n[i] + 63) / 64 * 64; }
+        Tensor arena = P ? at::empty({std::max<long long>(o, 1)}, f32) : at::zeros({std::max<long long>(o, 1)}, f32);
+        auto seg = [&](int i, c10::IntArrayRef shape) { return arena.narrow(0, off[i], n[i]).view(shape); };
+        seg(1, {P, 3}).zero_();  // the arena's one-view means2D slot: a batch returns those gradients per view, beside the arena
+        g[3] = seg(0, {P, 3}); g[5] = seg(2, {P, M, 3}); g[2] = seg(3, {P, 1});
+        g[6] = seg(4, {P, 3}); g[7] = seg(5, {P, 4}); g[4] = seg(6, {P, 6}); g[1] = seg(7, {P, 3});
+        for (int i = 1; i < 8; i++) gp[i] = ptr<float>(g[i]);
+        if (need_means2D) { d2 = at::empty({V, P, 3}, f32); g[0] = d2; }
+    } else {
+        map_off = true;  // nobody reads the per-Gaussian sums: the blend kernels form the three pose sums only
+    }
+    Tensor dview = at::empty({V, 4, 4}, f32);
+    const size_t nscr = std::max<size_t>(dgr_light_backward_scratch_bytes(P, (int)W, (int)H), 1);
+    Tensor scratch = at::empty({V, (long long)nscr}, at::TensorOptions().dtype(at::kByte).device(dev));
+    dgr_light_view_grad w[DGR_MAX_BATCH_VIEWS];
+    for (long v = 0; v < V; v++) {
+        w[v] = dgr_light_view_grad{row_bytes(geom, v), row_bytes(binning, v), row_bytes(img, v), row<float>(views, v),
+                                   row<float>(projs, v), row<float>(campos, v), ptr<float>(perspec), row<float>(alphas, v),
+                                   row<float>(gts, v), row<int>(radii, v), row<float>(gC, v), row<float>(gD, v), row<float>(gM, v),
+                                   row<float>(gV, v), d2.defined() ? row<float>(d2, v) : nullptr, row<float>(dview, v),
+                                   row_bytes(scratch, v), nscr};
+    }
+    // gp: [1] colors [2] opacity [3] means3D [4] cov3D [5] sh [6] scales [7] rotations
+    check(dgr_light_backward_batch(stream_of(dev), (int)V, w, P, (int)degree, M, ptr<float>(bg), (int)W, (int)H, ptr<float>(means3D),
+                                   ptr<float>(sh), ptr<float>(colors), ptr<float>(scales), (float)scale_modifier,
+                                   ptr<float>(rotations), ptr<float>(cov3D), (float)tan_fovx, (float)tan_fovy, gp[2], gp[1], gp[3],
+                                   gp[4], gp[5], gp[6], gp[7], track_off ? 1 : 0, map_off ? 1 : 0));
+    g[8] = dview;
+    return g;
+}
+
 Tensor mark_visible(const Tensor& means3D_, const Tensor& viewmatrix_, const Tensor& projmatrix_) {  // L/rasterize_points.cu:238-256
     const c10::Device dev = means3D_.device();
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
@@ -359,6 +481,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("light_backward", &light_backward);
     m.def("full_forward", &full_forward);
     m.def("full_backward", &full_backward);
+    m.def("light_forward_batch", &light_forward_batch);
+    m.def("light_backward_batch", &light_backward_batch);
     m.def("mark_visible", &mark_visible);
     m.def("status_poll", &status_poll);
 }

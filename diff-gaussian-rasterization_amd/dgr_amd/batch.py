@@ -55,6 +55,50 @@ def _row(t, v):
     return t.data_ptr() + v * t.stride(0) * t.element_size()
 
 
+def _ext():
+    """the compiled torch extension (csrc/torch_ext.cpp: light_forward_batch / light_backward_batch -- allocation and
+    marshalling in C++) when dgr_amd.light selected it, else None: the ctypes code below binds the same C ABI"""
+    return _light._CompiledC.ext if _light._C is _light._CompiledC else None
+
+
+def _forward_batch_compiled(ext, bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices,
+                            gt_depths, projmatrices, tanfovx, tanfovy, H, W, sh, degree, campos, prefiltered, key, V):
+    cap = _light._capacity_cache.get(key, 0)
+    lazy = _light._sync_mode() == "lazy" and cap > 0
+    cap = (int(cap * 1.5) + 4096) if lazy else (int(cap * 1.25) + 4096 if cap else 4 * key[1] + 4096)
+    capturing = torch.cuda.is_current_stream_capturing()
+    while True:
+        if lazy and not capturing:
+            while len(_light._pending_status) > V:
+                _light._check_oldest()  # status words of earlier calls have long completed: no stall
+        out, tickets = ext.light_forward_batch(bg, means3D, colors, opacity, scales, rotations, float(scale_modifier),
+                                               cov3D_precomp, viewmatrices, gt_depths, projmatrices, float(tanfovx),
+                                               float(tanfovy), int(H), int(W), sh, int(degree), campos, bool(prefiltered), cap,
+                                               bool(lazy))
+        status = out[0]
+        if key[1] == 0:
+            rendered = [0] * V
+            break
+        if lazy or capturing:
+            for t in tickets:
+                _light._pending_status.append((t, key))
+            if capturing:  # recorded into a hipGraph: nothing can be read back now (dgr_amd.light.check_captured_status)
+                import weakref
+                _light._captured_status.append(weakref.ref(status))
+                _light._capture_keepalive.append(status)
+            rendered = [_light._capacity_cache.get(key, 0)] * V
+            break
+        s = status.tolist()  # the one host wait of a strict batch
+        if any(r[2] for r in s):
+            raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+        rendered = [r[0] for r in s]
+        _light._capacity_cache[key] = max(_light._capacity_cache.get(key, 0), max(rendered))
+        if max(rendered) <= cap:
+            break
+        cap = int(max(rendered) * 1.1) + 4096  # overflow: those views' tile lists were left empty; run again
+    return (rendered,) + tuple(out[1:])
+
+
 def _forward_batch(bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices, gt_depths,
                    projmatrices, tanfovx, tanfovy, H, W, sh, degree, campos, prefiltered):
     lib = _lib()
@@ -65,6 +109,11 @@ def _forward_batch(bg, means3D, colors, opacity, scales, rotations, scale_modifi
     if not 1 <= V <= MAX_VIEWS:
         raise RuntimeError(f"1 .. {MAX_VIEWS} views per batch")
     P = means3D.size(0)
+    ext = _ext()
+    if ext is not None:
+        return _forward_batch_compiled(ext, bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                                       viewmatrices, gt_depths, projmatrices, tanfovx, tanfovy, H, W, sh, degree, campos,
+                                       prefiltered, (dev.index, P, H, W), V)
     f32 = dict(dtype=torch.float32, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
     u8 = dict(dtype=torch.uint8, device=dev)
@@ -125,6 +174,13 @@ def _forward_batch(bg, means3D, colors, opacity, scales, rotations, scale_modifi
 def _backward_batch(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices, projmatrices,
                     tanfovx, tanfovy, gC, gD, gM, gV, gt_depths, sh, degree, campos, geom, binning, img, alphas,
                     perspec_matrix, track_off, map_off, need_gaussian_grads, need_means2D):
+    ext = _ext()
+    if ext is not None:
+        g = ext.light_backward_batch(bg, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp,
+                                     viewmatrices, projmatrices, float(tanfovx), float(tanfovy), gC, gD, gM, gV, gt_depths, sh,
+                                     int(degree), campos, geom, binning, img, alphas, perspec_matrix, bool(track_off),
+                                     bool(map_off), bool(need_gaussian_grads), bool(need_means2D))
+        return tuple(g)
     lib = _lib()
     dev = means3D.device
     V, P = viewmatrices.size(0), means3D.size(0)

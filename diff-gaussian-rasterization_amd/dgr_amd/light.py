@@ -95,12 +95,12 @@ def check_captured_status():
         st = ref()
         if st is None:
             continue
-        s = st.tolist()
-        if s[2]:
-            raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
-        if s[1]:
-            raise RuntimeError(f"dgr_hip: binning buffer overflow in a graph-captured forward (needed {s[0]} instances): "
-                               f"re-capture after an eager warm-up on the larger scene")
+        for s in st.reshape(-1, 4).tolist():  # (a batched forward keeps the [V,4] status words of its views in one tensor)
+            if s[2]:
+                raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+            if s[1]:
+                raise RuntimeError(f"dgr_hip: binning buffer overflow in a graph-captured forward (needed {s[0]} instances): "
+                                   f"re-capture after an eager warm-up on the larger scene")
 
 
 def check_async_errors():

@@ -22,6 +22,17 @@ from dgr_amd import light as L
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["compiled", "ctypes"])
+def binding(request, monkeypatch):
+    """every test runs over the compiled torch extension (csrc/torch_ext.cpp: light_forward_batch / light_backward_batch) and
+    over the ctypes binding of the same C ABI"""
+    if request.param == "ctypes":
+        monkeypatch.setattr(L, "_C", L._CtypesC)
+    elif L._C is not L._CompiledC:
+        pytest.skip("compiled extension not built")
+    assert (B._ext() is not None) == (request.param == "compiled")
+
 IMAGES = ("color", "depth", "depth_median", "opacity_map")
 T, E = hh.T, hh.E
 
@@ -315,3 +326,31 @@ def test_a_batch_recorded_into_a_hipgraph_replays():
             os.environ.pop("DGR_SYNC_MODE", None)
         else:
             os.environ["DGR_SYNC_MODE"] = old
+
+
+def test_batch_at_baseline_config3_size():
+    """BASELINE config 3's Gaussians (500 k, 1920x1080, SH degree 3) from three cameras in one batch: every view bit-identical
+    to its one-view call (which tests/test_hip_light_parity.py holds against the oracle at this size), the summed gradients
+    equal to the one-view backward passes accumulated in view order."""
+    P, W, H, deg, V = 500000, 1920, 1080, 3, 3
+    ss = scenes(P, W, H, V, 0)
+    out, cams = batch_forward(ss, deg)
+    grads = [(s.gC, s.gD, s.gM, s.gV) for s in ss]
+    g = batch_backward(ss, deg, out, cams, grads)
+    acc = None
+    for v, s in enumerate(ss):
+        one, d1 = hh.hip_forward(s, deg)
+        ov = one_view_dict(out, v)
+        assert ov[0] == one[0] == d1["num_rendered"]
+        for k in (1, 2, 3, 5, 6, 11):
+            assert torch.equal(ov[k], one[k]), (v, k)
+        dv = {"num_rendered": ov[0], "geom": ov[7], "binning": ov[8], "img": ov[9]}
+        for name in ("ranges", "point_list", "n_contrib"):
+            assert np.array_equal(hh.hip_state(name, s, dv), hh.hip_state(name, s, d1)), (v, name)
+        g1 = hh.hip_backward(s, deg, one, grads=grads[v])
+        assert close(g["dL_dview"][v], g1["dL_dview"], 1e-5) and close(g["dL_dmeans2D"][v], g1["dL_dmeans2D"])
+        acc = {k: g1[k].copy() for k in g1} if acc is None else {k: acc[k] + g1[k] for k in g1}
+    if ss[0].view is not None:
+        assert out[0][0] == 1654310  # SURVEY.md Appendix C: num_rendered of config 3's view 0
+    for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations"):
+        assert close(g[k], acc[k]), k
