@@ -172,17 +172,21 @@ def _get(obj, name, default=None):
 
 def _matmul_fixed_order(a, b):
     """a @ b for [..., n, 4] @ [4, m] with the four products of every entry added in index order by elementwise kernels
-    (see _campos: the result must not depend on whether `a` is one matrix or a slice of a stack)."""
-    return ((a[..., :, 0:1] * b[0] + a[..., :, 1:2] * b[1]) + a[..., :, 2:3] * b[2]) + a[..., :, 3:4] * b[3]
+    (see _campos: the result must not depend on whether `a` is one matrix or a slice of a stack).  Four launches."""
+    r = a[..., :, 0:1] * b[0]
+    for k in (1, 2, 3):
+        r = torch.addcmul(r, a[..., :, k:k + 1], b[k])
+    return r
 
 
 def _campos(vm):
     """Camera centre -(R^T t) from viewmatrix = W2C^T ([4,4] or [V,4,4]), with the three products added in a fixed order
     by elementwise kernels: a `sum()` reduction picks its summation order from the tensor's layout and alignment, so the
-    same pose gave cameras one ulp apart as a [4,4] tensor and as a slice of a [V,4,4] one."""
-    r0, r1, r2 = vm[..., :3, 0], vm[..., :3, 1], vm[..., :3, 2]
-    t0, t1, t2 = vm[..., 3, 0:1], vm[..., 3, 1:2], vm[..., 3, 2:3]
-    return (-((r0 * t0 + r1 * t1) + r2 * t2)).contiguous()
+    same pose gave cameras one ulp apart as a [4,4] tensor and as a slice of a [V,4,4] one.  Three launches."""
+    nt = -vm[..., 3, 0:3]
+    r = vm[..., :3, 0] * nt[..., 0:1]
+    r = torch.addcmul(r, vm[..., :3, 1], nt[..., 1:2])
+    return torch.addcmul(r, vm[..., :3, 2], nt[..., 2:3]).contiguous()
 
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, viewmatrix=None, fov=None,
