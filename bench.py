@@ -399,8 +399,9 @@ def main():
                        "rccl_ranks": None if dist is None else dist.get_world_size(),
                        "rank_gpus": rank_gpus,
                        "gradient_allreduce": (None if dist is None else
-                                              f"one fused RCCL sum of 248 B/Gaussian per {G} local view(s)"
-                                              + ("" if G > 1 else f" ({args.allreduce})")),
+                                              (f"one fused RCCL sum of 248 B/Gaussian per {G} local view(s)"
+                                               + ("" if G > 1 else f" ({args.allreduce})")) if not Vb else
+                                              f"one fused RCCL sum of 248 B/Gaussian per batched step of {Vb} local views (blocking)"),
                        "view_hbm_frac": 0.83e9 * (316 * P + 566 * V + 172 * R + 72 * N) / (316 * 5e5 + 566 * 425824 + 172 * 1654310 + 72 * 2073600)
                                         * (views_per_s / world) / (HBM_PEAK_GBS * 1e9),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
