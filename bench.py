@@ -105,6 +105,7 @@ def main():
                          "Gaussians' gradients summed over the views in registers); value still counts views.  N>1: one fused "
                          "all-reduce per batch (BASELINE config 5's pattern)")
     ap.add_argument("--batch-streams", type=int, default=0, help="--batch: dgr_set_option('batch_streams') (0 = library default)")
+    ap.add_argument("--batch-order", type=int, default=-1, help="--batch: dgr_set_option('batch_order') (-1 = library default)")
     ap.add_argument("--group", type=int, default=0,
                     help="the comparison for --batch: the same views one call at a time, .grad accumulating over this many "
                          "views (autograd's `+=`) before it is reset -- what a mapping iteration over a keyframe batch does "
@@ -153,6 +154,8 @@ def main():
         _capi.set_option("tight_cull", 1)
     if args.batch_streams:
         _capi.set_option("batch_streams", args.batch_streams)
+    if args.batch_order >= 0:
+        _capi.set_option("batch_order", args.batch_order)
     P, W, H, deg = WORKLOADS[args.workload]
     s = make_scene(P, W, H, seed=0, view_index=rank)  # rank r renders view r of the same Gaussians
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731

@@ -315,6 +315,18 @@ int check_common(const FwdCommon& c) {
 // 0.380 / 0.391 / 0.407 -- one view's binning under another view's blend is the whole gain; more blend kernels at once
 // only take each other's L2 and wave slots.
 std::atomic<int> g_batch_streams{2};
+// dgr_set_option("batch_order", o): how the per-view stages of a batch are spread over the streams.
+//   0 (default) = round robin: view v's whole chain on stream v mod K ("batch_streams");
+//   1 = pipeline: the views' BINNING stages (count, scan, emit, sort -- kernels that leave most of the chip idle) one after the
+//       other on a helper stream, the views' BLEND stages one after the other on the caller's stream, view v's blend waiting
+//       for view v's binning with an event (the backward likewise: the next view's scratch cleared under the current blend).
+//       On paper binning v + 1 always runs under blend v and two VALU-bound blend kernels never share the chip; measured
+//       (profiles/batch_order.sh) it LOSES to the round robin at every size -- config 3, ms per view, pipeline / round robin:
+//       2 views 0.509 / 0.461, 4 views 0.468 / 0.417, 8 views 0.431 / 0.383; config 2: 0.193 / 0.156, 0.172 / 0.130,
+//       0.156 / 0.116 -- slower even than one stream (0.450 at 4 views): one cross-stream event wait per view each way costs more
+//       than the overlap it arranges (the same finding as round 1's high-priority companion stream).  Kept as the
+//       measured alternative.
+std::atomic<int> g_batch_order{0};
 constexpr int DGR_BATCH_MAX_STREAMS = 8;
 inline int batch_stream_count(int n_views) {
     const int kmax = std::max(1, std::min(g_batch_streams.load(), DGR_BATCH_MAX_STREAMS));
@@ -326,6 +338,7 @@ struct BatchStreams {
     hipStream_t helper[DGR_BATCH_MAX_STREAMS - 1] = {};
     hipEvent_t fork = nullptr;
     hipEvent_t join[DGR_BATCH_MAX_STREAMS - 1] = {};
+    hipEvent_t stage[DGR_MAX_BATCH_VIEWS] = {};  // pipelined order: view v's binning (forward) / cleared scratch (backward) is ready
 };
 thread_local BatchStreams g_batch;
 int batch_streams_ready() {
@@ -340,6 +353,7 @@ int batch_streams_ready() {
         HIP_TRY(hipEventCreateWithFlags(&g_batch.join[i], hipEventDisableTiming));
     }
     HIP_TRY(hipEventCreateWithFlags(&g_batch.fork, hipEventDisableTiming));
+    for (int v = 0; v < DGR_MAX_BATCH_VIEWS; v++) HIP_TRY(hipEventCreateWithFlags(&g_batch.stage[v], hipEventDisableTiming));
     g_batch.device = dev;
     return DGR_OK;
 }
@@ -754,10 +768,11 @@ int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* vie
         }
         { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd_batch(b, st)); }
     }
-    const int K = batch_stream_count(n_views);
+    const bool pipeline = g_batch_order.load() == 1 && n_views > 1 && g_batch_streams.load() > 1;
+    const int K = pipeline ? 2 : batch_stream_count(n_views);
     if ((rc = batch_fork(st, K))) return rc;
     for (int v = 0; v < n_views; v++) {
-        hipStream_t sv = batch_stream(st, v, K);
+        hipStream_t sv = pipeline ? g_batch.helper[0] : batch_stream(st, v, K);
         const int cap = views[v].binning_capacity;
         int mode = COUNT_LDS;
         if (!shared_front) {
@@ -765,9 +780,14 @@ int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* vie
             if ((rc = forward_front(cv[v], geom[v], img[v], sv, &bin[v], cap, views[v].image_buffer, mode))) return rc;
         }
         if ((rc = binning_stages(cv[v], geom[v], img[v], bin[v], cap, sv, mode, views[v].binning_buffer))) return rc;
+        if (pipeline) {  // the blend of view v on the caller's stream, behind its binning on the helper stream
+            HIP_TRY(hipEventRecord(g_batch.stage[v], sv));
+            HIP_TRY(hipStreamWaitEvent(st, g_batch.stage[v], 0));
+            sv = st;
+        }
         if ((rc = forward_back(cv[v], geom[v], img[v], bin[v], sv))) return rc;
     }
-    return batch_join(st, K);
+    return pipeline ? DGR_OK : batch_join(st, K);  // (pipeline: the helper's last kernel has been waited for already)
 }
 
 int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_grad* views, int P, int D, int M,
@@ -799,16 +819,22 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
     int rc;
     if ((rc = batch_streams_ready())) return rc;
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    const int K = batch_stream_count(n_views);
+    const bool pipeline = g_batch_order.load() == 1 && n_views > 1 && g_batch_streams.load() > 1;
+    const int K = pipeline ? 2 : batch_stream_count(n_views);
     dgr::PreprocessBwdBatchArgs bb{};
     if ((rc = batch_fork(st, K))) return rc;
     for (int v = 0; v < n_views; v++) {
         const dgr_light_view_grad& w = views[v];
-        hipStream_t sv = batch_stream(st, v, K);
+        hipStream_t sv = pipeline ? g_batch.helper[0] : batch_stream(st, v, K);
         dgr::GeometryView geom = dgr::carve_geometry(w.geometry_buffer, P);
         dgr::ImageView img = dgr::carve_image(w.image_buffer, width, height);
         dgr::BackwardScratch sc = dgr::carve_backward_scratch(w.scratch, P);
         { ScopedStage t(ST_ZERO, sv); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, sv)); }
+        if (pipeline) {  // the blend backward of view v on the caller's stream, behind its cleared scratch
+            HIP_TRY(hipEventRecord(g_batch.stage[v], sv));
+            HIP_TRY(hipStreamWaitEvent(st, g_batch.stage[v], 0));
+            sv = st;
+        }
         dgr::RenderBwdLightArgs r{};
         r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
         r.ranges = img.ranges; r.point_list = (const uint32_t*)w.binning_buffer; r.rec = geom.rec; r.bg = background;
@@ -822,7 +848,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
         q.radii = w.radii ? w.radii : geom.radii; q.geom = geom; q.acc = sc.acc; q.dL_dmean2D = w.dL_dmean2D;
         q.pose_part = sc.pose_part; q.ticket = sc.ticket; q.dL_dview = w.dL_dview;
     }
-    if ((rc = batch_join(st, K))) return rc;
+    if (!pipeline && (rc = batch_join(st, K))) return rc;
     dgr::PreprocessBwdArgs& b = bb.base;
     b.P = P; b.D = D; b.M = M; b.W = width; b.H = height; b.means3D = means3D; b.shs = shs; b.scales = scales;
     b.rotations = rotations; b.scale_modifier = scale_modifier; b.cov3D_precomp = cov3D_precomp;
@@ -1018,6 +1044,7 @@ int dgr_set_option(const char* name, int value) {
     if (n == "bwd_rows") { g_bwd_rows.store(value ? 1 : 0); return DGR_OK; }
     if (n == "lds_count") { g_lds_count.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
     if (n == "profile_every") { g_profile_every.store(value > 0 ? value : 1); return DGR_OK; }
+    if (n == "batch_order") { g_batch_order.store(value ? 1 : 0); return DGR_OK; }
     if (n == "batch_streams") { g_batch_streams.store(value < 1 ? 1 : value > DGR_BATCH_MAX_STREAMS ? DGR_BATCH_MAX_STREAMS : value); return DGR_OK; }
     g_last_error = "unknown option: " + n;
     return DGR_ERR_BAD_ARGUMENT;
@@ -1029,6 +1056,7 @@ int dgr_get_option(const char* name) {
     if (n == "lds_count") return g_lds_count.load();
     if (n == "profile_every") return g_profile_every.load();
     if (n == "batch_streams") return g_batch_streams.load();
+    if (n == "batch_order") return g_batch_order.load();
     return DGR_ERR_BAD_ARGUMENT;
 }
 

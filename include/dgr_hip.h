@@ -236,7 +236,9 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
  *     2 = LDS whenever the histogram fits; 0 = never.  Results are identical bit for bit.  dgr_binning_bytes() includes the
  *     LDS count's forward-only workspace.
  *  "profile_every": n >= 1 = dgr_profile_* brackets every n-th launch of the selected stage only (default 1).
- *  "batch_streams" (default 2): streams the batched entry points spread the per-view stages of a batch over (1..8). */
+ *  "batch_streams" (default 2): streams the batched entry points spread the per-view stages of a batch over (1..8).
+ *  "batch_order" (default 0): 0 = view v's binning + blend chain on stream v mod batch_streams; 1 = all binning stages on a
+ *     helper stream and all blend stages on the caller's, joined per view by events (measured slower: csrc/api.hip). */
 int dgr_set_option(const char* name, int value);
 int dgr_get_option(const char* name);
 
