@@ -291,7 +291,7 @@ def main():
     # events ride in the kernel's dispatch packet and cost a little of the overlap between streams when attached to
     # every launch
     _capi.profile_select(dominant)
-    _capi.set_option("profile_every", max(1, args.steps // 16))
+    _capi.set_option("profile_every", int(os.environ.get("DGR_BENCH_PROFILE_EVERY", max(1, args.steps // 16))))
 
     if args.graph:
         if dist is not None:
@@ -315,10 +315,15 @@ def main():
     _capi.profile_read(dominant)  # discard the events of the untimed passes
     t0 = time.perf_counter()
     radii = run(args.steps)
+    t_issue = time.perf_counter() - t0
     light.check_async_errors()  # status words of every timed step (lazy mode): raises if any forward was invalid
+    t_check = time.perf_counter() - t0
     drain()  # the last view's gradient sum completes inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("DGR_BENCH_TRACE") == "1" and rank == 0:
+        print(f"[trace] host issue of {args.steps} steps done at {t_issue * 1e3:.3f} ms, status checks at {t_check * 1e3:.3f} ms, "
+              f"GPU idle at {elapsed * 1e3:.3f} ms", file=sys.stderr)
     dom_tot, dom_n = _capi.profile_read(dominant)
     _capi.profile_select("")
 
