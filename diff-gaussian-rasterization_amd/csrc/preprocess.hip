@@ -846,24 +846,37 @@ __device__ __forceinline__ void cov3d_backward_terms(float3 sc, float4 q, float 
     drot.w = 2 * r * (dMt.m[0][1] - dMt.m[1][0]) + 2 * x * (dMt.m[2][0] + dMt.m[0][2]) + 2 * y * (dMt.m[1][2] + dMt.m[2][1]) - 4 * z * (dMt.m[1][1] + dMt.m[0][0]);
 }
 
-// Block reduction of the 12 pose terms and their delivery: wave64 butterfly, then the 4 waves through LDS.  In double: the sum
-// over 4e5 Gaussians cancels to ~1e-3 of its terms, so float partial sums would cost ~2e-5 of the result.
+// Block reduction of the 12 pose terms and their delivery.  The sum over 4e5 Gaussians cancels to ~1e-3 of its terms, so
+// everything beyond a 16-lane row is accumulated in double.
 // The block's partial goes into one of 64 bucket rows with double atomics performed at L2 (agent scope: no
 // cache to keep coherent), then the block takes a ticket; the block that draws the last ticket finds every
 // partial delivered and finishes the sum -- no separate reduction kernel, no fence that writes back an L2.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], double* pose_part, uint32_t* ticket, float* dL_dview,
                                                   double (*red)[12], uint32_t* s_ticket) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // Round 4: the 16 lanes of a DPP row are summed in float on the vector pipe (quad_perm ^1, ^2, row_half_mirror,
+    // row_mirror: four adds per value, every lane of the row ends up with the row's sum), the 16 row sums of the block in
+    // double by the delivering threads.  Sixteen float terms add nothing to the rounding the float terms already carry
+    // (each is a float product), and the 144 ds_bpermute + 72 double adds per wave of the all-double butterfly were 11 of
+    // this kernel's 52 us (measured with the reduction compiled out).
+    const int row = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        double v = (double)pose[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) red[wv][i] = v;
+        float v = pose[i];
+        v += dpp_row_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+        v += dpp_row_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+        v += dpp_row_mov<0x141>(v);  // row_half_mirror
+        v += dpp_row_mov<0x140>(v);  // row_mirror
+        if ((threadIdx.x & 15) == 0) red[row][i] = (double)v;
     }
     __syncthreads();
     if (threadIdx.x < 12) {
-        const double part = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) part += red[r][threadIdx.x];
         double* slot = pose_part + (size_t)(blockIdx.x % DGR_POSE_BUCKETS) * 12 + threadIdx.x;
         __hip_atomic_fetch_add(slot, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1033,11 +1046,14 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
         if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
     }
 
-    if (a.track_off) {  // no pose gradient asked for: zeros (L/rasterize_points.cu:186)
+#ifndef DGR_ABLATE_POSE
+#define DGR_ABLATE_POSE 0  // 1: measurement build without the pose reduction (wrong dL_dview, right cost of the rest)
+#endif
+    if (a.track_off || DGR_ABLATE_POSE) {  // no pose gradient asked for: zeros (L/rasterize_points.cu:186)
         if (blockIdx.x == 0 && threadIdx.x < 16) a.dL_dview[threadIdx.x] = 0.0f;
         return;
     }
-    __shared__ double red[4][12];
+    __shared__ double red[16][12];
     __shared__ uint32_t s_ticket;
     pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red, &s_ticket);
 }
@@ -1063,7 +1079,7 @@ __global__ void __launch_bounds__(256, DGR_BWD_BATCH_WAVES) preprocess_bwd_batch
     const int P = b.base.P, V = b.V;
     const bool in = idx < P;
     __shared__ float sht[4 * SHT_ROWS * SHT_LD];
-    __shared__ double red[4][12];
+    __shared__ double red[16][12];
     __shared__ uint32_t s_ticket;
     float3 m = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
