@@ -856,7 +856,7 @@ __device__ __forceinline__ float dpp_row_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
 __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], double* pose_part, uint32_t* ticket, float* dL_dview,
-                                                  double (*red)[12], uint32_t* s_ticket) {
+                                                  double (*red)[12]) {
     // Round 4: the 16 lanes of a DPP row are summed in float on the vector pipe (quad_perm ^1, ^2, row_half_mirror,
     // row_mirror: four adds per value, every lane of the row ends up with the row's sum), the 16 row sums of the block in
     // double by the delivering threads.  Sixteen float terms add nothing to the rounding the float terms already carry
@@ -873,6 +873,10 @@ __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], doubl
         if ((threadIdx.x & 15) == 0) red[row][i] = (double)v;
     }
     __syncthreads();
+    // The delivery is wave 0's alone (no workgroup barrier from here on): two L2 round trips -- the bucket adds, then the
+    // ticket -- during which the other three waves would only hold their registers; they leave (one-view kernel) or go on
+    // to the next view's loads (batched kernel, which alternates between two `red` buffers for that reason).
+    if (threadIdx.x >= 64) return;
     if (threadIdx.x < 12) {
         double part = 0.0;
 #pragma unroll
@@ -881,17 +885,17 @@ __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], doubl
         __hip_atomic_fetch_add(slot, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the adds are acknowledged before the ticket is taken
-    __syncthreads();
-    if (threadIdx.x == 0) *s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*s_ticket != gridDim.x - 1) return;
+    uint32_t t = 0u;
+    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t != gridDim.x - 1) return;
     if (threadIdx.x < 16) {
         float out = 0.0f;
         if (threadIdx.x < 12) {
-            double t = 0.0;
+            double tot = 0.0;
             for (int g = 0; g < DGR_POSE_BUCKETS; g++)  // (agent-scope loads: served by L2, where the adds were performed)
-                t += __hip_atomic_load(pose_part + (size_t)g * 12 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            out = (float)t;
+                tot += __hip_atomic_load(pose_part + (size_t)g * 12 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            out = (float)tot;
         }
         // slot order v0,v1,v2,v4,v5,v6,v8,v9,v10,v12,v13,v14 (L/cuda_rasterizer/backward.cu:723)
         if (threadIdx.x < 12) dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
@@ -1054,8 +1058,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
         return;
     }
     __shared__ double red[16][12];
-    __shared__ uint32_t s_ticket;
-    pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red, &s_ticket);
+    pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1079,8 +1082,7 @@ __global__ void __launch_bounds__(256, DGR_BWD_BATCH_WAVES) preprocess_bwd_batch
     const int P = b.base.P, V = b.V;
     const bool in = idx < P;
     __shared__ float sht[4 * SHT_ROWS * SHT_LD];
-    __shared__ double red[16][12];
-    __shared__ uint32_t s_ticket;
+    __shared__ double red[2][16][12];  // (two: wave 0 may still deliver view v while the others reduce view v + 1)
     float3 m = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
     float c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1150,7 +1152,7 @@ __global__ void __launch_bounds__(256, DGR_BWD_BATCH_WAVES) preprocess_bwd_batch
         if (a.track_off) {
             if (blockIdx.x == 0 && threadIdx.x < 16) a.dL_dview[threadIdx.x] = 0.0f;
         } else {
-            pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red, &s_ticket);
+            pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red[v & 1]);
         }
     }
     const int M = b.base.M;
