@@ -86,3 +86,6 @@ def test_batch_entry_points_reject_bad_view_counts_before_touching_the_gpu():
     assert lib.dgr_get_option(b"batch_streams") == 2
     assert lib.dgr_set_option(b"batch_streams", 1) == 0 and lib.dgr_get_option(b"batch_streams") == 1
     assert lib.dgr_set_option(b"batch_streams", 2) == 0
+    assert lib.dgr_get_option(b"batch_order") == 0
+    assert lib.dgr_set_option(b"batch_order", 1) == 0 and lib.dgr_get_option(b"batch_order") == 1
+    assert lib.dgr_set_option(b"batch_order", 0) == 0

@@ -354,3 +354,28 @@ def test_batch_at_baseline_config3_size():
         assert out[0][0] == 1654310  # num_rendered of config 3's view 0
     for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations"):
         assert close(g[k], acc[k]), k
+
+
+@pytest.mark.parametrize("option", [("batch_order", 1), ("batch_streams", 1), ("batch_streams", 4)])
+def test_stream_layout_options_do_not_change_a_batch(option):
+    """dgr_set_option("batch_order" / "batch_streams"): how a batch's per-view stages are spread over the internal streams
+    (round robin over K streams, or all binning on one stream and all blending on another) is a scheduling choice -- the
+    forward stays bit-identical, the gradients agree to the order of the float atomics."""
+    P, W, H, deg, V = 20000, 320, 200, 3, 5
+    ss = scenes(P, W, H, V, 0)
+    grads = [tuple(x * (W * H) ** 0.5 for x in (s.gC, s.gD, s.gM, s.gV)) for s in ss]
+    out0, cams = batch_forward(ss, deg)
+    g0 = batch_backward(ss, deg, out0, cams, grads)
+    keep = L._capi.get_option(option[0])
+    L._capi.set_option(*option)
+    try:
+        out1, cams1 = batch_forward(ss, deg)
+        g1 = batch_backward(ss, deg, out1, cams1, grads)
+    finally:
+        L._capi.set_option(option[0], keep)
+    for k in (1, 2, 3, 5, 6, 11):
+        assert torch.equal(out0[k], out1[k]), k
+    assert out0[0] == out1[0]
+    for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dmeans2D"):
+        assert close(g1[k], g0[k]), k
+    assert close(g1["dL_dview"], g0["dL_dview"], 1e-5)
