@@ -1067,8 +1067,9 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
 // radius, clamp bits and SH direction derivatives and runs the code of the one-view kernel (bwd_view_terms); position,
 // covariance, scale and rotation are read once; the covariance backward -- linear in dL_dcov3D -- runs once on the summed
 // dL_dcov3D.  A view's terms are formed exactly as the one-view kernel forms them and added in view order with FMA
-// contraction off, so dL_dmeans3D / dL_dsh / dL_dopacity / dL_dcov3D equal, bit for bit, what accumulating the one-view
-// outputs view after view (autograd's `.grad +=`) gives -- without the V dense 248-byte rows per Gaussian that costs.
+// contraction off, so -- for the same accumulator rows -- dL_dmeans3D / dL_dsh / dL_dopacity / dL_dcov3D are what accumulating
+// the one-view outputs view after view (autograd's `.grad +=`) gives, operation for operation, without the V dense 248-byte
+// rows per Gaussian that costs.
 // Pose gradients and dL_dmean2D (densification statistics) stay per view.  Light variant only.
 __device__ __forceinline__ PreprocessBwdArgs batch_view_args(const PreprocessBwdBatchArgs& b, int v) {
     PreprocessBwdArgs a = b.base;

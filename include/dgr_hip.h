@@ -260,8 +260,10 @@ int dgr_cov3d_backward(void* stream, int P, const float* scales, const float* ro
  *    fetched once and evaluated for every camera that sees the Gaussian;
  *  - backward: ONE per-Gaussian launch that sums the views' gradients of the shared Gaussians in registers and writes each
  *    dense row (248 bytes per Gaussian at SH degree 3) once instead of V times plus V - 1 accumulation passes; the covariance
- *    backward (linear in dL_dcov3D) runs once on the sum.  dL_dopacity / dL_dmean3D / dL_dsh / dL_dcov3D equal, bit for bit,
- *    the one-view outputs accumulated in view order; dL_dscale / dL_drot agree to rounding (converted once, not V times);
+ *    backward (linear in dL_dcov3D) runs once on the sum.  Given the same per-view accumulator rows, dL_dopacity / dL_dmean3D /
+ *    dL_dsh / dL_dcov3D are the one-view outputs accumulated in view order, operation for operation; dL_dscale / dL_drot agree
+ *    to rounding (converted once, not V times).  (Two runs of the blend backward -- batched or not -- leave accumulator rows
+ *    that differ by the arrival order of their float atomics, so two runs agree to ~1e-6 of a tensor's scale, not bitwise);
  *  - the per-view stages in between (binning and blend) are issued on internal streams forked from and joined to `stream`
  *    with events (option "batch_streams", 1..8, default 2: one view's binning runs under another view's blend);
  *  - no host synchronisation (hipGraph-capturable after one warm-up call, which creates the internal streams).
