@@ -855,13 +855,12 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_row_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
 }
-__device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], double* pose_part, uint32_t* ticket, float* dL_dview,
-                                                  double (*red)[12]) {
-    // Round 4: the 16 lanes of a DPP row are summed in float on the vector pipe (quad_perm ^1, ^2, row_half_mirror,
-    // row_mirror: four adds per value, every lane of the row ends up with the row's sum), the 16 row sums of the block in
-    // double by the delivering threads.  Sixteen float terms add nothing to the rounding the float terms already carry
-    // (each is a float product), and the 144 ds_bpermute + 72 double adds per wave of the all-double butterfly were 11 of
-    // this kernel's 52 us (measured with the reduction compiled out).
+// Step 1 (every wave): the 16 lanes of a DPP row are summed in float on the vector pipe (quad_perm ^1, ^2, row_half_mirror,
+// row_mirror: four adds per value, every lane of the row ends up with the row's sum) and the row sums go to LDS as doubles.
+// Sixteen float terms add nothing to the rounding the float terms already carry (each is a float product), and the 144
+// ds_bpermute + 72 double adds per wave of the all-double 64-lane butterfly this replaces were 11 of the one-view kernel's
+// 52 us (measured with the reduction compiled out).
+__device__ __forceinline__ void pose_rows_to_lds(const float (&pose)[12], double (*red)[12]) {
     const int row = threadIdx.x >> 4;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
@@ -872,11 +871,10 @@ __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], doubl
         v += dpp_row_mov<0x140>(v);  // row_mirror
         if ((threadIdx.x & 15) == 0) red[row][i] = (double)v;
     }
-    __syncthreads();
-    // The delivery is wave 0's alone (no workgroup barrier from here on): two L2 round trips -- the bucket adds, then the
-    // ticket -- during which the other three waves would only hold their registers; they leave (one-view kernel) or go on
-    // to the next view's loads (batched kernel, which alternates between two `red` buffers for that reason).
-    if (threadIdx.x >= 64) return;
+}
+// Step 2 (wave 0, after a workgroup barrier): the 16 row sums of the block in double, added to one of 64 bucket rows with
+// double atomics performed at L2 (agent scope: no cache to keep coherent).
+__device__ __forceinline__ void pose_add_partial(double (*red)[12], double* pose_part) {
     if (threadIdx.x < 12) {
         double part = 0.0;
 #pragma unroll
@@ -884,10 +882,10 @@ __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], doubl
         double* slot = pose_part + (size_t)(blockIdx.x % DGR_POSE_BUCKETS) * 12 + threadIdx.x;
         __hip_atomic_fetch_add(slot, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the adds are acknowledged before the ticket is taken
-    uint32_t t = 0u;
-    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+}
+// Step 3 (wave 0, once its adds are acknowledged and it has drawn ticket `t`): the block that draws the last ticket finds
+// every partial delivered and finishes the sum -- no separate reduction kernel, no fence that writes back an L2.
+__device__ __forceinline__ void pose_finish_if_last(uint32_t t, const double* pose_part, float* dL_dview) {
     if (t != gridDim.x - 1) return;
     if (threadIdx.x < 16) {
         float out = 0.0f;
@@ -901,6 +899,19 @@ __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], doubl
         if (threadIdx.x < 12) dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
         if (threadIdx.x < 4) dL_dview[threadIdx.x * 4 + 3] = 0.0f;
     }
+}
+// One view: the delivery is wave 0's alone (no workgroup barrier after the first): two L2 round trips -- the bucket adds,
+// then the ticket -- during which the other three waves would only hold their registers.
+__device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], double* pose_part, uint32_t* ticket, float* dL_dview,
+                                                  double (*red)[12]) {
+    pose_rows_to_lds(pose, red);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    pose_add_partial(red, pose_part);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the adds are acknowledged before the ticket is taken
+    uint32_t t = 0u;
+    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pose_finish_if_last((uint32_t)__builtin_amdgcn_readfirstlane((int)t), pose_part, dL_dview);
 }
 
 // Fused per-Gaussian backward.  Order of the dL_dmean3D accumulation follows the reference's kernel
@@ -1083,7 +1094,7 @@ __global__ void __launch_bounds__(256, DGR_BWD_BATCH_WAVES) preprocess_bwd_batch
     const int P = b.base.P, V = b.V;
     const bool in = idx < P;
     __shared__ float sht[4 * SHT_ROWS * SHT_LD];
-    __shared__ double red[2][16][12];  // (two: wave 0 may still deliver view v while the others reduce view v + 1)
+    __shared__ double red[DGR_MAX_BATCH_VIEWS][16][12];  // every view's row sums: ONE barrier behind the view loop
     float3 m = make_float3(0.f, 0.f, 0.f), sc_in = make_float3(0.f, 0.f, 0.f);
     float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
     float c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1153,7 +1164,7 @@ __global__ void __launch_bounds__(256, DGR_BWD_BATCH_WAVES) preprocess_bwd_batch
         if (a.track_off) {
             if (blockIdx.x == 0 && threadIdx.x < 16) a.dL_dview[threadIdx.x] = 0.0f;
         } else {
-            pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red[v & 1]);
+            pose_rows_to_lds(pose, red[v]);  // (no barrier inside the view loop: the waves run through it independently)
         }
     }
     const int M = b.base.M;
@@ -1191,6 +1202,21 @@ __global__ void __launch_bounds__(256, DGR_BWD_BATCH_WAVES) preprocess_bwd_batch
         }
     }
     if (blk_fast) lanes_to_sh_rows(dsh, b.base.dL_dsh, (size_t)blockIdx.x * 256, sht);
+    if (b.base.track_off) return;
+    // Pose gradients of all views: one barrier, then wave 0 adds every view's partial, waits once, draws every view's ticket
+    // (issued back to back: one L2 round trip for the batch) and finishes the views whose last block this is.
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+#pragma unroll 1
+    for (int v = 0; v < V; v++) pose_add_partial(red[v], b.v[v].pose_part);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t t = 0u;
+#pragma unroll 1
+    for (int v = 0; v < V; v++)
+        if ((int)threadIdx.x == v) t = __hip_atomic_fetch_add(b.v[v].ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+    for (int v = 0; v < V; v++)
+        pose_finish_if_last((uint32_t)__builtin_amdgcn_readlane((int)t, v), b.v[v].pose_part, b.v[v].dL_dview);
 }
 
 // ------------------------------------------------------------------------------------------------
