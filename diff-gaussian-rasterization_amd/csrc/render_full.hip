@@ -133,7 +133,7 @@ struct StagedBwdFull {
     int max_last;
 };
 
-__global__ void __launch_bounds__(256, 7) render_bwd_full_kernel(RenderBwdFullArgs a) {
+__global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullArgs a) {
     __shared__ StagedBwdFull sb;
     StagedT<BWD_NB>& s = sb.f;
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
