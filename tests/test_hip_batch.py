@@ -6,7 +6,7 @@ What is pinned:
     against the oracle), and the views are checked against the oracle directly as well;
   * the gradients of the Gaussians are the sum over the views: against the sum of the ORACLE's per-view backward passes
     (stage-isolated, flipped pixels masked, the bars of tests/test_hip_light_parity.py), and against the one-view HIP
-    backward accumulated in view order to 2e-6 of each tensor's scale (the per-Gaussian stage adds the views' terms in that
+    backward accumulated in view order to 1e-5 of each tensor's scale (measured <= 2e-6) (the per-Gaussian stage adds the views' terms in that
     order with the one-view kernel's operations; what is left is the order of the blend backward's float atomics, which
     differs between any two runs);
   * pose gradients and dL_dmeans2D stay per view.
@@ -37,9 +37,11 @@ IMAGES = ("color", "depth", "depth_median", "opacity_map")
 T, E = hh.T, hh.E
 
 
-def close(a, b, tol=2e-6):
+def close(a, b, tol=1e-5):
     """Two runs of the blend backward add their float atomics in different orders, so two backward passes agree to
-    rounding of the sums, not bit for bit: max |a - b| <= tol * max |b|."""
+    rounding of the sums, not bit for bit: max |a - b| <= tol * max |b|.  (Measured on these scenes: <= 2e-6; the bar leaves
+    room for the heavy tail tests/tools/soak_batch.py found on ill-conditioned Gaussians, where the one-view backward
+    differs from ITSELF by more.)"""
     a, b = (x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x) for x in (a, b))
     scale = float(np.abs(b).max())
     return float(np.abs(a.astype(np.float64) - b).max()) <= tol * scale + 1e-30
