@@ -113,11 +113,14 @@ std::atomic<int> g_profile_every{1};
 
 // dgr_set_option("tight_cull", 1): alpha-aware tile rectangles (preprocess.hip); process-wide, default off
 std::atomic<int> g_tight_cull{0};
-// dgr_set_option("bwd_rows", 1): light mapping backward with one 4x4 block per 16-lane row (render_light_rows.hip)
-// instead of one 8x8 quadrant per wave (render_light.hip, the default).  Measured 4 % faster on the backward and 7 %
-// slower on the forward that has to produce the 16-bit tags: off by default, kept for A/B runs.
-// Set it before the forward whose backward should use it.
-std::atomic<int> g_bwd_rows{0};
+// dgr_set_option("fast_alpha", v): how the blend kernels evaluate alpha and T / (1 - alpha) (csrc/render_common.h).
+//   0 (default) = the reference's expression with the host library's bits (exp_ref / div_ref, csrc/exact_math.h): alpha image,
+//       n_contrib and median depth bit-identical to the CPU restatement, gradients within 1e-5 of it;
+//   1 = log2(e)-scaled conic, one v_exp_f32, v_rcp_f32: every operation good to an ulp, but the light backward's
+//       T_final = 1 - alpha and its divisions by (1 - alpha) amplify the last-bit differences to 6e-5 abs at config 3.
+// Set it before the forward whose backward should use it (forward and backward of a view must use the same mode).
+// Initial value from DGR_FAST_ALPHA (for A/B runs).
+std::atomic<int> g_alpha_mode{[] { const char* e = getenv("DGR_FAST_ALPHA"); return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0; }()};
 // dgr_set_option("lds_count", v): how the forward counts tile instances (csrc/binning.hip).
 //   1 (default) = in per-workgroup LDS histograms when the frame's histogram fits LDS and the binning buffer holds at most
 //       DGR_LDS_COUNT_AUTO_MAX instances; larger jobs count with returning global atomics on per-tile counters (round 2's
@@ -275,8 +278,8 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
     r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background; r.gt_depth = c.gt_depth;
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_median = c.out_median_depth; r.out_alpha = c.out_alpha;
     r.out_depth_var = c.out_depth_var; r.n_contrib = img.n_contrib; r.gau_uncertainty = c.gau_uncertainty;
-    r.gau_related_pixels = c.gau_related_pixels; r.tags16 = g_bwd_rows.load() ? bin.tags16 : nullptr;
-    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_light(r, st)); }
+    r.gau_related_pixels = c.gau_related_pixels;
+    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_light(r, g_alpha_mode.load(), st)); }
     return DGR_OK;
 }
 
@@ -290,7 +293,7 @@ int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryV
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_uncertainty = out_uncertainty;
     r.n_contrib = img.n_contrib; r.n_valid = img.n_valid; r.first_contrib = img.first_contrib; r.final_T = img.final_T;
     r.status = img.status;
-    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_full(r, st)); }
+    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_full(r, g_alpha_mode.load(), st)); }
     return DGR_OK;
 }
 
@@ -552,14 +555,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     r.gt_depth = gt_depth; r.alphas = alphas; r.n_contrib = img.n_contrib; r.dL_dpix = dL_dpix;
     r.dL_dpix_depth = dL_dpix_depth; r.dL_dpix_median = dL_dpix_median_depth; r.dL_dpix_var = dL_dpix_depth_var;
     r.means3D = means3D; r.view = viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
-    r.binning_base = binning_buffer; r.capacity = img.cursor + 2;
-    // mapping modes: one 4x4 block per 16-lane row, raw moments out (preprocess_bwd finishes them); tracking (map_off)
-    // needs three sums only and keeps the quadrant kernel's 4-value butterfly
-    const bool rows = !map_off && g_bwd_rows.load() != 0;
-    {
-        ScopedStage t(ST_RENDER_BWD, st);
-        HIP_TRY(rows ? dgr::launch_render_bwd_light_rows(r, st) : dgr::launch_render_bwd_light(r, st));
-    }
+    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_light(r, g_alpha_mode.load(), st)); }
 
     dgr::PreprocessBwdArgs b{};
     b.P = P; b.D = D; b.M = M; b.W = width; b.H = height; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs;
@@ -569,7 +565,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     b.focal_y = height / (2.0f * tan_fovy);
     b.focal_x = width / (2.0f * tan_fovx);
     b.sh_vec_ok = aligned16(shs) && aligned16(dL_dsh);
-    b.track_off = track_off; b.map_off = map_off; b.geom = geom; b.acc = sc.acc; b.acc_raw = rows ? 1 : 0;
+    b.track_off = track_off; b.map_off = map_off; b.geom = geom; b.acc = sc.acc;
     b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor;
     b.dL_ddepth = dL_ddepth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
     b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part; b.ticket = sc.ticket; b.dL_dview = dL_dview;
@@ -689,7 +685,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     r.ranges = img.ranges; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
     r.gt_depth = gt_depth; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.first_contrib = img.first_contrib;
     r.dL_dpix = dL_dpix; r.dL_depths = dL_depths; r.dL_duncertainties = dL_duncertainties; r.acc = sc.acc;
-    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_full(r, st)); }
+    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_full(r, g_alpha_mode.load(), st)); }
 
     dgr::PreprocessBwdArgs b{};
     b.P = P; b.D = D; b.M = M; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs; b.scales = scales;
@@ -841,8 +837,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
         r.gt_depth = w.gt_depth; r.alphas = w.alphas; r.n_contrib = img.n_contrib; r.dL_dpix = w.dL_dpix;
         r.dL_dpix_depth = w.dL_dpix_depth; r.dL_dpix_median = w.dL_dpix_median_depth; r.dL_dpix_var = w.dL_dpix_depth_var;
         r.means3D = means3D; r.view = w.viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
-        r.binning_base = w.binning_buffer; r.capacity = img.cursor + 2;
-        { ScopedStage t(ST_RENDER_BWD, sv); HIP_TRY(dgr::launch_render_bwd_light(r, sv)); }
+        { ScopedStage t(ST_RENDER_BWD, sv); HIP_TRY(dgr::launch_render_bwd_light(r, g_alpha_mode.load(), sv)); }
         dgr::BwdViewPart& q = bb.v[v];
         q.view = w.viewmatrix; q.proj = w.projmatrix; q.campos = w.cam_pos; q.perspec = w.perspec_matrix;
         q.radii = w.radii ? w.radii : geom.radii; q.geom = geom; q.acc = sc.acc; q.dL_dmean2D = w.dL_dmean2D;
@@ -879,16 +874,17 @@ int dgr_cov3d_backward(void* stream, int P, const float* scales, const float* ro
     return DGR_OK;
 }
 
-int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4) {
-    HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out4, comp16, comp4, false, (hipStream_t)stream));
+int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12,
+                          int* comp4) {
+    HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out12, out4, comp16, comp12, comp4, (hipStream_t)stream));
     return DGR_OK;
 }
-int dgr_debug_wave_reduce_d(void* stream, const float* in, float* out16, float* out12, int* comp16, int* comp12) {
-    HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out12, comp16, comp12, true, (hipStream_t)stream));
-    return DGR_OK;
-}
-int dgr_debug_row_reduce(void* stream, const float* in, float* out, int* comp) {
-    HIP_TRY(dgr::launch_row_reduce_test(in, out, comp, (hipStream_t)stream));
+int dgr_debug_exact_math(void* stream, int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div) {
+    if (n < 0 || (n > 0 && (!x || !a || !b || !out_exp || !out_div))) {
+        g_last_error = "dgr_debug_exact_math: bad argument";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
+    HIP_TRY(dgr::launch_exact_math_test(n, x, a, b, out_exp, out_div, (hipStream_t)stream));
     return DGR_OK;
 }
 
@@ -1041,7 +1037,14 @@ int dgr_early_status_wait(int* host_status4) {
 int dgr_set_option(const char* name, int value) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }
-    if (n == "bwd_rows") { g_bwd_rows.store(value ? 1 : 0); return DGR_OK; }
+    if (n == "fast_alpha") {
+#ifdef DGR_ALPHA_EXPERIMENT
+        g_alpha_mode.store(value < 0 ? 0 : value > 3 ? 3 : value);
+#else
+        g_alpha_mode.store(value ? 1 : 0);
+#endif
+        return DGR_OK;
+    }
     if (n == "lds_count") { g_lds_count.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
     if (n == "profile_every") { g_profile_every.store(value > 0 ? value : 1); return DGR_OK; }
     if (n == "batch_order") { g_batch_order.store(value ? 1 : 0); return DGR_OK; }
@@ -1052,7 +1055,7 @@ int dgr_set_option(const char* name, int value) {
 int dgr_get_option(const char* name) {
     const std::string n(name ? name : "");
     if (n == "tight_cull") return g_tight_cull.load();
-    if (n == "bwd_rows") return g_bwd_rows.load();
+    if (n == "fast_alpha") return g_alpha_mode.load();
     if (n == "lds_count") return g_lds_count.load();
     if (n == "profile_every") return g_profile_every.load();
     if (n == "batch_streams") return g_batch_streams.load();
@@ -1138,7 +1141,6 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
         }
         return num_rendered;
     }
-    if (n == "contribution_tags16") return copy(bin.tags16, 2 * (size_t)num_rendered) ? -1 : num_rendered;
     if (n == "keys") {
         hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)tiles), dim3(256), 0, st, img, bin, g, (uint64_t*)dst);
         if (hipGetLastError() != hipSuccess) return -1;

@@ -403,23 +403,17 @@ __global__ void __launch_bounds__(CL_THREADS) scan_table_kernel(ImageView img, u
 // __shfl_xor (ds_bpermute: the LDS crossbar, no bank conflicts, no barrier): all 21 steps of sizes 2..64.  Larger
 // merge stages do their cross-wave steps (distance >= 64) on the LDS array with a barrier each, then return to
 // registers for distances 32..1.  n = 256 costs 7 barriers instead of the 36 of a plain LDS network.
-#ifndef DGR_ABLATE_SORT
-#define DGR_ABLATE_SORT 0  // measurement builds (profiles/sort_ablate.sh; wrong order, right cost of what is left):
-#endif                     //   1 = no register compare-exchange steps, 2 = also no LDS merge stages
 // Partner exchange lane ^ MASK.  Inside a 16-lane row the DPP network does it on the vector pipe (quad_perm for 1, 2, 3;
 // row_half_mirror = ^7, row_mirror = ^15; ^4 = ^7 then ^3, ^8 = ^15 then ^7): 26 of the 33 compare-exchange steps of a 256-key
 // tile.  ds_bpermute -- the LDS crossbar, which the four SIMDs of a CU share -- is left with the 7 steps that cross rows (16, 31,
-// 32, 63).  Measured (profiles/sort_ablate.sh): the register steps were 20 of the kernel's 30 us and bound by that crossbar.
-#ifndef DGR_SORT_DPP
-#define DGR_SORT_DPP 1  // 0: every exchange through ds_bpermute (round 1's form, kept for A/B)
-#endif
+// 32, 63).  Measured in round 2 (every exchange through ds_bpermute): the register steps were 20 of the kernel's 30 us and
+// bound by that crossbar.
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_mov(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
 template <int MASK>
 __device__ __forceinline__ unsigned xor_lane32(unsigned v) {
-#if DGR_SORT_DPP
     if constexpr (MASK == 1) return dpp_mov<0xB1>(v);        // quad_perm [1,0,3,2]
     else if constexpr (MASK == 2) return dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
     else if constexpr (MASK == 3) return dpp_mov<0x1B>(v);   // quad_perm [3,2,1,0]
@@ -427,15 +421,10 @@ __device__ __forceinline__ unsigned xor_lane32(unsigned v) {
     else if constexpr (MASK == 15) return dpp_mov<0x140>(v); // row_mirror
     else if constexpr (MASK == 4) return dpp_mov<0x1B>(dpp_mov<0x141>(v));
     else if constexpr (MASK == 8) return dpp_mov<0x141>(dpp_mov<0x140>(v));
-    else
-#endif
-        return (unsigned)__shfl_xor(v, MASK, 64);
+    else return (unsigned)__shfl_xor(v, MASK, 64);
 }
 template <int MASK, int LOWBIT>
 __device__ __forceinline__ uint64_t cmpx(uint64_t v, int lane) {
-#if DGR_ABLATE_SORT >= 1
-    return v;
-#endif
     const uint64_t o = ((uint64_t)xor_lane32<MASK>((unsigned)(v >> 32)) << 32) | xor_lane32<MASK>((unsigned)v);
     const bool lower = (lane & LOWBIT) == 0;  // this lane holds the lower index of the pair
     return (lower == (v < o)) ? v : o;         // lower keeps the minimum, upper the maximum
@@ -506,7 +495,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_tiles_kernel(ImageView img,
     }
     __syncthreads();
     const int half = np2 >> 1;
-    for (int size = 128; size <= (DGR_ABLATE_SORT >= 2 ? 0 : np2); size <<= 1) {
+    for (int size = 128; size <= np2; size <<= 1) {
         {  // flip across the `size` block (distance >= 64 for every pair once the chunks are sorted ... not always:
            // pairs i <-> blk*size + size-1-off span all distances, so this step runs on the LDS array)
             const int hs = size >> 1;

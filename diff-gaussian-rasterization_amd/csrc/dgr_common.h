@@ -66,7 +66,7 @@ struct ImageView {
     int* status;          // [4] {num_rendered, overflow, prefiltered violation, reserved}
     uint32_t* cursor;     // [3] presized path: {instances handed out so far (preprocess_fwd's blocks bump it to place their
                           //     ranks), prefiltered violation seen}; cleared together with the tile counters.
-                          //     [2] = capacity the binning buffer was carved with (scan_tiles; the backward finds tags16 with it)
+                          //     [2] = capacity the binning buffer was carved with (scan_tiles)
     uint32_t* tile_count; // [tiles * DGR_COUNT_STRIDE] instances per tile (histogram filled by count_rank), one per line
     uint2* ranges;        // [tiles] {start, end} into point_list
     uint32_t* n_contrib;  // [N]
@@ -98,8 +98,6 @@ struct BinningView {
                            //       backward can find it without knowing the capacity
     uint64_t* keys;        // [cap] (depth bits << 32 | gaussian id), grouped by tile, unsorted (sort_tiles reads them)
     uint32_t* ranks;       // [cap] Gaussian-major: arrival rank of each instance within its tile (count_rank -> emit)
-    uint16_t* tags16;      // [cap] light forward: bit 4 w + r set <=> some pixel of the 4x4 block r of quadrant w blended
-                           //       the instance (r = 2 (y / 4) + x / 4 inside the quadrant); the backward's row lists
     size_t bytes;
 };
 __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
@@ -108,7 +106,6 @@ __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
     b.point_list = (uint32_t*)(base + o); o = align_up(o + 4 * cap, 256);
     b.keys = (uint64_t*)(base + o);       o = align_up(o + 8 * cap, 256);
     b.ranks = (uint32_t*)(base + o);      o = align_up(o + 4 * cap, 256);
-    b.tags16 = (uint16_t*)(base + o);     o = align_up(o + 2 * cap, 256);
     b.bytes = o;
     return b;
 }

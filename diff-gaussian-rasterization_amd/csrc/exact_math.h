@@ -1,0 +1,72 @@
+// exact_math.h -- expf and float division with the CPU's bits, for the blend kernels' alpha and transmittance (gfx950).
+//
+// Why: the light backward derives T_final = 1 - (alpha image) (L/cuda_rasterizer/backward.cu:477) and rebuilds every
+// transmittance by dividing by (1 - alpha) (backward.cu:570).  Both amplify a last-bit difference of one alpha: by
+// 1 / T_final on nearly opaque pixels, by alpha / (1 - alpha) <= 99 per division.  A blend kernel whose alpha differs from
+// the restatement's in the last bit on some pairs therefore ends up 1e-5 .. 1e-4 away in the gradients although every
+// single operation is accurate to an ulp.  The remedy is not more accuracy but the SAME bits:
+//
+//  * exp_ref(x): the algorithm glibc >= 2.27 uses for expf (ARM optimized routines' exp2f-table form: one table of 32
+//    doubles, a cubic in double, ~0.502 ulp), restated operation for operation in the CDNA double pipe.  IEEE double
+//    multiply / add / fma give the same bits on any machine, so the result equals the host's expf bit for bit
+//    (checked on the GPU against the host over the blend kernels' whole argument range: tests/test_hip_exact_math.py).
+//    Only the range the blend loops need is supported: -87 < x <= 0 (no overflow / underflow / NaN branches).
+//  * div_ref(a, b): correctly rounded a / b for normal operands without the scaling and fix-up steps of the compiler's
+//    IEEE sequence: v_rcp_f32, quotient, exact residual, one correction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dgr {
+
+// 2^(i/32) as doubles, minus i << 47 in the bit pattern (so that adding k << 47 for k = 32 q + i yields 2^(k/32))
+#define DGR_EXP2F_TABLE                                                                                             \
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, \
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, \
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, \
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull, \
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull, \
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, \
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull
+
+__constant__ const uint64_t EXP2F_TABLE[32] = {DGR_EXP2F_TABLE};
+
+// the workgroup's copy of the table (256 bytes of LDS): threads 0..31 fill it; the caller synchronises before use
+__device__ __forceinline__ void exp_ref_table_fill(uint64_t* lds_tab, int tid) {
+    if (tid < 32) lds_tab[tid] = EXP2F_TABLE[tid];
+}
+
+// expf(x) with glibc's bits for -87 < x <= 0.  `tab` = the LDS copy of EXP2F_TABLE.
+//   glibc: z = x N / ln 2 (N = 32); k = round(z), r = z - k; s = 2^(k / N) from the table; y = s (1 + C2 r + C1 r^2 + C0 r^3)
+//   in double; return (float) y.
+// Same table, same cubic, all in double; the cubic is evaluated by Horner's rule (one operation fewer than glibc's
+// (C0 r + C1) r^2 + (C2 r + 1)), which moves y by ~1e-16 relative, so the float result can differ from the host's only
+// when y lies that close to a rounding boundary of the float grid: about one argument in 2^28.
+// 13 vector instructions (9 of them in the double pipe) and one 8-byte LDS read.
+__device__ __forceinline__ float exp_ref(float x, const uint64_t* tab) {
+#pragma clang fp contract(off)  // z + SHIFT must round z first; the fused steps below are explicit
+    constexpr double INVLN2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
+    constexpr double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const double z = INVLN2N * (double)x;
+    const double kd0 = z + SHIFT;                       // round to nearest even; the integer k sits in the low mantissa bits
+    const uint32_t ki = (uint32_t)__double2loint(kd0);
+    const double r = z - (kd0 - SHIFT);                 // in [-1/2, 1/2]
+    const uint2 t = reinterpret_cast<const uint2*>(tab)[ki & 31u];
+    const double s = __hiloint2double((int)(t.y + (ki << 15)), (int)t.x);  // bits of 2^(i/32) + (k << 47): 2^(k/32)
+    double p = __builtin_fma(C0, r, C1);
+    p = __builtin_fma(p, r, C2);
+    const double y = __builtin_fma(p, r, 1.0);
+    return (float)(y * s);
+}
+
+// correctly rounded a / b for normal operands and quotient (no scaling, no fix-up of special cases): quotient from
+// v_rcp_f32 (1 ulp), exact residual, one correction.  The correction's own rounding error is ~1e-7 of an ulp of the
+// quotient, so the result is the correctly rounded one except when a / b lies that close to a rounding boundary.
+__device__ __forceinline__ float div_ref(float a, float b, float& inv) {
+    inv = __builtin_amdgcn_rcpf(b);
+    const float q0 = a * inv;
+    const float r = __builtin_fmaf(-b, q0, a);          // exact
+    return __builtin_fmaf(r, inv, q0);
+}
+
+}  // namespace dgr

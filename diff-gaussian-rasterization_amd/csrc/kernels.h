@@ -110,8 +110,6 @@ struct PreprocessBwdArgs {
                         //    dgc_dCampos / colour-only ndc sums / front-most depth sums); 0: light
     GeometryView geom;
     const float* acc;   // [P,16] sums written by the blend backward
-    int acc_raw;        // 1: components 4..9 are the raw moments {Sx, Sy, Sxx, Sxy, Syy, S0} of q over the pixel offsets
-                        //    (render_light_rows.hip); the conic / opacity / ndc factors are applied here.  0: finished values
     float* dL_dmean2D;  // [P,3]
     float* dL_dconic;   // [P,4] optional
     float* dL_dopacity; // [P]
@@ -161,7 +159,6 @@ struct RenderFwdLightArgs {
     uint32_t* n_contrib;
     float* gau_uncertainty;
     int* gau_related_pixels;
-    uint16_t* tags16;  // [R] 16-bit contribution tags (one bit per 4x4 pixel block), next to the 4-bit tags in point_list
 };
 
 struct RenderBwdLightArgs {
@@ -181,8 +178,6 @@ struct RenderBwdLightArgs {
     const float* view;
     float* acc;  // [P,16]
     int track_off, map_off;
-    const char* binning_base;    // rows kernel: tags16 lives in the binning buffer behind a capacity-dependent offset;
-    const uint32_t* capacity;    // the capacity is read on the device (ImageView::cursor[2])
 };
 
 struct RenderFwdFullArgs {
@@ -266,14 +261,14 @@ hipError_t launch_scan_table(int P, GeometryView geom, ImageView img, CountTable
                              hipStream_t stream);
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);
 
-hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream);
-hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stream);
-// rows variant (render_light_rows.hip): returns true in *raw when it ran and left raw moments in acc (mapping modes)
-hipError_t launch_render_bwd_light_rows(const RenderBwdLightArgs& a, hipStream_t stream);
-hipError_t launch_row_reduce_test(const float* in, float* out, int* comp, hipStream_t stream);
-hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, hipStream_t stream);
-hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, hipStream_t stream);
-hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, bool with_d,
+// alpha_mode: render_common.h (0 = ALPHA_REF, the reference's bits; 1 = ALPHA_FAST)
+hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, hipStream_t stream);
+hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, int alpha_mode, hipStream_t stream);
+hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hipStream_t stream);
+hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream);
+hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12, int* comp4,
                                    hipStream_t stream);
+hipError_t launch_exact_math_test(int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div,
+                                  hipStream_t stream);
 
 }  // namespace dgr

@@ -17,9 +17,6 @@
 
 #include "kernels.h"
 #include "count_rank.h"
-#ifndef DGR_ABLATE_SHD
-#define DGR_ABLATE_SHD 0  // 1 / 2: measurement builds (derivatives not stored / not computed)
-#endif
 
 #pragma clang fp contract(off)
 #ifndef DGR_BWD_BATCH_WAVES
@@ -429,20 +426,11 @@ __device__ __forceinline__ void fwd_view_colour(const PreprocessFwdArgs& a, int 
         // d(colour)/d(direction) (L/cuda_rasterizer/backward.cu:50-133), kept for the backward: it is all the
         // backward needs of the SH coefficients beyond the basis values, which depend on the direction alone
         float3 dRGBdx = make_float3(0, 0, 0), dRGBdy = make_float3(0, 0, 0), dRGBdz = make_float3(0, 0, 0);
-#if DGR_ABLATE_SHD != 2
         sh_direction_derivatives(s, a.D, dir, dRGBdx, dRGBdy, dRGBdz);
-#endif
-#if DGR_ABLATE_SHD == 1
-        float4* shd = a.geom.shd + (size_t)(a.P < 0 ? idx : 0);
-        if (dRGBdx.x == 12345.f)
-#else
         float4* shd = a.geom.shd + (size_t)idx;  // three planes of P float4: consecutive lanes store consecutive 16-byte pieces
-#endif
-        {
-            shd[0] = make_float4(dRGBdx.x, dRGBdx.y, dRGBdx.z, 0.0f);
-            shd[(size_t)a.P] = make_float4(dRGBdy.x, dRGBdy.y, dRGBdy.z, 0.0f);
-            shd[2 * (size_t)a.P] = make_float4(dRGBdz.x, dRGBdz.y, dRGBdz.z, 0.0f);
-        }
+        shd[0] = make_float4(dRGBdx.x, dRGBdx.y, dRGBdx.z, 0.0f);
+        shd[(size_t)a.P] = make_float4(dRGBdy.x, dRGBdy.y, dRGBdy.z, 0.0f);
+        shd[2 * (size_t)a.P] = make_float4(dRGBdz.x, dRGBdz.y, dRGBdz.z, 0.0f);
     }
     a.geom.clamped[idx] = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
     rgb = make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
@@ -951,29 +939,11 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
         }
         const uint8_t cl_in = a.geom.clamped[idx];
         const float4 shd0 = a.geom.shd[idx], shd1 = a.geom.shd[(size_t)a.P + idx], shd2 = a.geom.shd[2 * (size_t)a.P + idx];
-        float4 r0_in = make_float4(0.f, 0.f, 0.f, 1.f), r1_in = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.acc_raw) {
-            r0_in = a.geom.rec[3 * (size_t)idx];
-            r1_in = a.geom.rec[3 * (size_t)idx + 1];
-        }
         const bool vis = rad > 0;
         float acc[16];
         if (vis) {
             acc[0] = a0.x; acc[1] = a0.y; acc[2] = a0.z; acc[3] = a0.w; acc[4] = a1.x; acc[5] = a1.y; acc[6] = a1.z; acc[7] = a1.w;
             acc[8] = a2.x; acc[9] = a2.y; acc[10] = a2.z; acc[11] = a2.w; acc[12] = a3.x; acc[13] = a3.y; acc[14] = a3.z; acc[15] = a3.w;
-            if (a.acc_raw) {
-                // the rows blend kernel leaves raw moments of q = o G dL/dalpha over the pixel offsets; the factors that
-                // depend on the Gaussian alone are applied here (L/cuda_rasterizer/backward.cu:627-631, 669-678):
-                //   dL/dmean2D = -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2;  dL/dconic = -S../2;  dL/dopacity = S0 / o
-                const float4 r0 = r0_in, r1 = r1_in;
-                const float Sx = acc[4], Sy = acc[5];
-                acc[4] = -(r1.x * Sx + r1.y * Sy) * (0.5f * a.W);
-                acc[5] = -(r1.z * Sy + r1.y * Sx) * (0.5f * a.H);
-                acc[6] *= -0.5f;
-                acc[7] *= -0.5f;
-                acc[8] *= -0.5f;
-                acc[9] = (acc[9] != 0.0f) ? acc[9] / r0.w : 0.0f;
-            }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.0f;
@@ -1061,10 +1031,7 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
         if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
     }
 
-#ifndef DGR_ABLATE_POSE
-#define DGR_ABLATE_POSE 0  // 1: measurement build without the pose reduction (wrong dL_dview, right cost of the rest)
-#endif
-    if (a.track_off || DGR_ABLATE_POSE) {  // no pose gradient asked for: zeros (L/rasterize_points.cu:186)
+    if (a.track_off) {  // no pose gradient asked for: zeros (L/rasterize_points.cu:186)
         if (blockIdx.x == 0 && threadIdx.x < 16) a.dL_dview[threadIdx.x] = 0.0f;
         return;
     }

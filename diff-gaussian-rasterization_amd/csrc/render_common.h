@@ -4,6 +4,7 @@
 #include "dgr_common.h"
 #include "kernels.h"
 #include "wave_reduce.h"
+#include "exact_math.h"
 
 namespace dgr {
 
@@ -12,22 +13,45 @@ __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballo
 
 namespace {
 
-constexpr float LOG2E = 1.4426950408889634f;
-// DGR_EXACT_ALPHA = 1 is a MEASUREMENT build (profiles/exact_alpha.sh, tests/test_hip_error_budget.py), never shipped: the
-// blend kernels then evaluate alpha as the reference writes it -- power = -0.5 (a dx dx + c dy dy) - b dx dy in that
-// association, o * expf(power), T / (1 - alpha) with IEEE division -- instead of o * 2^p2 with a conic pre-scaled by
-// log2(e) (one v_exp_f32) and v_rcp_f32.  It exists to separate how much of the end-to-end gradient error comes from the
-// fast alpha path and how much is inherent.
-#ifndef DGR_EXACT_ALPHA
-#define DGR_EXACT_ALPHA 0
-#endif
-constexpr float PSCALE = DGR_EXACT_ALPHA ? 1.0f : LOG2E;           // scale of the staged conic
-constexpr float PUNSCALE = DGR_EXACT_ALPHA ? 1.0f : 0.6931471805599453f;  // its inverse (ln 2)
-__device__ __forceinline__ float alpha_raw(float o, float p2) {     // o G
-    return DGR_EXACT_ALPHA ? o * expf(p2) : o * __builtin_amdgcn_exp2f(p2);
-}
-__device__ __forceinline__ float recip(float x) { return DGR_EXACT_ALPHA ? 1.0f / x : __builtin_amdgcn_rcpf(x); }
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr float ALPHA_MIN = 15.0f / 255.0f;  // forward.cu:365
+
+// How the blend kernels evaluate alpha = min(0.99, o exp(power)) and T / (1 - alpha)  (exact_math.h):
+//   ALPHA_REF  (default): the reference's expression in the reference's association (forward.cu:354-364,
+//       backward.cu:561-570), expf with the host library's bits (exp_ref), correctly rounded division (div_ref).  The
+//       light backward amplifies a last-bit difference of one alpha by 1 / T_final and by alpha / (1 - alpha) per
+//       division, so agreement with the CPU restatement to 1e-5 needs the same BITS, not merely the same accuracy.
+//   ALPHA_FAST (dgr_set_option("fast_alpha", 1)): the conic pre-scaled by log2(e), power from two fused multiply-adds,
+//       one v_exp_f32, v_rcp_f32 -- every operation accurate to an ulp, gradients up to 6e-5 abs away at config 3.
+enum { ALPHA_REF = 0, ALPHA_FAST = 1, ALPHA_HILO = 2, ALPHA_OCML = 3 };
+template <int AM>
+struct AlphaPath {
+    static constexpr bool LOG2 = (AM == ALPHA_FAST);               // staged conic scaled by log2(e): p2 = log2(e) power
+    static constexpr float PSCALE = LOG2 ? LOG2E : 1.0f;
+    static constexpr float PUNSCALE = LOG2 ? LN2 : 1.0f;
+    static constexpr bool TABLE = (AM == ALPHA_REF);               // needs the workgroup's copy of EXP2F_TABLE
+};
+// o G for one pair: alpha before the 0.99 clamp.  p2 = pair_p2<AM>(); `tab` = LDS copy of EXP2F_TABLE (ALPHA_REF only)
+template <int AM>
+__device__ __forceinline__ float alpha_raw(float o, float p2, const uint64_t* tab) {
+    if (AM == ALPHA_FAST) return o * __builtin_amdgcn_exp2f(p2);
+    if (AM == ALPHA_HILO) {
+        const float ph = p2 * LOG2E;
+        float c = __builtin_fmaf(-ph, 0.693147182464599609375f, p2);
+        c = __builtin_fmaf(-ph, -1.90465429995776804525e-09f, c);
+        const float r = __builtin_amdgcn_exp2f(ph);
+        return o * __builtin_fmaf(r, c, r);
+    }
+    if (AM == ALPHA_OCML) return o * expf(p2);
+    return o * exp_ref(p2, tab);
+}
+// T / om for the backward's transmittance; `inv` ~ 1 / om for the terms that are not amplified
+template <int AM>
+__device__ __forceinline__ float t_div(float T, float om, float& inv) {
+    if (AM == ALPHA_FAST) { inv = __builtin_amdgcn_rcpf(om); return T * inv; }
+    if (AM == ALPHA_OCML) { inv = 1.0f / om; return T / om; }
+    return div_ref(T, om, inv);
+}
 
 // bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of tiles
 __device__ __forceinline__ int xcd_tile(int b, int n) {
@@ -59,7 +83,7 @@ using Staged = StagedT<DGR_TILE_PIX>;
 // fast rcp / sqrt used here), so every dropped (pixel, Gaussian) pair is one the per-pixel test rejects.
 // (An exact ellipse-vs-quadrant test was measured: it removes almost no list entries beyond the box -- the
 // iterations without a valid lane are finished pixels and sub-pixel splats -- and costs more VALU than it saves.)
-template <int NB>
+template <int AM, int NB>
 __device__ __forceinline__ unsigned stage_one(StagedT<NB>& s, int slot, uint32_t gid, const float4* __restrict__ rec,
                                               float tile_x0, float tile_y0) {
     const float4 q0 = rec[3 * (size_t)gid + 0];
@@ -69,7 +93,8 @@ __device__ __forceinline__ unsigned stage_one(StagedT<NB>& s, int slot, uint32_t
     // log-domain threshold: alpha >= 15/255 <=> p2 >= log2(15/(255 o)); the loop compares against a slightly lower
     // value and re-tests alpha itself on the rare path, so decisions are those of the linear-domain test.
     const float l2 = __log2f(o * (255.0f / 15.0f));  // = tau / (2 ln 2)
-    const float lthr = (o > 0.f) ? (-l2 * (DGR_EXACT_ALPHA ? 0.6931471805599453f : 1.0f) - 1.0e-4f) : 3.0e38f;
+    constexpr float PSCALE = AlphaPath<AM>::PSCALE;
+    const float lthr = (o > 0.f) ? (-l2 * (AlphaPath<AM>::LOG2 ? 1.0f : LN2) - 1.0e-4f) : 3.0e38f;
     s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
     s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, o, __int_as_float(slot), lthr);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
@@ -95,8 +120,9 @@ constexpr int TAG_SHIFT = DGR_TAG_SHIFT;
 constexpr uint32_t ID_MASK = DGR_ID_MASK;
 
 // backward staging: returns the entry's tag; untagged entries are not loaded
-template <int NB>
+template <int AM, int NB>
 __device__ __forceinline__ unsigned stage_tagged(StagedT<NB>& s, int slot, uint32_t entry, const float4* __restrict__ rec) {
+    constexpr float PSCALE = AlphaPath<AM>::PSCALE;
     const unsigned code = entry >> TAG_SHIFT;
     if (code == 0u) return 0u;
     const uint32_t gid = entry & ID_MASK;
@@ -143,23 +169,25 @@ __device__ __forceinline__ int build_lists(StagedT<NB>& s, unsigned code, int ti
 // v_pk_*_f32 operands: gfx950 issues two fp32 operations per lane with one packed instruction
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// log2(e) * power of one (pixel, Gaussian) pair from a staged record, and the offsets d = centre - pixel.
-// Forward and backward must agree on every decision, so both evaluate exactly this sequence: a packed subtract, a
-// packed multiply, two fused multiply-adds and one multiply (explicit fma: nothing is left to contraction).
+// power (ALPHA_FAST: log2(e) * power) of one (pixel, Gaussian) pair from a staged record, and the offsets d = centre - pixel.
+// Forward and backward must agree on every decision, so both evaluate exactly this sequence.
+//   ALPHA_FAST: a packed subtract, a packed multiply, two fused multiply-adds and one multiply;
+//   otherwise : the reference's association without contraction (forward.cu:354, backward.cu:561); the staged a2, c2
+//               carry the factor -0.5 and b2 the sign, which are exact.
+template <int AM>
 __device__ __forceinline__ float pair_p2(const float4& q0, const float4& q1, f2 pxy, f2& dxy) {
     const f2 g = {q0.x, q0.y}, ac = {q0.z, q0.w};
     dxy = g - pxy;
-#if DGR_EXACT_ALPHA
-    {   // the reference's association (forward.cu:354, backward.cu:561), no contraction; the staged a2, c2 carry the -0.5
+    if (AM == ALPHA_FAST) {
+        const f2 m = ac * dxy;                                      // a2 dx, c2 dy
+        const float t = __builtin_fmaf(q1.x, dxy.y, m.x);           // a2 dx + b2 dy
+        return __builtin_fmaf(dxy.x, t, m.y * dxy.y);
+    } else {
 #pragma clang fp contract(off)
-        const float A = (q0.z * dxy.x) * dxy.x, Cc = (q0.w * dxy.y) * dxy.y, B = (q1.x * dxy.x) * dxy.y;
-        return (A + Cc) + B;
+        const f2 m = (ac * dxy) * dxy;                              // (a2 dx) dx, (c2 dy) dy
+        const float B = (q1.x * dxy.x) * dxy.y;
+        return (m.x + m.y) + B;
     }
-#else
-    const f2 m = ac * dxy;                                      // a2 dx, c2 dy
-    const float t = __builtin_fmaf(q1.x, dxy.y, m.x);           // a2 dx + b2 dy
-    return __builtin_fmaf(dxy.x, t, m.y * dxy.y);
-#endif
 }
 
 // two consecutive list entries: one 4-byte LDS read yields two record offsets

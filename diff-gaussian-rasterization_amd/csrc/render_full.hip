@@ -28,10 +28,12 @@ __device__ __forceinline__ void flush_tags(const Staged& s, const uint32_t* hit,
     point_list[pos0 + tid] = s.id[tid] | (tag << TAG_SHIFT);
 }
 
+template <int AM>
 __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullArgs a) {
     __shared__ Staged s;
     __shared__ uint32_t hit[DGR_TILE_PIX];  // byte w of word j: quadrant wave w blended staged instance j
     __shared__ int s_nvalid;
+    __shared__ uint64_t exptab[32];         // ALPHA_REF: exact_math.h
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -52,6 +54,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
         write_sentinel(s);
         s_nvalid = 0;
     }
+    if (AlphaPath<AM>::TABLE) exp_ref_table_fill(exptab, tid);  // (visible after the first batch's barriers)
 
     bool have_flush = false;
     int last_base = 0;
@@ -63,7 +66,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
         last_base = base;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
-        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
+        if (tid < cnt) code = stage_one<AM>(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
         const int n = build_lists(s, code, tid, wave, lane);
 
         for (int k = 0; k < n; k += 2) {
@@ -72,17 +75,18 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 f2 dxy;
-                const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
+                const float p2 = pair_p2<AM>(q0[u], q1[u], pxy, dxy);
                 if ((p2 <= ub) & (p2 >= q1[u].w)) {
-                  const float alpha = fminf(0.99f, alpha_raw(q1[u].y, p2));
+                  const float alpha = fminf(0.99f, alpha_raw<AM>(q1[u].y, p2, exptab));
                   if (alpha >= ALPHA_MIN) {
+#pragma clang fp contract(off)  // T (1 - alpha) and the sum of alpha T round as the reference's do (forward.cu:366-381)
                     const int j = __float_as_int(q1[u].z);
                     const float4 cd = s.rgbd[j];
                     reinterpret_cast<unsigned char*>(hit)[4 * j + wave] = 1;  // contribution tag
                     const float w = alpha * T;
-                    C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
-                    Dd += cd.w * w;
-                    U += w;
+                    C0 = __builtin_fmaf(cd.x, w, C0); C1 = __builtin_fmaf(cd.y, w, C1); C2 = __builtin_fmaf(cd.z, w, C2);
+                    Dd = __builtin_fmaf(cd.w, w, Dd);
+                    U = U + w;
                     nvalid++;
                     T = T * (1.0f - alpha);
                     last_contributor = (uint32_t)(base + j + 1);
@@ -131,8 +135,10 @@ struct StagedBwdFull {
     StagedT<BWD_NB> f;
     float acc[NACC_FULL * BWD_LD];
     int max_last;
+    uint64_t exptab[32];  // ALPHA_REF: exact_math.h
 };
 
+template <int AM>
 __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullArgs a) {
     __shared__ StagedBwdFull sb;
     StagedT<BWD_NB>& s = sb.f;
@@ -154,6 +160,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
         sb.max_last = 0;
         write_sentinel<true>(s);
     }
+    if (AlphaPath<AM>::TABLE) exp_ref_table_fill(sb.exptab, tid);
     __syncthreads();
     {
         int v = last_contributor;
@@ -191,7 +198,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
         const int cnt = hi - lo;
         __syncthreads();
         unsigned code = 0;
-        if (tid < cnt) code = stage_tagged(s, tid, a.point_list[range.x + lo + tid], a.rec);
+        if (tid < cnt) code = stage_tagged<AM>(s, tid, a.point_list[range.x + lo + tid], a.rec);
 #pragma unroll
         for (int k = 0; k < NACC_FULL; k++)
             if (tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
@@ -205,10 +212,10 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
 #pragma unroll
             for (int u = 1; u >= 0; u--) {
                 f2 dxy;
-                const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
+                const float p2 = pair_p2<AM>(q0[u], q1[u], pxy, dxy);
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
-                const float oG = alpha_raw(q1[u].y, p2);  // o G: alpha before the 0.99 clamp
+                const float oG = alpha_raw<AM>(q1[u].y, p2, sb.exptab);  // o G: alpha before the 0.99 clamp
                 const float alpha = fminf(0.99f, oG);
                 const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
                 // No branch (see render_light.hip): a lane the Gaussian does not reach runs the same instructions with
@@ -220,8 +227,8 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
                 const float oGm = valid ? oG : 0.f;
                 const float4 cd = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rgbd) + __float_as_int(q1[u].w));
                 const float om = 1.f - am;
-                const float inv = recip(om);
-                T = T * inv;
+                float inv;
+                T = t_div<AM>(T, om, inv);  // backward.cu:663
                 const float w = am * T;  // dchannel_dcolor
                 const float e = cd.w - gt_px;
                 const float Xc = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2, Xd = cd.w, Xu = e * e;
@@ -266,9 +273,9 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
         __syncthreads();
         // moments -> gradients per staged Gaussian: every "d/d(ndc)" sum is -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2
         if (code != 0u) {
-            constexpr float LN2 = PUNSCALE;  // (undoes the scale of the staged conic)
+            constexpr float UN = AlphaPath<AM>::PUNSCALE;  // (undoes the scale of the staged conic)
             const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
-            const float ca = r0.z * (-2.f * LN2), cb = r1.x * (-LN2), cc = r0.w * (-2.f * LN2);
+            const float ca = r0.z * (-2.f * UN), cb = r1.x * (-UN), cc = r0.w * (-2.f * UN);
 #pragma unroll
             for (int p = 0; p < 3; p++) {
                 const int cx = (p == 0) ? 4 : (p == 1) ? 10 : 13, cy = cx + 1;
@@ -279,7 +286,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
             sb.acc[6 * BWD_LD + tid] *= -0.5f;
             sb.acc[7 * BWD_LD + tid] *= -0.5f;
             sb.acc[8 * BWD_LD + tid] *= -0.5f;
-            sb.acc[9 * BWD_LD + tid] *= recip(r1.y);
+            sb.acc[9 * BWD_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
         }
         __syncthreads();
         flush_acc<NACC_FULL, BWD_LD>(sb.acc, s.id, cnt, a.acc, tid);
@@ -288,16 +295,30 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
 
 }  // namespace
 
-hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, hipStream_t stream) {
+hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
-    launch(render_fwd_full_kernel, dim3(tiles), dim3(256), stream, a);
+    switch (alpha_mode) {
+        case ALPHA_FAST: launch(render_fwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+#ifdef DGR_ALPHA_EXPERIMENT
+        case ALPHA_HILO: launch(render_fwd_full_kernel<ALPHA_HILO>, dim3(tiles), dim3(256), stream, a); break;
+        case ALPHA_OCML: launch(render_fwd_full_kernel<ALPHA_OCML>, dim3(tiles), dim3(256), stream, a); break;
+#endif
+        default: launch(render_fwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
+    }
     return hipGetLastError();
 }
-hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, hipStream_t stream) {
+hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
-    launch(render_bwd_full_kernel, dim3(tiles), dim3(256), stream, a);
+    switch (alpha_mode) {
+        case ALPHA_FAST: launch(render_bwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+#ifdef DGR_ALPHA_EXPERIMENT
+        case ALPHA_HILO: launch(render_bwd_full_kernel<ALPHA_HILO>, dim3(tiles), dim3(256), stream, a); break;
+        case ALPHA_OCML: launch(render_bwd_full_kernel<ALPHA_OCML>, dim3(tiles), dim3(256), stream, a); break;
+#endif
+        default: launch(render_bwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -23,16 +23,12 @@
 //  * XCD-aware block->tile map: block b runs on XCD b%8, so each XCD is handed a contiguous band of
 //    tiles and neighbouring tiles share Gaussian records / accumulator rows in one L2.
 //
-// alpha is evaluated as o * exp2(p2) with the conic pre-scaled by log2(e) (one v_exp_f32, no range
-// reduction); forward and backward use the identical expression so they agree on every decision.
+// alpha: template parameter AM (render_common.h).  ALPHA_REF, the default, evaluates the reference's expression with the
+// host library's bits (exact_math.h): the alpha image, n_contrib and the median depth then equal the CPU restatement's bit
+// for bit, which is what the light backward's T_final = 1 - alpha needs.  ALPHA_FAST (an option) is
+// o * exp2(p2) on a conic pre-scaled by log2(e) -- one v_exp_f32.  Forward and backward of one mode use the identical
+// expression, so they agree on every decision.
 #include "render_common.h"
-
-#ifndef DGR_REDUCE_DPP
-#define DGR_REDUCE_DPP 1  // the twelve-value reduction with its within-row stages first (wave_reduce12d: render_bwd 212 -> 205 us); 0 = swap-first
-#endif
-#ifndef DGR_ABLATE
-#define DGR_ABLATE 0  // 1 / 2: measurement builds (profiles/ablate.sh), never shipped
-#endif
 
 namespace dgr {
 namespace {
@@ -40,14 +36,12 @@ namespace {
 // ================================================================================ forward
 constexpr int FWD_UNROLL = 2;  // list entries per loop iteration (4 was measured: no faster, more registers)
 
-template <bool TAGS16>
-struct StagedFwdT {
+struct StagedFwd {
     Staged f;
     float unc[DGR_TILE_PIX];   // per staged instance: sum of (d - gt)^2 alpha T over its median pixels (forward.cu:386)
     uint32_t cnt[DGR_TILE_PIX];
-    // TAGS16 (the rows backward is selected): byte 4 w + r of entry j != 0 <=> some pixel of the 4x4 block r of quadrant
-    // wave w blended staged instance j (r = 2 (y / 4) + x / 4 inside the quadrant); otherwise one byte per quadrant
-    uint32_t hit[DGR_TILE_PIX * (TAGS16 ? 4 : 1)];
+    uint32_t hit[DGR_TILE_PIX];  // byte w of word j != 0 <=> some pixel of quadrant wave w blended staged instance j
+    uint64_t exptab[32];         // ALPHA_REF: exact_math.h
 };
 
 // Per-slot results of the batch staged at list position `pos0`: the median statistics go to the Gaussian, the
@@ -55,19 +49,9 @@ struct StagedFwdT {
 // four 0/1 bytes -> four bits
 __device__ __forceinline__ uint32_t pack4(uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); }
 
-template <bool TAGS16>
-__device__ __forceinline__ void flush_slot(const StagedFwdT<TAGS16>& sf, const RenderFwdLightArgs& a, uint32_t pos0, int tid,
-                                           bool staged) {
+__device__ __forceinline__ void flush_slot(const StagedFwd& sf, const RenderFwdLightArgs& a, uint32_t pos0, int tid, bool staged) {
     if (!staged) return;
-    uint32_t tag;
-    if (TAGS16) {
-        const uint4 h = reinterpret_cast<const uint4*>(sf.hit)[tid];
-        const uint32_t tag16 = pack4(h.x) | (pack4(h.y) << 4) | (pack4(h.z) << 8) | (pack4(h.w) << 12);
-        a.tags16[pos0 + tid] = (uint16_t)tag16;  // (every staged entry: the backward reads the tag of every list position)
-        tag = (h.x ? 1u : 0u) | (h.y ? 2u : 0u) | (h.z ? 4u : 0u) | (h.w ? 8u : 0u);  // per quadrant
-    } else {
-        tag = pack4(sf.hit[tid]);
-    }
+    const uint32_t tag = pack4(sf.hit[tid]);
     if (tag == 0u) return;  // nothing blended this instance
     const uint32_t gid = sf.f.id[tid];
     if (sf.cnt[tid] != 0u) {
@@ -77,9 +61,9 @@ __device__ __forceinline__ void flush_slot(const StagedFwdT<TAGS16>& sf, const R
     a.point_list[pos0 + tid] = gid | (tag << TAG_SHIFT);
 }
 
-template <bool TAGS16>
-__global__ void __launch_bounds__(256, TAGS16 ? 7 : 8) render_fwd_light_kernel(RenderFwdLightArgs a) {  // (LDS: 7 workgroups per CU with the wide tags)
-    __shared__ StagedFwdT<TAGS16> sf;
+template <int AM>
+__global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
+    __shared__ StagedFwd sf;
     Staged& s = sf.f;
     const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -90,9 +74,6 @@ __global__ void __launch_bounds__(256, TAGS16 ? 7 : 8) render_fwd_light_kernel(R
     const size_t pix_id = (size_t)a.W * py + px;
     const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
-    // byte of a staged entry's hit word(s) this pixel marks: its 4x4 block (quadrant, y / 4, x / 4) or its quadrant
-    const int hit_byte = TAGS16 ? 4 * wave + 2 * (lane >> 5) + ((lane >> 2) & 1) : wave;
-    constexpr int HIT_STRIDE = TAGS16 ? 16 : 4;
 
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
@@ -104,6 +85,7 @@ __global__ void __launch_bounds__(256, TAGS16 ? 7 : 8) render_fwd_light_kernel(R
     float ub = inside ? 0.f : -__builtin_inff();
     const float gt_px = inside ? a.gt_depth[pix_id] : 0.f;
     if (tid == 0) write_sentinel(s);
+    if (AlphaPath<AM>::TABLE) exp_ref_table_fill(sf.exptab, tid);  // (visible after the first batch's barriers)
     bool have_flush = false;
     int last_base = 0;
 
@@ -115,17 +97,12 @@ __global__ void __launch_bounds__(256, TAGS16 ? 7 : 8) render_fwd_light_kernel(R
         if (have_flush) flush_slot(sf, a, range.x + base - DGR_TILE_PIX, tid, true);  // (an earlier batch is always full)
         sf.unc[tid] = 0.f;
         sf.cnt[tid] = 0u;
-        if (TAGS16) reinterpret_cast<uint4*>(sf.hit)[tid] = make_uint4(0u, 0u, 0u, 0u);
-        else sf.hit[tid] = 0u;
+        sf.hit[tid] = 0u;
         have_flush = true;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
-        if (tid < cnt) code = stage_one(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
-#if DGR_ABLATE == 1
-        const int n = build_lists(s, code, tid, wave, lane) * (a.W < 0 ? 1 : 0);  // (measurement build: no pair loop, nothing else removed)
-#else
+        if (tid < cnt) code = stage_one<AM>(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
         const int n = build_lists(s, code, tid, wave, lane);
-#endif
 
         for (int k = 0; k < n; k += FWD_UNROLL) {
             float4 q0[FWD_UNROLL], q1[FWD_UNROLL];
@@ -133,21 +110,22 @@ __global__ void __launch_bounds__(256, TAGS16 ? 7 : 8) render_fwd_light_kernel(R
 #pragma unroll
             for (int u = 0; u < FWD_UNROLL; u++) {
                 f2 dxy;
-                const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
-                if ((p2 <= ub) & (p2 >= q1[u].w)) {  // cheap log-domain pre-test: v_exp stays off the common path
-                  const float alpha = fminf(0.99f, alpha_raw(q1[u].y, p2));
+                const float p2 = pair_p2<AM>(q0[u], q1[u], pxy, dxy);
+                if ((p2 <= ub) & (p2 >= q1[u].w)) {  // cheap log-domain pre-test: the exponential stays off the common path
+                  const float alpha = fminf(0.99f, alpha_raw<AM>(q1[u].y, p2, sf.exptab));
                   if (alpha >= ALPHA_MIN) {
+#pragma clang fp contract(off)  // T (1 - alpha) and the alpha image's sum round as the reference's do (forward.cu:366-379)
                     const float test_T = T * (1.0f - alpha);
                     if (test_T < 0.0001f) {
                         ub = -__builtin_inff();  // done; this Gaussian is not blended (forward.cu:368-373)
                     } else {
                         const int j = __float_as_int(q1[u].z);
                         const float4 cd = s.rgbd[j];
-                        reinterpret_cast<unsigned char*>(sf.hit)[HIT_STRIDE * j + hit_byte] = 1;  // contribution tag
+                        reinterpret_cast<unsigned char*>(sf.hit)[4 * j + wave] = 1;  // contribution tag
                         const float w = alpha * T;
-                        C0 += cd.x * w; C1 += cd.y * w; C2 += cd.z * w;
-                        weight += w;
-                        Dd += cd.w * w;
+                        C0 = __builtin_fmaf(cd.x, w, C0); C1 = __builtin_fmaf(cd.y, w, C1); C2 = __builtin_fmaf(cd.z, w, C2);
+                        weight = weight + w;
+                        Dd = __builtin_fmaf(cd.w, w, Dd);
                         if (T > 0.5f && test_T < 0.5f) {  // forward.cu:381-388
                             D_median = cd.w;
                             const float e = cd.w - gt_px;
@@ -165,9 +143,6 @@ __global__ void __launch_bounds__(256, TAGS16 ? 7 : 8) render_fwd_light_kernel(R
     }
     __syncthreads();
     if (have_flush) flush_slot(sf, a, range.x + last_base, tid, tid < total - last_base);
-    // list positions no batch reached (the whole tile finished early): no pixel blended them
-    if (TAGS16)
-        for (int i = (have_flush ? last_base + DGR_TILE_PIX : 0) + tid; i < total; i += DGR_TILE_PIX) a.tags16[range.x + i] = 0;
 
     if (inside) {
         const size_t N = (size_t)a.W * a.H;
@@ -201,10 +176,11 @@ struct StagedBwd {
     StagedT<BWD_NB> f;
     float acc[NACC_LIGHT * BWD_LD];
     int max_last;
+    uint64_t exptab[32];  // ALPHA_REF: exact_math.h
 };
 
 // 8 waves per SIMD (63 VGPRs, no scratch): measured 258 us at the compiler's own choice of 7, 247 us at 8
-template <bool DO_MAP, bool DO_POSE>
+template <int AM, bool DO_MAP, bool DO_POSE>
 __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
     __shared__ StagedBwd sb;
     StagedT<BWD_NB>& s = sb.f;
@@ -226,6 +202,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         sb.max_last = 0;
         write_sentinel<true>(s);
     }
+    if (AlphaPath<AM>::TABLE) exp_ref_table_fill(sb.exptab, tid);
     __syncthreads();
     {
         int v = last_contributor;  // wave max, then one LDS atomic per wave
@@ -264,11 +241,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     if (DO_MAP) {
         // butterfly slots 0..9 = components 0..9; with the pose gradient slot 10 = component 13 (pose depth) and slot 11 =
         // component 10 (median), without it slot 10 = component 10
-#if DGR_REDUCE_DPP
         const int c = (lane >= 48) ? 12 : wave_reduce12d_comp(lane);  // (rows 2 and 3 hold the same four totals: row 2 delivers)
-#else
-        const int c = wave_reduce16_comp(lane);
-#endif
         my_comp = ((lane & 3) != 0 || c > 11) ? -1 : (c == 10 ? (DO_POSE ? 13 : 10) : c == 11 ? (DO_POSE ? 10 : -1) : c);
     } else {
         const int c = wave_reduce4_comp(lane);  // {4: gmx, 5: gmy, 13: pose depth}
@@ -281,15 +254,11 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         const int cnt = hi - lo;
         __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
-        if (tid < cnt) code = stage_tagged(s, tid, a.point_list[range.x + lo + tid], a.rec);
+        if (tid < cnt) code = stage_tagged<AM>(s, tid, a.point_list[range.x + lo + tid], a.rec);
 #pragma unroll
         for (int k = 0; k < NACC_LIGHT; k++)
             if (BWD_NB == DGR_TILE_PIX || tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
-#if DGR_ABLATE == 1
-        const int n = build_lists(s, code, tid, wave, lane) * (a.W < 0 ? 1 : 0);  // (measurement build: no pair loop, nothing else removed)
-#else
         const int n = build_lists(s, code, tid, wave, lane);
-#endif
         const int rel_last = last_contributor - lo;  // slots below this are at or before the last contributor
 
         // (the list is padded with sentinels to a multiple of 4, so a multiple of 2 is always readable)
@@ -299,11 +268,11 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
 #pragma unroll
             for (int u = 1; u >= 0; u--) {
                 f2 dxy;
-                const float p2 = pair_p2(q0[u], q1[u], pxy, dxy);
+                const float p2 = pair_p2<AM>(q0[u], q1[u], pxy, dxy);
                 const float dx = dxy.x, dy = dxy.y;
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
-                const float oG = alpha_raw(q1[u].y, p2);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
+                const float oG = alpha_raw<AM>(q1[u].y, p2, sb.exptab);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
                 const float alpha0 = fminf(0.99f, oG);
                 const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha0 >= ALPHA_MIN);
                 // No branch: a lane the Gaussian does not reach runs the same instructions with alpha = 0 and o G = 0, which
@@ -314,8 +283,8 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                 const float oGm = valid ? oG : 0.f;
                 const float4 cd = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rgbd) + __float_as_int(q1[u].w));
                 const float om = 1.f - alpha;
-                const float inv = recip(om);
-                T = T * inv;
+                float inv;
+                T = t_div<AM>(T, om, inv);  // backward.cu:570
                 const float w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
                 const float e = cd.w - gt_px;
                 const float X = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2 + cd.w * dpix_depth + (e * e) * dpix_var;
@@ -349,25 +318,13 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     g[9] = qq;         // sum q
                     g[10] = DO_POSE ? wd : gmed;   // -> accumulator component 13 / 10
                     g[11] = DO_POSE ? gmed : 0.f;  // -> accumulator component 10
-#if DGR_ABLATE == 2
-                    tot = ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7])) + ((g[8] + g[9]) + (g[10] + g[11]));  // (measurement build: no butterfly)
-#else
-#if DGR_REDUCE_DPP
                     tot = wave_reduce12d(g);
-#else
-                    tot = wave_reduce12(g);
-#endif
-#endif
                 } else {
                     float g4[4] = {qdx, qdy, wd, 0.f};
                     tot = wave_reduce4(g4);
                 }
                 // j is wave-uniform here (every lane read the same record)
-#if DGR_ABLATE == 3
-                if (my_comp >= 0) sb.acc[my_comp * BWD_LD + j] = tot;  // (measurement build: a plain store instead of the LDS atomic)
-#else
                 if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * BWD_LD + j], tot);
-#endif
             }
         }
 
@@ -375,9 +332,9 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         // moments -> gradients, one thread per staged Gaussian (backward.cu:627-631, 669-678):
         //   dL/dmean2D = -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2;  dL/dconic = -Sxx/2, -Sxy/2, -Syy/2;  dL/dopacity = S0/o
         if (code != 0u) {
-            constexpr float LN2 = PUNSCALE;  // (undoes the scale of the staged conic)
+            constexpr float UN = AlphaPath<AM>::PUNSCALE;  // (undoes the scale of the staged conic)
             const float4 r0 = s.rec[2 * tid], r1 = s.rec[2 * tid + 1];
-            const float ca = r0.z * (-2.f * LN2), cb = r1.x * (-LN2), cc = r0.w * (-2.f * LN2);  // unscaled conic
+            const float ca = r0.z * (-2.f * UN), cb = r1.x * (-UN), cc = r0.w * (-2.f * UN);  // unscaled conic
             const float Sx = sb.acc[4 * BWD_LD + tid], Sy = sb.acc[5 * BWD_LD + tid];
             sb.acc[4 * BWD_LD + tid] = -(ca * Sx + cb * Sy) * ddelx_dx;
             sb.acc[5 * BWD_LD + tid] = -(cc * Sy + cb * Sx) * ddely_dy;
@@ -385,7 +342,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                 sb.acc[6 * BWD_LD + tid] *= -0.5f;
                 sb.acc[7 * BWD_LD + tid] *= -0.5f;
                 sb.acc[8 * BWD_LD + tid] *= -0.5f;
-                sb.acc[9 * BWD_LD + tid] *= recip(r1.y);
+                sb.acc[9 * BWD_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
             }
         }
         __syncthreads();
@@ -393,59 +350,84 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     }
 }
 
-// self-test of the butterflies: in[c * 64 + lane] -> out16[lane], out4[lane] (see dgr_debug_wave_reduce); the networks with
-// the within-row stages first go to out16[64 + lane] (16 values) and out4[64 + lane] (12 values), their value maps to
-// comp16[64 + lane], comp4[64 + lane]
-__global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, float* out16, float* out4, int* comp16,
-                                                             int* comp4, int with_d) {
+// self-test of the butterflies: in[c * 64 + lane] -> the three networks' results and value maps per lane (dgr_debug_wave_reduce)
+__global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, float* out16, float* out12, float* out4,
+                                                             int* comp16, int* comp12, int* comp4) {
     const int lane = threadIdx.x;
-    float g[16];
+    float g16[16], g12[12], g4[4];
 #pragma unroll
-    for (int k = 0; k < 16; k++) g[k] = in[k * 64 + lane];
-    float g4[4] = {g[0], g[1], g[2], g[3]};
-    float g12[12], g12d[12], g16d[16];
+    for (int k = 0; k < 16; k++) g16[k] = in[k * 64 + lane];
 #pragma unroll
-    for (int k = 0; k < 12; k++) g12[k] = g12d[k] = g[k];
+    for (int k = 0; k < 12; k++) g12[k] = g16[k];
 #pragma unroll
-    for (int k = 0; k < 16; k++) g16d[k] = g[k];
-    const float r12 = wave_reduce12(g12);
-    const float r16 = wave_reduce16(g);
-    // out16: lanes whose component is < 12 must agree between the 12- and 16-value networks; report a mismatch as NaN
-    out16[lane] = (wave_reduce16_comp(lane) < 12 && r12 != r16) ? __builtin_nanf("") : r16;
+    for (int k = 0; k < 4; k++) g4[k] = g16[k];
+    out16[lane] = wave_reduce16d(g16);
+    out12[lane] = wave_reduce12d(g12);
     out4[lane] = wave_reduce4(g4);
-    comp16[lane] = wave_reduce16_comp(lane);
+    comp16[lane] = wave_reduce16d_comp(lane);
+    comp12[lane] = wave_reduce12d_comp(lane);
     comp4[lane] = wave_reduce4_comp(lane);
-    if (with_d) {
-        out16[64 + lane] = wave_reduce16d(g16d);
-        out4[64 + lane] = wave_reduce12d(g12d);
-        comp16[64 + lane] = wave_reduce16d_comp(lane);
-        comp4[64 + lane] = wave_reduce12d_comp(lane);
+}
+
+// self-test of exact_math.h: out_exp[i] = exp_ref(x[i]), out_div[i] = div_ref(a[i], b[i]) (dgr_debug_exact_math)
+__global__ void __launch_bounds__(256) exact_math_test_kernel(int n, const float* x, const float* a, const float* b, float* out_exp,
+                                                             float* out_div) {
+    __shared__ uint64_t tab[32];
+    exp_ref_table_fill(tab, threadIdx.x);
+    __syncthreads();
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        out_exp[i] = exp_ref(x[i], tab);
+        float inv;
+        out_div[i] = t_div<ALPHA_REF>(a[i], b[i], inv);
     }
 }
 
+template <int AM>
+void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t stream) {
+    if (!a.map_off && !a.track_off)
+        launch((render_bwd_light_kernel<AM, true, true>), dim3(tiles), dim3(256), stream, a);
+    else if (!a.map_off)
+        launch((render_bwd_light_kernel<AM, true, false>), dim3(tiles), dim3(256), stream, a);
+    else
+        launch((render_bwd_light_kernel<AM, false, true>), dim3(tiles), dim3(256), stream, a);
+}
 }  // namespace
 
-hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, hipStream_t stream) {
+hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
-    if (a.tags16) launch(render_fwd_light_kernel<true>, dim3(tiles), dim3(256), stream, a);
-    else launch(render_fwd_light_kernel<false>, dim3(tiles), dim3(256), stream, a);
+    switch (alpha_mode) {
+        case ALPHA_FAST: launch(render_fwd_light_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+#ifdef DGR_ALPHA_EXPERIMENT
+        case ALPHA_HILO: launch(render_fwd_light_kernel<ALPHA_HILO>, dim3(tiles), dim3(256), stream, a); break;
+        case ALPHA_OCML: launch(render_fwd_light_kernel<ALPHA_OCML>, dim3(tiles), dim3(256), stream, a); break;
+#endif
+        default: launch(render_fwd_light_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
+    }
     return hipGetLastError();
 }
-hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, hipStream_t stream) {
+hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, int alpha_mode, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0 || (a.track_off && a.map_off)) return hipSuccess;
-    if (!a.map_off && !a.track_off)
-        launch((render_bwd_light_kernel<true, true>), dim3(tiles), dim3(256), stream, a);
-    else if (!a.map_off)
-        launch((render_bwd_light_kernel<true, false>), dim3(tiles), dim3(256), stream, a);
-    else
-        launch((render_bwd_light_kernel<false, true>), dim3(tiles), dim3(256), stream, a);
+    switch (alpha_mode) {
+        case ALPHA_FAST: launch_bwd_light_mode<ALPHA_FAST>(a, tiles, stream); break;
+#ifdef DGR_ALPHA_EXPERIMENT
+        case ALPHA_HILO: launch_bwd_light_mode<ALPHA_HILO>(a, tiles, stream); break;
+        case ALPHA_OCML: launch_bwd_light_mode<ALPHA_OCML>(a, tiles, stream); break;
+#endif
+        default: launch_bwd_light_mode<ALPHA_REF>(a, tiles, stream);
+    }
     return hipGetLastError();
 }
-hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out4, int* comp16, int* comp4, bool with_d,
+hipError_t launch_exact_math_test(int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div,
+                                  hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    launch(exact_math_test_kernel, dim3(min((n + 255) / 256, 4096)), dim3(256), stream, n, x, a, b, out_exp, out_div);
+    return hipGetLastError();
+}
+hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12, int* comp4,
                                    hipStream_t stream) {
-    launch(wave_reduce_test_kernel, dim3(1), dim3(64), stream, in, out16, out4, comp16, comp4, with_d ? 1 : 0);
+    launch(wave_reduce_test_kernel, dim3(1), dim3(64), stream, in, out16, out12, out4, comp16, comp12, comp4);
     return hipGetLastError();
 }
 

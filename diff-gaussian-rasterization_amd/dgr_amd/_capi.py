@@ -93,9 +93,8 @@ _SIGS = {
     "dgr_state_export": (C.c_long, [_vp, C.c_char_p, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dgr_cov3d_forward": (_i, [_vp, _i, _vp, _vp, _f, _vp]),
     "dgr_cov3d_backward": (_i, [_vp, _i, _vp, _vp, _f, _vp, _vp, _vp]),
-    "dgr_debug_wave_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "dgr_debug_wave_reduce_d": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
-    "dgr_debug_row_reduce": (_i, [_vp, _vp, _vp, _vp]),
+    "dgr_debug_wave_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dgr_debug_exact_math": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "dgr_profile_select": (_i, [C.c_char_p]),
     "dgr_profile_stage_count": (_i, []),
     "dgr_profile_stage_name": (C.c_char_p, [_i]),

@@ -224,6 +224,13 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
                          float* dL_ddepth);
 
 /* Process-wide options (default 0 unless stated).
+ *  "fast_alpha": how the blend kernels evaluate alpha = min(0.99, o exp(power)) and T / (1 - alpha).  0 (default) = the
+ *     reference's expression in the reference's association (forward.cu:354-364, backward.cu:561-570) with expf and the
+ *     division rounded exactly as on the host (csrc/exact_math.h): the alpha image, n_contrib and the median depth are
+ *     bit-identical to the CPU restatement and the gradients agree with it to 1e-5 abs (BASELINE's loss scaling).
+ *     1 = log2(e)-scaled conic, v_exp_f32, v_rcp_f32: each operation good to an ulp and the blend kernels faster, but
+ *     the light backward's T_final = 1 - alpha image and its divisions by (1 - alpha) amplify last-bit differences: up to
+ *     6e-5 abs on the pose gradient at BASELINE config 3.  Forward and backward of a view must run in the same mode.
  *  "tight_cull": 1 = alpha-aware tile rectangles.  The reference gives a Gaussian every tile its
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle
  *     is cut down to the box where alpha can reach 15/255.  Images and gradients are unchanged, but num_rendered, the
@@ -323,18 +330,16 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
                              float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                              int track_off, int map_off);
 
-/* Self-test of the wave64 multi-value butterfly reductions the backward blend relies on.  `in` holds 16
- * values per lane as in[c * 64 + lane]; out16[lane] / out4[lane] receive what each lane holds after the
- * 16-value / 4-value reduction, comp16[lane] / comp4[lane] the index of the value that lane's total belongs to. */
-int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out4, int* comp16, int* comp4);
-/* The same self-test including the networks the blend kernels use since round 3 (within-row DPP stages first, csrc/wave_reduce.h:
- * wave_reduce16d / wave_reduce12d).  All four arrays hold 128 entries: [0, 64) as dgr_debug_wave_reduce fills them,
- * out16[64 + lane] / comp16[64 + lane] the 16-value network, out12[64 + lane] / comp12[64 + lane] the 12-value one (which
- * reads in[0 .. 12 * 64)). */
-int dgr_debug_wave_reduce_d(void* stream, const float* in, float* out16, float* out12, int* comp16, int* comp12);
-/* The same for the 16-lane row reduction of the rows backward (render_light_rows.hip): in[c * 64 + lane], c < 12;
- * out[lane] = what the lane holds afterwards, comp[lane] = the value it belongs to (-1: a duplicate lane). */
-int dgr_debug_row_reduce(void* stream, const float* in, float* out, int* comp);
+/* Self-test of the wave64 multi-value butterfly reductions the backward blend relies on (csrc/wave_reduce.h: within-row DPP
+ * stages first, then v_permlane16/32_swap as inline asm).  `in` holds 16 values per lane as in[c * 64 + lane]; out16 /
+ * out12 / out4 [lane] receive what each lane holds after the 16- / 12- / 4-value network (the 12- and 4-value ones read the
+ * first 12 / 4 values), comp16 / comp12 / comp4 [lane] the index of the value that lane's total belongs to.  64 entries each. */
+int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12,
+                          int* comp4);
+/* Self-test of csrc/exact_math.h, the arithmetic behind the default alpha path: out_exp[i] = exp_ref(x[i]) -- expf with the
+ * host C library's bits, for -87 < x <= 0 -- and out_div[i] = div_ref(a[i], b[i]) -- correctly rounded a / b for normal
+ * operands.  n device floats each.  tests/test_hip_exact_math.py compares both with the host bit for bit. */
+int dgr_debug_exact_math(void* stream, int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div);
 
 /* ---- per-stage timing (bench.py's roofline object) ----
  * dgr_profile_select("") disables timing (default), "all" brackets every stage, a stage name brackets that

@@ -1270,6 +1270,11 @@ void pairStats(const State& st, double* out, double* out2, double* out3 = nullpt
 }
 
 extern "C" {
+// y[i] = the exponential exactly as renderForward / renderBackward call it (m_exp on a float), so that the GPU's exp_ref
+// (csrc/exact_math.h) can be compared with THIS library's binding bit for bit (tests/test_hip_exact_math.py)
+void dgro_exp(const float* x, float* y, long n) {
+    for (long i = 0; i < n; i++) y[i] = (float)m_exp(x[i]);
+}
 void dgro_pair_stats(void* st, double* out) { pairStats(*(State*)st, out, nullptr); }
 void dgro_pair_stats2(void* st, double* out, double* out2) { pairStats(*(State*)st, out, out2); }
 void dgro_pair_stats3(void* st, double* out, double* out2, double* out3) { pairStats(*(State*)st, out, out2, out3); }

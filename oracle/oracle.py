@@ -75,6 +75,15 @@ def lib(cmath=None):
     return _LIBS[cmath]
 
 
+def exp_as_the_oracle_calls_it(x):
+    """exp of a float32 array through the very function the blend loops of dgr_oracle.cpp call (std::exp(float) = the C
+    library's expf in the default build)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().dgro_exp(C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), C.c_long(x.size))
+    return y
+
+
 def _p(a):
     """float32/int32 numpy array (or None) -> void pointer (NULL for None / empty)."""
     if a is None or a.size == 0:

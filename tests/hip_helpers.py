@@ -43,7 +43,7 @@ _EXPORT = {  # name -> (numpy dtype, elements per unit, unit)
     "depths": (np.float32, "P"), "radii": (np.int32, "P"), "cov3D": (np.float32, "6P"), "means2D": (np.float32, "2P"),
     "conic_opacity": (np.float32, "4P"), "rgb": (np.float32, "3P"), "clamped": (np.uint8, "3P"),
     "tiles_touched": (np.uint32, "P"), "point_list": (np.uint32, "R"), "keys": (np.uint64, "R"),
-    "contribution_tags": (np.uint8, "R1"), "contribution_tags16": (np.uint16, "R"),
+    "contribution_tags": (np.uint8, "R1"),
     "ranges": (np.uint32, "2T"), "n_contrib": (np.uint32, "N"), "n_valid": (np.uint32, "N"), "final_T": (np.float32, "N"),
 }
 

@@ -37,10 +37,10 @@ def test_state_sizes_scale_as_documented():
     # 48 (rec) + 4 (depth) + 4 (radius) + 24 (cov3D) + 8 (rect) + 1 (clamped) + 4 (goff) + 48 (SH direction derivatives) B
     # per Gaussian, plus the per-256-Gaussian block totals and 256-byte alignment of each array
     assert 141 * 1000 <= g1 <= 141 * 1000 + 10 * 256 and g2 > g1
-    # 18 B per instance (list, keys, ranks, 16-bit tags) + the LDS count's workspace: one histogram row of the frame's 16
-    # tiles per counting workgroup (256) and one row of segment sums
+    # 16 B per instance (list, keys, ranks) + the LDS count's workspace: one histogram row of the frame's 16 tiles per
+    # counting workgroup (256) and one row of segment sums
     b = lib.dgr_binning_bytes(1000, 64, 64)
-    assert 18 * 1000 + 256 * 16 * 4 <= b <= 18 * 1000 + 256 * 16 * 4 + 256 * 4 + 6 * 256
+    assert 16 * 1000 + 256 * 16 * 4 <= b <= 16 * 1000 + 256 * 16 * 4 + 256 * 4 + 6 * 256
     assert lib.dgr_binning_bytes(2000, 64, 64) > b and lib.dgr_binning_bytes(1000, 1920, 1080) - b >= 256 * (8160 - 16) * 4
     assert lib.dgr_light_backward_scratch_bytes(1000, 64, 64) >= 64 * 1000
 
@@ -52,6 +52,9 @@ def test_options_round_trip_and_reject_unknown_names():
     assert lib.dgr_set_option(b"tight_cull", 0) == 0
     assert lib.dgr_set_option(b"profile_every", 8) == 0 and lib.dgr_get_option(b"profile_every") == 8
     assert lib.dgr_set_option(b"profile_every", 1) == 0
+    assert lib.dgr_get_option(b"fast_alpha") == 0  # the default alpha path carries the host's bits
+    assert lib.dgr_set_option(b"fast_alpha", 1) == 0 and lib.dgr_get_option(b"fast_alpha") == 1
+    assert lib.dgr_set_option(b"fast_alpha", 0) == 0
     assert lib.dgr_get_option(b"lds_count") in (0, 1, 2)
     keep = lib.dgr_get_option(b"lds_count")
     assert lib.dgr_set_option(b"lds_count", 2) == 0 and lib.dgr_get_option(b"lds_count") == 2

@@ -1,8 +1,11 @@
-"""Error budget of the end-to-end gradients: how much of the difference to the oracle comes from the
-fast alpha path (alpha = o * 2^p2 on a log2(e)-scaled conic with v_exp_f32, T / (1 - alpha) with v_rcp_f32) and how much
-is inherent in the reference algorithm (T_final = 1 - alpha_image, hard thresholds).  The same scene is run through the
-shipped library and through the exact-alpha MEASUREMENT build (lib/libdgr_hip_exact.so: expf on the reference's own
-expression, IEEE division), each in its own process, with BASELINE's loss scaling (pixel gradients N(0,1)/(H W))."""
+"""Error budget of the end-to-end gradients against north_star's tolerance (1e-5 abs on float outputs and pose gradients),
+with BASELINE's loss scaling (pixel gradients N(0,1)/(H W)), on BASELINE config 2's and config 3's sizes.
+
+The light backward derives T_final = 1 - alpha image (L/cuda_rasterizer/backward.cu:477) and rebuilds every transmittance by
+dividing by (1 - alpha) (:570): a last-bit difference of ONE alpha is amplified by 1 / T_final on nearly opaque pixels and by
+alpha / (1 - alpha) per division.  The default path therefore evaluates alpha with the host library's bits
+(csrc/exact_math.h); the fast_alpha option (v_exp_f32 on a log2(e)-scaled conic, v_rcp_f32) is run beside it, in its own
+process, to keep the cost of the difference on record."""
 import json
 import os
 import subprocess
@@ -12,36 +15,46 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXACT = os.path.join(ROOT, "diff-gaussian-rasterization_amd", "lib", "libdgr_hip_exact.so")
+GRADS = ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dview")
 
 
-def run(lib, P, W, H):
+def run(fast_alpha, P, W, H):
     env = dict(os.environ)
     env.pop("DGR_HIP_LIB", None)
-    if lib:
-        env["DGR_HIP_LIB"] = lib
+    env["DGR_FAST_ALPHA"] = str(fast_alpha)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "error_budget.py"), str(P), str(W), str(H)],
-                         env=env, capture_output=True, text=True, timeout=600)
+                         env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
 @pytest.mark.parametrize("shape", [(100000, 640, 480), (500000, 1920, 1080)])
-def test_fast_alpha_stays_inside_the_references_own_spread(shape):
-    assert os.path.exists(EXACT), "make -C diff-gaussian-rasterization_amd builds the measurement library"
-    fast, exact = run(None, *shape), run(EXACT, *shape)
-    assert fast["lib"] == "default" and exact["lib"].endswith("libdgr_hip_exact.so")
-    for d in (fast, exact):
-        assert d["integer_path_exact"] and d["n_contrib_mismatch"] <= 2
-    print("\n[error budget]", shape, {v: {k: "%.1e" % x["max_abs"] for k, x in d["end_to_end"].items()}
-                                       for v, d in (("fast", fast), ("exact", exact))})
-    # measured: config 3 fast 5.8e-5 / exact 6.7e-6 abs on dL_dview (scale 1.6); 640x480 5.2e-5 / 1.5e-5.
-    # The reference itself moves by 5e-4 there between an FMA and a non-FMA build of its own sources.
-    for d in (fast, exact):
-        assert d["end_to_end"]["dL_dview"]["max_abs"] < 2e-4
-        for k in ("dL_dmeans3D", "dL_dscales"):
-            assert d["end_to_end"][k]["max_abs"] < 2e-4 and d["isolated"][k]["max_abs"] < 1e-4
-    # with alpha evaluated as the reference writes it the stage-isolated backward agrees to rounding
-    for k, x in exact["isolated"].items():
-        assert x["max_abs"] <= 1e-5 * max(1.0, x["scale"]), k
-    assert exact["end_to_end"]["dL_dview"]["max_abs"] <= fast["end_to_end"]["dL_dview"]["max_abs"]
+def test_default_alpha_path_meets_the_north_star_tolerance(shape):
+    d = run(0, *shape)
+    assert d["fast_alpha"] == 0 and d["lib"] == "default"
+    print("\n[error budget, default]", shape, {k: "%.1e" % x["max_abs"] for k, x in d["end_to_end"].items()},
+          {k: d[k]["differing_values"] for k in d if k.startswith("img_")})
+    assert d["integer_path_exact"] and d["n_contrib_mismatch"] == 0  # no pixel decides a hard threshold differently
+    # the alpha image and the median depth carry the reference's bits; colour and depth are summed with fused
+    # multiply-adds (one rounding fewer than the reference's (c alpha) T + C) and stay within a few ulp
+    assert d["img_opacity_map"]["differing_values"] == 0 and d["img_depth_median"]["differing_values"] == 0
+    assert d["img_color"]["max_abs"] <= 1e-6 and d["img_depth"]["max_abs"] <= 1e-5
+    for lab in ("end_to_end", "isolated"):
+        for k in GRADS:
+            x = d[lab][k]
+            assert x["max_abs"] <= 1e-5 * max(1.0, x["scale"]), (lab, k, x)
+    assert d["end_to_end"]["dL_dview"]["max_abs"] <= 1e-5  # north_star, absolute
+
+
+@pytest.mark.parametrize("shape", [(500000, 1920, 1080)])
+def test_fast_alpha_option_stays_inside_the_references_own_spread(shape):
+    fast, default = run(1, *shape), run(0, *shape)
+    assert fast["fast_alpha"] == 1
+    print("\n[error budget, fast_alpha]", shape, {k: "%.1e" % x["max_abs"] for k, x in fast["end_to_end"].items()})
+    assert fast["integer_path_exact"] and fast["n_contrib_mismatch"] <= 2
+    # measured: 5.8e-5 abs on dL_dview (scale 1.6) at config 3.  The reference itself moves by 5e-4 there
+    # between an FMA and a non-FMA build of its own sources.
+    assert fast["end_to_end"]["dL_dview"]["max_abs"] < 2e-4
+    for k in ("dL_dmeans3D", "dL_dscales"):
+        assert fast["end_to_end"][k]["max_abs"] < 2e-4 and fast["isolated"][k]["max_abs"] < 1e-4
+    assert default["end_to_end"]["dL_dview"]["max_abs"] <= fast["end_to_end"]["dL_dview"]["max_abs"]

@@ -24,13 +24,19 @@ def test_full_forward(oracle, case):
     st, ref, _ = hh.oracle_full(oracle, s, deg, backward=False)
     assert np.array_equal(d["radii"], ref["radii"]) and d["num_rendered"] == ref["num_rendered"]
     assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    # the default alpha path carries the host's bits (csrc/exact_math.h): every threshold decision, the final transmittance
+    # and the "uncertainty" image (the sum of alpha T) are the restatement's; colour and depth are summed with fused
+    # multiply-adds and stay within a few ulp
     for k in ("color", "depth", "uncertainty"):
         assert d[k].shape == ref[k].shape
-        assert_image_close(d[k], ref[k], k)
-    assert np.mean(hh.hip_state("n_contrib", s, d) != st.get("n_contrib")) <= 1e-4
-    assert np.mean(hh.hip_state("n_valid", s, d) != st.get("n_valid_contrib")) <= 1e-4
-    assert abs(d["num_related"] - ref["num_related"]) <= max(4, 2e-6 * ref["num_related"])  # threshold flips only
-    assert_image_close(hh.hip_state("final_T", s, d).view(np.float32), st.get("final_T"), "final_T", tol=1e-6)
+    assert np.array_equal(d["uncertainty"], ref["uncertainty"])
+    for k in ("color", "depth"):
+        a, b = d[k].astype(np.float64), ref[k].astype(np.float64)
+        assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(1.0, np.abs(b))), (k, float(np.abs(a - b).max()))
+    assert np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
+    assert np.array_equal(hh.hip_state("n_valid", s, d), st.get("n_valid_contrib"))
+    assert d["num_related"] == ref["num_related"]
+    assert np.array_equal(hh.hip_state("final_T", s, d).view(np.float32), st.get("final_T"))
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -41,9 +47,10 @@ def test_full_backward(oracle, case):
     out, d = hh.hip_full_forward(s, deg)
     g = hh.hip_full_backward(s, deg, out, grads=grads)
     st, ref, gr = hh.oracle_full(oracle, s, deg, grads=grads)
-    # full stores the final transmittance itself (no 1 - alpha cancellation), so end-to-end tolerances are tight
-    same = np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
-    tol = dict(rel_to_max=2e-5, elem_rtol=2e-3, elem_frac=1e-3) if same else dict(rel_to_max=3e-3, elem_rtol=2e-2, elem_frac=2e-2)
+    # both forward passes walk the same lists (no threshold decision differs: the default alpha path carries the host's
+    # bits), so one unconditional bar
+    assert np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
+    tol = dict(rel_to_max=1e-5, elem_rtol=2e-3, elem_frac=1e-3)
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
         assert g[k].shape == gr[k].shape, k
         assert_grad_close(g[k], gr[k], k, **tol)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak run of the parity checks of tests/test_hip_random_sweep.py over many more random draws (not part of the test suite:
 minutes of oracle time).  usage: python tests/tools/soak_parity.py [n_light] [n_full] [seed]
-DGR_SOAK_ROWS=1 runs the light draws through the opt-in rows backward (dgr_set_option "bwd_rows")."""
+DGR_FAST_ALPHA=1 in the environment runs the draws through the fast-alpha option."""
 import os
 import sys
 import time
@@ -15,9 +15,6 @@ from util import assert_grad_close, assert_image_close, make_scene, mask_flipped
 from oracle import oracle as O  # noqa: E402
 
 O.use_cmath(False)
-if os.environ.get("DGR_SOAK_ROWS") == "1":
-    from dgr_amd import _capi
-    _capi.set_option("bwd_rows", 1)
 n_light = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_full = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 7)
