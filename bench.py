@@ -56,6 +56,8 @@ def algorithmic_bytes(stage, P, V, R, N, M):
         "preprocess_fwd": 44 * P + 8 * P + (sh + 67) * V,   # means/scales/rot/opacity in, radii + tiles_touched out; SH + state per visible
         "scan_blocks": 8 * P,                                # the scan of tiles_touched
         "count_rank": 8 * P + 12 * V,                        # duplicateWithKeys: its reads
+        "bin_segments": 8 * P + 12 * V + 12 * R,             # segment binning, first kernel: duplicateWithKeys' reads and key/value pairs
+        "bin_tiles": 24 * R + 8 * R,                         # ... second kernel: the sort's read + write and the range detection
         "emit_instances": 12 * R,                            # ... its key/value pairs out
         "sort_tiles": 24 * R,                                # one read + one write of the 12-byte pairs
         "scan_tiles": 8 * R,                                 # range detection
@@ -396,10 +398,7 @@ def main():
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
                        "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "views_per_step": max(1, Vb),
                        "ms_per_view": 1e3 * elapsed / args.steps / max(1, Vb), "hipgraph_replay": bool(args.graph),
-                       "tile_count": ("global atomics while several views are in flight (dgr_amd.multiview.ViewStreams; their wait "
-                                      "is filled by the other views), LDS histograms for ms_per_view_one_stream, stage_ms and the "
-                                      "roofline's isolated figure" if (views is not None and not captured) else
-                                      "library default (LDS histograms up to 4 Mi instances)"),
+                       "binning": "two-level segment binning (csrc/segment_binning.hip)" if _capi.get_option("lds_count") else "global tile counters (csrc/binning.hip)",
                        "pair_evals_per_view": pair_evals,
                        "pair_evals_per_s": None if pair_evals is None else pair_evals * views_per_s / world, "tight_cull": bool(args.tight_cull),
                        "view_hbm_frac_one_stream": None if not serial_ms else

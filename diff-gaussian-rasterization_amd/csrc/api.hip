@@ -18,6 +18,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
 
 #include "../../include/dgr_hip.h"
@@ -26,6 +27,29 @@
 
 namespace dgr {
 thread_local LaunchEvents* g_launch_events = nullptr;
+}
+namespace { extern std::atomic<int> g_blend_wgs_per_cu; }
+namespace dgr {
+size_t blend_pad_bytes(const void* kernel) {
+    const int n = g_blend_wgs_per_cu.load(std::memory_order_relaxed);
+    if (n < 3 || n > 7) return 0;
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, size_t>> known;  // static LDS bytes of the blend kernels seen so far
+    size_t static_lds = ~(size_t)0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const auto& e : known)
+            if (e.first == kernel) static_lds = e.second;
+        if (static_lds == ~(size_t)0) {
+            hipFuncAttributes attr{};
+            if (hipFuncGetAttributes(&attr, kernel) != hipSuccess) return 0;
+            static_lds = attr.sharedSizeBytes;
+            known.emplace_back(kernel, static_lds);
+        }
+    }
+    const size_t per = (size_t)(160 * 1024) / (size_t)n;  // LDS budget of one workgroup when exactly n fit a CU
+    return per > static_lds ? ((per - static_lds) & ~(size_t)255) : 0;
+}
 }
 
 namespace {
@@ -104,10 +128,11 @@ struct StageProf {
     unsigned seen = 0;  // launches of this stage since it was selected
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
-StageProf g_prof[] = {{"zero_counters"}, {"preprocess_fwd"}, {"scan_blocks"}, {"count_rank"}, {"scan_tiles"}, {"emit_instances"},
-                      {"sort_tiles"}, {"render_fwd"}, {"zero_scratch"}, {"render_bwd"}, {"preprocess_bwd"}};
-enum { ST_ZERO_FWD, ST_PRE_FWD, ST_SCAN_BLOCKS, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD, ST_ZERO, ST_RENDER_BWD,
-       ST_PRE_BWD, ST_COUNT };
+StageProf g_prof[] = {{"zero_counters"}, {"preprocess_fwd"}, {"scan_blocks"}, {"bin_segments"}, {"bin_tiles"}, {"count_rank"},
+                      {"scan_tiles"}, {"emit_instances"}, {"sort_tiles"}, {"render_fwd"}, {"zero_scratch"}, {"render_bwd"},
+                      {"preprocess_bwd"}};
+enum { ST_ZERO_FWD, ST_PRE_FWD, ST_SCAN_BLOCKS, ST_BIN_SEGMENTS, ST_BIN_TILES, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD,
+       ST_ZERO, ST_RENDER_BWD, ST_PRE_BWD, ST_COUNT };
 std::mutex g_prof_mu;
 std::atomic<int> g_profile_every{1};
 
@@ -120,18 +145,20 @@ std::atomic<int> g_tight_cull{0};
 //       T_final = 1 - alpha and its divisions by (1 - alpha) amplify the last-bit differences to 6e-5 abs at config 3.
 // Set it before the forward whose backward should use it (forward and backward of a view must use the same mode).
 // Initial value from DGR_FAST_ALPHA (for A/B runs).
-std::atomic<int> g_alpha_mode{[] { const char* e = getenv("DGR_FAST_ALPHA"); return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0; }()};
-// dgr_set_option("lds_count", v): how the forward counts tile instances (csrc/binning.hip).
-//   1 (default) = in per-workgroup LDS histograms when the frame's histogram fits LDS and the binning buffer holds at most
-//       DGR_LDS_COUNT_AUTO_MAX instances; larger jobs count with returning global atomics on per-tile counters (round 2's
-//       path: inside preprocess_fwd when presized).  The split is a measured one: the LDS count is faster on an otherwise
-//       idle GPU at every size (one view at a time: 0.545 -> 0.51 ms at config 3, 1.74 -> 1.69 ms at config 4), but the
-//       global atomics WAIT on the memory-side atomic unit with the CUs idle, and under several views in flight another
-//       view's kernels fill that wait -- three views in flight: equal at config 3 (R = 1.65 M), LDS 6 % slower at config 4
-//       (R = 6.6 M), 4 % at config 5 (profiles/count_ab.sh);
-//   2 = LDS whenever the histogram fits;  0 = never (global atomics).  Initial value from DGR_LDS_COUNT (for A/B runs).
-constexpr int DGR_LDS_COUNT_AUTO_MAX = 4 << 20;
+std::atomic<int> g_alpha_mode{[] { const char* e = getenv("DGR_FAST_ALPHA"); return (e && e[0] == '1') ? 1 : 0; }()};
+// dgr_set_option("lds_count", v): how the forward bins tile instances.
+//   1 (default) = the two-level segment binning (csrc/segment_binning.hip) whenever the frame's segment tables fit LDS;
+//   0 = returning global atomics on per-tile counters (csrc/binning.hip; inside preprocess_fwd when presized), which also
+//       serves frames too large for the segment tables.  (2 is accepted as a synonym of 1.)
+// Measured, round 5 (profiles/r5/): the segment binning is faster one view at a time at every size (config 3: 0.51 against
+// 0.59 ms per view, config 4: 1.71 / 1.85, config 5: 4.54 / 4.86) and equal or faster with three views in flight (0.455 /
+// 0.466, 1.57 / 1.57, 4.27 / 4.53), so nothing switches by job size or by the number of views in flight any more.
+// Initial value from DGR_LDS_COUNT (for A/B runs).
 std::atomic<int> g_lds_count{[] { const char* e = getenv("DGR_LDS_COUNT"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; }()};
+
+// dgr_set_option("blend_wgs_per_cu", n): cap on the blend kernels' workgroups per CU (kernels.h: launch_blend); 0 = none.
+// Initial value from DGR_BLEND_WGS_PER_CU (for A/B runs).
+std::atomic<int> g_blend_wgs_per_cu{[] { const char* e = getenv("DGR_BLEND_WGS_PER_CU"); return (e && e[0] >= '3' && e[0] <= '7') ? e[0] - '0' : 0; }()};
 
 // A kernel stage hands its two events to the stage's first kernel launch (dgr::launch, kernels.h): they then hold
 // that kernel's start and end.  A stage without a kernel (the scratch memset) is bracketed with hipEventRecord.
@@ -196,14 +223,15 @@ int zero_outputs(const FwdCommon& c, hipStream_t st) {
 // block and scan_blocks turns them into offsets and num_rendered.  Presized path (the binning buffer exists already):
 // the kernel also takes the tile-counter atomics and stores the ranks (count_rank.h), behind one small clear of the
 // counters; scan_blocks and count_rank disappear.
-// Presized path, counting mode: COUNT_LDS = per-workgroup LDS histograms after preprocess (binning.hip; frames whose tile
-// histogram fits LDS), COUNT_FUSED = returning global atomics inside preprocess_fwd.
-// Callback path (the binning buffer is sized after a host read of num_rendered): COUNT_LDS_CALLBACK = the same LDS count
-// behind scan_blocks, COUNT_CALLBACK = the count_rank kernel on global tile counters (R = 0, or a frame too large for LDS).
+// Presized path, binning mode: COUNT_LDS = the two-level segment binning after preprocess (segment_binning.hip; frames
+// whose segment tables fit LDS), COUNT_FUSED = returning global atomics inside preprocess_fwd (binning.hip).
+// Callback path (the binning buffer is sized after a host read of num_rendered): COUNT_LDS_CALLBACK = the same segment
+// binning behind scan_blocks, COUNT_CALLBACK = the count_rank kernel on global tile counters (R = 0, or a frame too large).
 enum { COUNT_CALLBACK = 0, COUNT_FUSED = 1, COUNT_LDS = 2, COUNT_LDS_CALLBACK = 3 };
 int presized_count_mode(int W, int H, int capacity) {
     const int v = g_lds_count.load();
-    const bool lds = v != 0 && dgr::count_lds_fits(dgr::tiles_x(W) * dgr::tiles_y(H)) && (v == 2 || capacity <= DGR_LDS_COUNT_AUTO_MAX);
+    (void)capacity;
+    const bool lds = v != 0 && dgr::segment_binning_fits(W, H);
     return lds ? COUNT_LDS : COUNT_FUSED;
 }
 int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, hipStream_t st,
@@ -228,7 +256,7 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
     (void)tiles;
     if (bin && mode == COUNT_LDS) {
         // nothing to clear: the kernel leaves its per-block instance totals (and the `prefiltered` flag) in
-        // geom.block_tiles, count_lds / scan_table take it from there
+        // geom.block_tiles, bin_segments / bin_tiles take it from there
         { ScopedStage t(ST_PRE_FWD, st); HIP_TRY(dgr::launch_preprocess_fwd(a, st)); }
         return DGR_OK;
     }
@@ -254,12 +282,11 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
     if (mode == COUNT_LDS || mode == COUNT_LDS_CALLBACK) {
         const bool cb = mode == COUNT_LDS_CALLBACK;
-        const dgr::CountTable ct = dgr::carve_count_table(binning_base + bin.bytes, c.W, c.H);
-        { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_lds(c.P, geom, bin, ct, gx, tiles, capacity, cb, st)); }
-        { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_table(c.P, geom, img, ct, tiles, capacity, cb, st)); }
-        if (!cb) { const int rc = early_status_post(img.status, st); if (rc) return rc; }
-        { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st, ct.table, tiles, dgr::count_lds_workgroups(c.P))); }
-        { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
+        const dgr::SegmentTables tb = dgr::carve_segment_tables(binning_base + bin.bytes, c.W, c.H);
+        const int ss = dgr::segment_shift(c.W, c.H, capacity);
+        { ScopedStage t(ST_BIN_SEGMENTS, st); HIP_TRY(dgr::launch_bin_segments(c.P, geom, bin, tb, gx, gy, ss, capacity, cb, st)); }
+        { ScopedStage t(ST_BIN_TILES, st); HIP_TRY(dgr::launch_bin_tiles(c.P, geom, img, bin, tb, gx, gy, ss, capacity, cb, st)); }
+        if (!cb) { const int rc = early_status_post(img.status, st); if (rc) return rc; }  // (bin_tiles writes the status word)
         return DGR_OK;
     }
     const bool fused = mode == COUNT_FUSED;
@@ -343,38 +370,53 @@ struct BatchStreams {
     hipEvent_t join[DGR_BATCH_MAX_STREAMS - 1] = {};
     hipEvent_t stage[DGR_MAX_BATCH_VIEWS] = {};  // pipelined order: view v's binning (forward) / cleared scratch (backward) is ready
 };
-thread_local BatchStreams g_batch;
+// One set per device and thread: streams and events belong to the device that was current when they were created, and a
+// single-process loop that alternates between GPUs (dgr_amd._capi.on_device) must neither re-create them on every call
+// nor lose the old ones.
+constexpr int DGR_BATCH_MAX_DEVICES = 32;
+thread_local BatchStreams g_batch_pool[DGR_BATCH_MAX_DEVICES];
+thread_local BatchStreams* g_batch_p = nullptr;
 int batch_streams_ready() {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (g_batch.device == dev) return DGR_OK;
-    // (streams and events belong to the device that was current when they were created; a thread that moves to another
-    //  device gets new ones, the old ones stay with their device)
-    g_batch = BatchStreams{};
+    if (dev < 0 || dev >= DGR_BATCH_MAX_DEVICES) { g_last_error = "device index above DGR_BATCH_MAX_DEVICES"; return DGR_ERR_BAD_ARGUMENT; }
+    g_batch_p = &g_batch_pool[dev];
+    if (g_batch_p->device == dev) return DGR_OK;
     for (int i = 0; i < DGR_BATCH_MAX_STREAMS - 1; i++) {
-        HIP_TRY(hipStreamCreateWithFlags(&g_batch.helper[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&g_batch.join[i], hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&g_batch_p->helper[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&g_batch_p->join[i], hipEventDisableTiming));
     }
-    HIP_TRY(hipEventCreateWithFlags(&g_batch.fork, hipEventDisableTiming));
-    for (int v = 0; v < DGR_MAX_BATCH_VIEWS; v++) HIP_TRY(hipEventCreateWithFlags(&g_batch.stage[v], hipEventDisableTiming));
-    g_batch.device = dev;
+    HIP_TRY(hipEventCreateWithFlags(&g_batch_p->fork, hipEventDisableTiming));
+    for (int v = 0; v < DGR_MAX_BATCH_VIEWS; v++) HIP_TRY(hipEventCreateWithFlags(&g_batch_p->stage[v], hipEventDisableTiming));
+    g_batch_p->device = dev;
     return DGR_OK;
 }
 // stream of view v among K; fork: the helpers wait for what the caller's stream has enqueued so far
-inline hipStream_t batch_stream(hipStream_t main, int v, int K) { return (v % K == 0) ? main : g_batch.helper[v % K - 1]; }
+inline hipStream_t batch_stream(hipStream_t main, int v, int K) { return (v % K == 0) ? main : g_batch_p->helper[v % K - 1]; }
 int batch_fork(hipStream_t main, int K) {
     if (K <= 1) return DGR_OK;
-    HIP_TRY(hipEventRecord(g_batch.fork, main));
-    for (int i = 0; i < K - 1; i++) HIP_TRY(hipStreamWaitEvent(g_batch.helper[i], g_batch.fork, 0));
+    HIP_TRY(hipEventRecord(g_batch_p->fork, main));
+    for (int i = 0; i < K - 1; i++) HIP_TRY(hipStreamWaitEvent(g_batch_p->helper[i], g_batch_p->fork, 0));
     return DGR_OK;
 }
 int batch_join(hipStream_t main, int K) {
     for (int i = 0; i < K - 1; i++) {
-        HIP_TRY(hipEventRecord(g_batch.join[i], g_batch.helper[i]));
-        HIP_TRY(hipStreamWaitEvent(main, g_batch.join[i], 0));
+        HIP_TRY(hipEventRecord(g_batch_p->join[i], g_batch_p->helper[i]));
+        HIP_TRY(hipStreamWaitEvent(main, g_batch_p->join[i], 0));
     }
     return DGR_OK;
 }
+// After batch_fork the helper streams may hold kernels that touch the caller's buffers: whatever way the call leaves --
+// an error in the middle of the view loop included -- the caller's stream must wait for them (and a stream capture must
+// see the forked streams rejoined).  done() performs the join once and reports its status.
+struct BatchJoinGuard {
+    hipStream_t main;
+    int K;
+    bool armed;
+    BatchJoinGuard(hipStream_t m, int k) : main(m), K(k), armed(true) {}
+    int done() { armed = false; return batch_join(main, K); }
+    ~BatchJoinGuard() { if (armed) batch_join(main, K); }
+};
 
 // ---- state export (tests / profiling) ----
 enum ExportKind { EX_MEANS2D, EX_CONIC_OPACITY, EX_RGB, EX_CLAMPED, EX_TILES_TOUCHED, EX_KEYS };
@@ -436,8 +478,9 @@ const char* dgr_version(void) { return "dgr_hip 0.1 gfx950"; }
 size_t dgr_geometry_bytes(int P) { return dgr::carve_geometry(nullptr, P).bytes; }
 size_t dgr_image_bytes(int width, int height) { return dgr::carve_image(nullptr, width, height).bytes; }
 size_t dgr_binning_bytes(int cap, int width, int height) {
-    // the sorted list, keys, ranks and tags of `cap` instances, then the forward-only workspace of the LDS count
-    return dgr::carve_binning(nullptr, (size_t)(cap > 0 ? cap : 0)).bytes + dgr::carve_count_table(nullptr, width, height).bytes;
+    // the sorted list, key scratch, ranks / pair columns and pair keys of `cap` instances, then the forward-only tables of
+    // the segment binning
+    return dgr::carve_binning(nullptr, (size_t)(cap > 0 ? cap : 0)).bytes + dgr::carve_segment_tables(nullptr, width, height).bytes;
 }
 size_t dgr_light_backward_scratch_bytes(int P, int, int) { return dgr::carve_backward_scratch(nullptr, P).bytes; }
 
@@ -465,6 +508,12 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     if (P == 0) {
         if (status) HIP_TRY(hipMemsetAsync(status, 0, 16, st));
         return zero_outputs(c, st);
+    }
+    // (the binning buffer also holds the segment binning's tables behind its per-instance arrays: dgr_binning_bytes() is
+    //  non-zero for a capacity of 0, and a NULL buffer is never valid for P > 0)
+    if (!geometry_buffer || !image_buffer || !binning_buffer || binning_capacity < 0) {
+        g_last_error = "presized forward: geometry, binning and image buffers are required (sizes: dgr_*_bytes)";
+        return DGR_ERR_BAD_ARGUMENT;
     }
     dgr::GeometryView geom = dgr::carve_geometry(geometry_buffer, P);
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
@@ -592,6 +641,12 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
         if (status) HIP_TRY(hipMemsetAsync(status, 0, 16, st));
         return zero_outputs(c, st);
     }
+    // (the binning buffer also holds the segment binning's tables behind its per-instance arrays: dgr_binning_bytes() is
+    //  non-zero for a capacity of 0, and a NULL buffer is never valid for P > 0)
+    if (!geometry_buffer || !image_buffer || !binning_buffer || binning_capacity < 0) {
+        g_last_error = "presized forward: geometry, binning and image buffers are required (sizes: dgr_*_bytes)";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
     dgr::GeometryView geom = dgr::carve_geometry(geometry_buffer, P);
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     if (status) img.status = status;  // the kernels write the caller's status word directly
@@ -716,7 +771,7 @@ int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* vie
                           w.out_color, w.out_depth, w.out_median_depth, w.out_alpha, w.gt_depth, w.out_depth_var,
                           w.gau_uncertainty, w.gau_related_pixels, w.radii};
         if (!w.viewmatrix || !w.projmatrix || !w.cam_pos || !w.out_color || !w.out_depth) { g_last_error = "view without camera or outputs"; return DGR_ERR_BAD_ARGUMENT; }
-        if (P > 0 && (!w.geometry_buffer || !w.image_buffer || (!w.binning_buffer && w.binning_capacity > 0) || w.binning_capacity < 0)) {
+        if (P > 0 && (!w.geometry_buffer || !w.image_buffer || !w.binning_buffer || w.binning_capacity < 0)) {
             g_last_error = "view without state buffers";
             return DGR_ERR_BAD_ARGUMENT;
         }
@@ -741,9 +796,9 @@ int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* vie
         bin[v] = dgr::carve_binning(views[v].binning_buffer, (size_t)views[v].binning_capacity);
     }
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    // One preprocess launch for all views needs the LDS count behind it (its epilogue leaves per-block instance totals);
-    // frames whose tile histogram does not fit LDS, or "lds_count" = 0, take the one-view front end per view.
-    const bool shared_front = g_lds_count.load() != 0 && dgr::count_lds_fits(gx * gy);
+    // One preprocess launch for all views needs the segment binning behind it (its epilogue leaves per-block instance
+    // totals); frames whose segment tables do not fit LDS, or "lds_count" = 0, take the one-view front end per view.
+    const bool shared_front = g_lds_count.load() != 0 && dgr::segment_binning_fits(width, height);
     if (shared_front) {
         dgr::PreprocessFwdBatchArgs b{};
         dgr::PreprocessFwdArgs& a = b.base;
@@ -767,8 +822,9 @@ int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* vie
     const bool pipeline = g_batch_order.load() == 1 && n_views > 1 && g_batch_streams.load() > 1;
     const int K = pipeline ? 2 : batch_stream_count(n_views);
     if ((rc = batch_fork(st, K))) return rc;
+    BatchJoinGuard joined(st, K);  // (an early return below still rejoins the helper streams)
     for (int v = 0; v < n_views; v++) {
-        hipStream_t sv = pipeline ? g_batch.helper[0] : batch_stream(st, v, K);
+        hipStream_t sv = pipeline ? g_batch_p->helper[0] : batch_stream(st, v, K);
         const int cap = views[v].binning_capacity;
         int mode = COUNT_LDS;
         if (!shared_front) {
@@ -777,13 +833,13 @@ int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* vie
         }
         if ((rc = binning_stages(cv[v], geom[v], img[v], bin[v], cap, sv, mode, views[v].binning_buffer))) return rc;
         if (pipeline) {  // the blend of view v on the caller's stream, behind its binning on the helper stream
-            HIP_TRY(hipEventRecord(g_batch.stage[v], sv));
-            HIP_TRY(hipStreamWaitEvent(st, g_batch.stage[v], 0));
+            HIP_TRY(hipEventRecord(g_batch_p->stage[v], sv));
+            HIP_TRY(hipStreamWaitEvent(st, g_batch_p->stage[v], 0));
             sv = st;
         }
         if ((rc = forward_back(cv[v], geom[v], img[v], bin[v], sv))) return rc;
     }
-    return pipeline ? DGR_OK : batch_join(st, K);  // (pipeline: the helper's last kernel has been waited for already)
+    return joined.done();
 }
 
 int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_grad* views, int P, int D, int M,
@@ -819,16 +875,17 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
     const int K = pipeline ? 2 : batch_stream_count(n_views);
     dgr::PreprocessBwdBatchArgs bb{};
     if ((rc = batch_fork(st, K))) return rc;
+    BatchJoinGuard joined(st, K);  // (an early return below still rejoins the helper streams)
     for (int v = 0; v < n_views; v++) {
         const dgr_light_view_grad& w = views[v];
-        hipStream_t sv = pipeline ? g_batch.helper[0] : batch_stream(st, v, K);
+        hipStream_t sv = pipeline ? g_batch_p->helper[0] : batch_stream(st, v, K);
         dgr::GeometryView geom = dgr::carve_geometry(w.geometry_buffer, P);
         dgr::ImageView img = dgr::carve_image(w.image_buffer, width, height);
         dgr::BackwardScratch sc = dgr::carve_backward_scratch(w.scratch, P);
         { ScopedStage t(ST_ZERO, sv); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, sv)); }
         if (pipeline) {  // the blend backward of view v on the caller's stream, behind its cleared scratch
-            HIP_TRY(hipEventRecord(g_batch.stage[v], sv));
-            HIP_TRY(hipStreamWaitEvent(st, g_batch.stage[v], 0));
+            HIP_TRY(hipEventRecord(g_batch_p->stage[v], sv));
+            HIP_TRY(hipStreamWaitEvent(st, g_batch_p->stage[v], 0));
             sv = st;
         }
         dgr::RenderBwdLightArgs r{};
@@ -843,7 +900,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
         q.radii = w.radii ? w.radii : geom.radii; q.geom = geom; q.acc = sc.acc; q.dL_dmean2D = w.dL_dmean2D;
         q.pose_part = sc.pose_part; q.ticket = sc.ticket; q.dL_dview = w.dL_dview;
     }
-    if (!pipeline && (rc = batch_join(st, K))) return rc;
+    if ((rc = joined.done())) return rc;
     dgr::PreprocessBwdArgs& b = bb.base;
     b.P = P; b.D = D; b.M = M; b.W = width; b.H = height; b.means3D = means3D; b.shs = shs; b.scales = scales;
     b.rotations = rotations; b.scale_modifier = scale_modifier; b.cov3D_precomp = cov3D_precomp;
@@ -1036,13 +1093,10 @@ int dgr_early_status_wait(int* host_status4) {
 
 int dgr_set_option(const char* name, int value) {
     const std::string n(name ? name : "");
+    if (n == "blend_wgs_per_cu") { g_blend_wgs_per_cu.store((value >= 3 && value <= 7) ? value : 0); return DGR_OK; }
     if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }
     if (n == "fast_alpha") {
-#ifdef DGR_ALPHA_EXPERIMENT
-        g_alpha_mode.store(value < 0 ? 0 : value > 3 ? 3 : value);
-#else
         g_alpha_mode.store(value ? 1 : 0);
-#endif
         return DGR_OK;
     }
     if (n == "lds_count") { g_lds_count.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
@@ -1054,6 +1108,7 @@ int dgr_set_option(const char* name, int value) {
 }
 int dgr_get_option(const char* name) {
     const std::string n(name ? name : "");
+    if (n == "blend_wgs_per_cu") return g_blend_wgs_per_cu.load();
     if (n == "tight_cull") return g_tight_cull.load();
     if (n == "fast_alpha") return g_alpha_mode.load();
     if (n == "lds_count") return g_lds_count.load();
@@ -1120,11 +1175,6 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
     const std::string n(name);
     if (n == "depths") return copy(g.depths, 4 * (size_t)P) ? -1 : P;
     if (n == "radii") return copy(g.radii, 4 * (size_t)P) ? -1 : P;
-    if (n == "cov3D") {  // two planes (float4 {c0..c3}, float2 {c4, c5}) -> the reference's [P, 6]
-        if (hipMemcpy2DAsync(dst, 24, g.cov3D, 16, 16, (size_t)P, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
-        if (hipMemcpy2DAsync((char*)dst + 16, 24, g.cov3D + 4 * (size_t)P, 8, 8, (size_t)P, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
-        return 6L * P;
-    }
     if (n == "means2D") return geomk(EX_MEANS2D) ? -1 : 2L * P;
     if (n == "conic_opacity") return geomk(EX_CONIC_OPACITY) ? -1 : 4L * P;
     if (n == "rgb") return geomk(EX_RGB) ? -1 : 3L * P;

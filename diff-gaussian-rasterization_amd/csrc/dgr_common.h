@@ -4,7 +4,8 @@
 // (L/cuda_rasterizer/rasterizer_impl.h:29-72, rasterizer_impl.cu:155-193).  The buffers stay
 // opaque at the boundary, so the layout here is chosen for the MI355X kernels instead:
 //   geometry : one 48-byte render record per Gaussian (3 x float4, gathered as whole 16-B
-//              pieces by the blend kernels), depth, radius, cov3D, tile rect (4 x u16), clamp bits
+//              pieces by the blend kernels), depth, radius, tile rect (4 x u16), clamp bits (the 3D covariance is
+//              NOT kept: the backward re-forms it from scale and rotation, same expression, same bits)
 //   image    : per-tile {count, fill, range} + per-pixel n_contrib (+ full: final T, n_valid)
 //   binning  : per-instance 64-bit sort keys (depth bits << 32 | gaussian id), the sorted id list, arrival ranks
 #pragma once
@@ -34,7 +35,6 @@ struct GeometryView {
     float4* rec;        // [3P]
     float* depths;      // [P]
     int* radii;         // [P] internal copy (the caller's `radii` may be NULL)
-    float* cov3D;       // [4P] + [2P]: plane {c0, c1, c2, c3} (float4 per Gaussian), then plane {c4, c5} (float2)
     ushort4* rect;      // [P] {xmin, ymin, xmax, ymax} in tiles; all-zero when culled
     uint8_t* clamped;   // [P] bit c set <=> channel c was clamped at 0
     uint32_t* goff;     // [P] index of the Gaussian's first instance in Gaussian-major order (the reference's
@@ -52,7 +52,6 @@ __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
     g.rec = (float4*)(base + o);      o = align_up(o + sizeof(float4) * 3 * (size_t)P, 256);
     g.depths = (float*)(base + o);    o = align_up(o + sizeof(float) * (size_t)P, 256);
     g.radii = (int*)(base + o);       o = align_up(o + sizeof(int) * (size_t)P, 256);
-    g.cov3D = (float*)(base + o);     o = align_up(o + sizeof(float) * 6 * (size_t)P, 256);
     g.rect = (ushort4*)(base + o);    o = align_up(o + sizeof(ushort4) * (size_t)P, 256);
     g.clamped = (uint8_t*)(base + o); o = align_up(o + (size_t)P, 256);
     g.goff = (uint32_t*)(base + o);   o = align_up(o + sizeof(uint32_t) * (size_t)P, 256);
@@ -98,6 +97,10 @@ struct BinningView {
                            //       backward can find it without knowing the capacity
     uint64_t* keys;        // [cap] (depth bits << 32 | gaussian id), grouped by tile, unsorted (sort_tiles reads them)
     uint32_t* ranks;       // [cap] Gaussian-major: arrival rank of each instance within its tile (count_rank -> emit)
+    // segment binning (segment_binning.hip): one PAIR per (Gaussian, tile row, 16-tile segment) it touches
+    uint64_t* pair_keys;   // [cap] (depth bits << 32 | gaussian id), grouped by producing workgroup, then by segment
+    uint8_t* pair_cov;     // [cap] columns covered inside the segment: first | last << 4  (shares the bytes of `ranks`:
+                           //       a forward uses either the global-atomic count or the segment binning)
     size_t bytes;
 };
 __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
@@ -105,29 +108,34 @@ __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
     size_t o = 0;
     b.point_list = (uint32_t*)(base + o); o = align_up(o + 4 * cap, 256);
     b.keys = (uint64_t*)(base + o);       o = align_up(o + 8 * cap, 256);
-    b.ranks = (uint32_t*)(base + o);      o = align_up(o + 4 * cap, 256);
+    b.ranks = (uint32_t*)(base + o);      b.pair_cov = (uint8_t*)(base + o); o = align_up(o + 4 * cap, 256);
+    b.pair_keys = (uint64_t*)(base + o);  o = align_up(o + 8 * cap, 256);
     b.bytes = o;
     return b;
 }
 
-// Forward-only workspace of the LDS count (binning.hip), carved behind the binning arrays: row w of `table` is the tile
-// histogram of counting workgroup w (afterwards: slot bases), seg[s][w] its sums over 64-tile segments.
-#ifndef DGR_COUNT_WGS
-#define DGR_COUNT_WGS 256              // one persistent counting workgroup per CU
-#endif
-#define DGR_COUNT_LDS_MAX_TILES 40000  // 160 000 B of the 160 KB of LDS: 3840x2160 has 32 400 tiles
-struct CountTable {
-    uint32_t* table;  // [DGR_COUNT_WGS * tiles]
-    uint32_t* seg;    // [ceil(tiles / 64) * DGR_COUNT_WGS]
+// Forward-only workspace of the segment binning (segment_binning.hip), carved behind the binning arrays.  A tile row is cut
+// into segments of 16, 8 or 4 tiles (chosen per call; the tables are carved for 4); workgroup w of bin_segments (at most
+// SEG_MAX_WGS) leaves
+//   pair_off[s][w]  start of its run of pairs for segment s (row nseg: end of its region), and
+//   inst_pre[s][w]  its instances in the segments 0..s (a running sum): the column sums are the list starts.
+#define SEG_TILES_MAX 16
+#define SEG_TILES_MIN 4
+#define SEG_MAX_WGS 256
+#define SEG_K1_LDS_MAX (128 * 1024)  // bin_segments holds 16 bytes per segment in LDS
+struct SegmentTables {
+    uint32_t* pair_off;  // [(nseg + 1) * SEG_MAX_WGS]
+    uint32_t* inst_pre;  // [nseg * SEG_MAX_WGS]
     size_t bytes;
 };
-__host__ __device__ inline CountTable carve_count_table(char* base, int W, int H) {
-    CountTable t;
-    const size_t tiles = (size_t)((W + DGR_BLOCK_X - 1) / DGR_BLOCK_X) * ((H + DGR_BLOCK_Y - 1) / DGR_BLOCK_Y);
+__host__ __device__ inline SegmentTables carve_segment_tables(char* base, int W, int H) {
+    SegmentTables t;
+    const size_t gx = (size_t)((W + DGR_BLOCK_X - 1) / DGR_BLOCK_X), gy = (size_t)((H + DGR_BLOCK_Y - 1) / DGR_BLOCK_Y);
+    const size_t nseg = gy * ((gx + SEG_TILES_MIN - 1) / SEG_TILES_MIN);
     size_t o = 0;
-    if (tiles == 0 || tiles > DGR_COUNT_LDS_MAX_TILES) { t.table = nullptr; t.seg = nullptr; t.bytes = 0; return t; }
-    t.table = (uint32_t*)(base + o); o = align_up(o + 4 * tiles * DGR_COUNT_WGS, 256);
-    t.seg = (uint32_t*)(base + o);   o = align_up(o + 4 * ((tiles + 63) / 64) * DGR_COUNT_WGS, 256);
+    if (gx == 0 || gy == 0 || nseg * 16 > SEG_K1_LDS_MAX) { t.pair_off = nullptr; t.inst_pre = nullptr; t.bytes = 0; return t; }
+    t.pair_off = (uint32_t*)(base + o); o = align_up(o + 4 * (nseg + 1) * SEG_MAX_WGS, 256);
+    t.inst_pre = (uint32_t*)(base + o); o = align_up(o + 4 * nseg * SEG_MAX_WGS, 256);
     t.bytes = o;
     return t;
 }

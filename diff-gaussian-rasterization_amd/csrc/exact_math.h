@@ -42,7 +42,8 @@ __device__ __forceinline__ void exp_ref_table_fill(uint64_t* lds_tab, int tid) {
 // Same table, same cubic, all in double; the cubic is evaluated by Horner's rule (one operation fewer than glibc's
 // (C0 r + C1) r^2 + (C2 r + 1)), which moves y by ~1e-16 relative, so the float result can differ from the host's only
 // when y lies that close to a rounding boundary of the float grid: about one argument in 2^28.
-// 13 vector instructions (9 of them in the double pipe) and one 8-byte LDS read.
+// 13 vector instructions (10 of them in the double pipe) and one 8-byte LDS read; 52 cycles of issue per wave at 8 waves per
+// SIMD against 14 for v_mul_f32 + v_exp_f32 (profiles/r5/exp_variants.txt).
 __device__ __forceinline__ float exp_ref(float x, const uint64_t* tab) {
 #pragma clang fp contract(off)  // z + SHIFT must round z first; the fused steps below are explicit
     constexpr double INVLN2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
@@ -53,9 +54,15 @@ __device__ __forceinline__ float exp_ref(float x, const uint64_t* tab) {
     const double r = z - (kd0 - SHIFT);                 // in [-1/2, 1/2]
     const uint2 t = reinterpret_cast<const uint2*>(tab)[ki & 31u];
     const double s = __hiloint2double((int)(t.y + (ki << 15)), (int)t.x);  // bits of 2^(i/32) + (k << 47): 2^(k/32)
-    double p = __builtin_fma(C0, r, C1);
-    p = __builtin_fma(p, r, C2);
-    const double y = __builtin_fma(p, r, 1.0);
+    // (written out: a VOP3 instruction takes ONE scalar operand, so the Horner steps are ordered such that each needs one
+    //  constant from an SGPR pair and only C1 sits in a VGPR pair; the compiler's choice was v_fmac_f64 with both C1 and C2
+    //  copied into fresh VGPR pairs per evaluation -- two moves and two registers more inside 64-register kernels)
+    double p, y;
+    asm("v_fma_f64 %0, %2, %3, %4\n\t"
+        "v_fma_f64 %0, %0, %2, %5\n\t"
+        "v_fma_f64 %1, %0, %2, 1.0"
+        : "=&v"(p), "=v"(y)
+        : "v"(r), "s"(C0), "v"(C1), "s"(C2));
     return (float)(y * s);
 }
 

@@ -37,6 +37,16 @@ inline void launch_shmem(K kernel, dim3 grid, dim3 block, size_t shmem, hipStrea
     }
 }
 
+// Blend kernels, when several views are in flight: they run at 8 workgroups per CU, i.e. they hold every wave slot, the
+// whole register file and 144 of the 160 KB of LDS, so another stream's kernels enter a CU only as blend workgroups drain.
+// dgr_set_option("blend_wgs_per_cu", n) (3 <= n <= 7; 0 = no cap) pads each blend workgroup with unused dynamic LDS so
+// that at most n fit a CU, which leaves wave slots, registers and LDS for the other views' bandwidth- and latency-bound
+// kernels.  blend_pad_bytes() (api.hip) caches the kernels' static LDS sizes.
+size_t blend_pad_bytes(const void* kernel);
+template <typename K, typename... Args>
+inline void launch_blend(K kernel, dim3 grid, dim3 block, hipStream_t stream, Args... args) {
+    launch_shmem(kernel, grid, block, blend_pad_bytes(reinterpret_cast<const void*>(kernel)), stream, args...);
+}
 
 struct PreprocessFwdArgs {
     int P, D, M, W, H, grid_x, grid_y;
@@ -248,17 +258,17 @@ hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity,
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,
                              hipStream_t stream);
 hipError_t launch_scan_blocks(int P, GeometryView geom, ImageView img, hipStream_t stream);
-hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream,
-                                 const uint32_t* table = nullptr, int tiles = 0, int nwg = 1);
-// counting in LDS (binning.hip): presized path, frames of at most DGR_COUNT_LDS_MAX_TILES tiles
-bool count_lds_fits(int tiles);
-int count_lds_workgroups(int P);
+hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, hipStream_t stream);
+// two-level binning (segment_binning.hip): presized and callback paths, frames whose segment tables fit LDS.
 // `prefixed`: geom.block_tiles is already the exclusive prefix of the block totals and the status word is initialised
 // (callback path, after scan_blocks)
-hipError_t launch_count_lds(int P, GeometryView geom, BinningView bin, CountTable ct, int grid_x, int tiles, int capacity,
-                            bool prefixed, hipStream_t stream);
-hipError_t launch_scan_table(int P, GeometryView geom, ImageView img, CountTable ct, int tiles, int capacity, bool prefixed,
-                             hipStream_t stream);
+bool segment_binning_fits(int W, int H);
+int segment_binning_workgroups(int P);
+int segment_shift(int W, int H, int capacity);  // log2 of the tiles per segment (4, 3 or 2) for this frame and capacity
+hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, SegmentTables tb, int grid_x, int grid_y, int seg_shift,
+                               int capacity, bool prefixed, hipStream_t stream);
+hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
+                            int seg_shift, int capacity, bool prefixed, hipStream_t stream);
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);
 
 // alpha_mode: render_common.h (0 = ALPHA_REF, the reference's bits; 1 = ALPHA_FAST)

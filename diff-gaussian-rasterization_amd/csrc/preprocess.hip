@@ -320,19 +320,13 @@ __device__ __forceinline__ FwdGeom fwd_view_geometry(const PreprocessFwdArgs& a,
         if (C3_GIVEN) {
 #pragma unroll
             for (int i = 0; i < 6; i++) c3[i] = c3_in[i];
-            if (!a.cov3D_precomp) {
-                reinterpret_cast<float4*>(a.geom.cov3D)[idx] = make_float4(c3[0], c3[1], c3[2], c3[3]);
-                reinterpret_cast<float2*>(a.geom.cov3D + 4 * (size_t)a.P)[idx] = make_float2(c3[4], c3[5]);
-            }
         } else if (a.cov3D_precomp) {
 #pragma unroll
             for (int i = 0; i < 6; i++) c3[i] = a.cov3D_precomp[6 * (size_t)idx + i];
         } else {
+            // (not kept for the backward: it reads scale and rotation anyway and re-forms the covariance with the same
+            //  expression, hence the same bits -- 24 bytes less written here and read there per Gaussian)
             compute_cov3d(a.scales, a.rotations, a.scale_modifier, idx, c3);
-            // two planes, {c0..c3} as float4 and {c4, c5} as float2: consecutive lanes store consecutive pieces (six 4-byte
-            // stores at a 24-byte lane stride touch 24 cache lines per wave instruction)
-            reinterpret_cast<float4*>(a.geom.cov3D)[idx] = make_float4(c3[0], c3[1], c3[2], c3[3]);
-            reinterpret_cast<float2*>(a.geom.cov3D + 4 * (size_t)a.P)[idx] = make_float2(c3[4], c3[5]);
         }
         Cov2D c;
         cov2d_common(p_orig, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.view, c);
@@ -925,10 +919,8 @@ __global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArg
                 const float* c3p = a.cov3D_precomp + 6 * (size_t)idx;
 #pragma unroll
                 for (int i = 0; i < 6; i++) c3[i] = c3p[i];
-            } else {  // the forward's two planes
-                const float4 ca = reinterpret_cast<const float4*>(a.geom.cov3D)[idx];
-                const float2 cb = reinterpret_cast<const float2*>(a.geom.cov3D + 4 * (size_t)a.P)[idx];
-                c3[0] = ca.x; c3[1] = ca.y; c3[2] = ca.z; c3[3] = ca.w; c3[4] = cb.x; c3[5] = cb.y;
+            } else {  // re-formed from scale and rotation: the forward's expression, the forward's bits
+                compute_cov3d(a.scales, a.rotations, a.scale_modifier, idx, c3);
             }
         }
         float3 sc_in = make_float3(0.f, 0.f, 0.f);

@@ -23,7 +23,11 @@ constexpr float ALPHA_MIN = 15.0f / 255.0f;  // forward.cu:365
 //       division, so agreement with the CPU restatement to 1e-5 needs the same BITS, not merely the same accuracy.
 //   ALPHA_FAST (dgr_set_option("fast_alpha", 1)): the conic pre-scaled by log2(e), power from two fused multiply-adds,
 //       one v_exp_f32, v_rcp_f32 -- every operation accurate to an ulp, gradients up to 6e-5 abs away at config 3.
-enum { ALPHA_REF = 0, ALPHA_FAST = 1, ALPHA_HILO = 2, ALPHA_OCML = 3 };
+// Measured at config 3 (profiles/r5/alpha_modes_summary.txt; end-to-end max |dL_dview - oracle|, forward / backward blend
+// kernel): REF 1.8e-7, 128 / 240 us; FAST 5.8e-5, 98-103 / 193-204 us; the reference association with a hi/lo-corrected
+// v_exp_f32 1.4e-5, 107 / 219 us; with ocml's expf and the compiler's IEEE division (round 2's "exact" build) 6.6e-6,
+// 115 / 271 us.  Only the path that reproduces the host's bits brings the alpha image itself to the restatement's.
+enum { ALPHA_REF = 0, ALPHA_FAST = 1 };
 template <int AM>
 struct AlphaPath {
     static constexpr bool LOG2 = (AM == ALPHA_FAST);               // staged conic scaled by log2(e): p2 = log2(e) power
@@ -35,21 +39,12 @@ struct AlphaPath {
 template <int AM>
 __device__ __forceinline__ float alpha_raw(float o, float p2, const uint64_t* tab) {
     if (AM == ALPHA_FAST) return o * __builtin_amdgcn_exp2f(p2);
-    if (AM == ALPHA_HILO) {
-        const float ph = p2 * LOG2E;
-        float c = __builtin_fmaf(-ph, 0.693147182464599609375f, p2);
-        c = __builtin_fmaf(-ph, -1.90465429995776804525e-09f, c);
-        const float r = __builtin_amdgcn_exp2f(ph);
-        return o * __builtin_fmaf(r, c, r);
-    }
-    if (AM == ALPHA_OCML) return o * expf(p2);
     return o * exp_ref(p2, tab);
 }
 // T / om for the backward's transmittance; `inv` ~ 1 / om for the terms that are not amplified
 template <int AM>
 __device__ __forceinline__ float t_div(float T, float om, float& inv) {
     if (AM == ALPHA_FAST) { inv = __builtin_amdgcn_rcpf(om); return T * inv; }
-    if (AM == ALPHA_OCML) { inv = 1.0f / om; return T / om; }
     return div_ref(T, om, inv);
 }
 

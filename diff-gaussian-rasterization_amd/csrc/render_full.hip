@@ -299,12 +299,8 @@ hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hi
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
     switch (alpha_mode) {
-        case ALPHA_FAST: launch(render_fwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
-#ifdef DGR_ALPHA_EXPERIMENT
-        case ALPHA_HILO: launch(render_fwd_full_kernel<ALPHA_HILO>, dim3(tiles), dim3(256), stream, a); break;
-        case ALPHA_OCML: launch(render_fwd_full_kernel<ALPHA_OCML>, dim3(tiles), dim3(256), stream, a); break;
-#endif
-        default: launch(render_fwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
+        case ALPHA_FAST: launch_blend(render_fwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+        default: launch_blend(render_fwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
     }
     return hipGetLastError();
 }
@@ -312,12 +308,8 @@ hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hi
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
     switch (alpha_mode) {
-        case ALPHA_FAST: launch(render_bwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
-#ifdef DGR_ALPHA_EXPERIMENT
-        case ALPHA_HILO: launch(render_bwd_full_kernel<ALPHA_HILO>, dim3(tiles), dim3(256), stream, a); break;
-        case ALPHA_OCML: launch(render_bwd_full_kernel<ALPHA_OCML>, dim3(tiles), dim3(256), stream, a); break;
-#endif
-        default: launch(render_bwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
+        case ALPHA_FAST: launch_blend(render_bwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+        default: launch_blend(render_bwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
     }
     return hipGetLastError();
 }

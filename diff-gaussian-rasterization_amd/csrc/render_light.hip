@@ -385,11 +385,11 @@ __global__ void __launch_bounds__(256) exact_math_test_kernel(int n, const float
 template <int AM>
 void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t stream) {
     if (!a.map_off && !a.track_off)
-        launch((render_bwd_light_kernel<AM, true, true>), dim3(tiles), dim3(256), stream, a);
+        launch_blend((render_bwd_light_kernel<AM, true, true>), dim3(tiles), dim3(256), stream, a);
     else if (!a.map_off)
-        launch((render_bwd_light_kernel<AM, true, false>), dim3(tiles), dim3(256), stream, a);
+        launch_blend((render_bwd_light_kernel<AM, true, false>), dim3(tiles), dim3(256), stream, a);
     else
-        launch((render_bwd_light_kernel<AM, false, true>), dim3(tiles), dim3(256), stream, a);
+        launch_blend((render_bwd_light_kernel<AM, false, true>), dim3(tiles), dim3(256), stream, a);
 }
 }  // namespace
 
@@ -397,12 +397,8 @@ hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, 
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
     switch (alpha_mode) {
-        case ALPHA_FAST: launch(render_fwd_light_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
-#ifdef DGR_ALPHA_EXPERIMENT
-        case ALPHA_HILO: launch(render_fwd_light_kernel<ALPHA_HILO>, dim3(tiles), dim3(256), stream, a); break;
-        case ALPHA_OCML: launch(render_fwd_light_kernel<ALPHA_OCML>, dim3(tiles), dim3(256), stream, a); break;
-#endif
-        default: launch(render_fwd_light_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
+        case ALPHA_FAST: launch_blend(render_fwd_light_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+        default: launch_blend(render_fwd_light_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
     }
     return hipGetLastError();
 }
@@ -411,10 +407,6 @@ hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, int alpha_mode, 
     if (tiles <= 0 || (a.track_off && a.map_off)) return hipSuccess;
     switch (alpha_mode) {
         case ALPHA_FAST: launch_bwd_light_mode<ALPHA_FAST>(a, tiles, stream); break;
-#ifdef DGR_ALPHA_EXPERIMENT
-        case ALPHA_HILO: launch_bwd_light_mode<ALPHA_HILO>(a, tiles, stream); break;
-        case ALPHA_OCML: launch_bwd_light_mode<ALPHA_OCML>(a, tiles, stream); break;
-#endif
         default: launch_bwd_light_mode<ALPHA_REF>(a, tiles, stream);
     }
     return hipGetLastError();

@@ -1,0 +1,442 @@
+// segment_binning.hip -- two-level instance binning for gfx950 (presized path and callback path; frames whose segment
+// tables fit LDS).
+//
+// Replaces cub::DeviceScan::InclusiveSum over P, duplicateWithKeys, cub::DeviceRadixSort::SortPairs on 64-bit
+// (tile | depth) keys and identifyTileRanges (L/cuda_rasterizer/rasterizer_impl.cu:70-138, 283-323) with TWO kernels and
+// no global atomics.  The reference's result -- point_list ascending on (tile id, depth bits, gaussian id), ranges per tile --
+// is reproduced bit for bit: keys are unique, so any placement followed by a sort of each tile's list yields it.
+//
+// Round 2-4 placed every tile INSTANCE individually: a table of per-(counting workgroup, tile) slot bases (8 MB at 1080p),
+// one 8-byte key scattered per instance (each reaching memory as its own 32-byte write: 4.6x write amplification), a
+// per-tile sort reading the keys back -- count_lds + scan_table + emit + sort_tiles = 66 us at config 3.  Here a
+// Gaussian is first binned by ROW SEGMENT, and instances exist only inside LDS:
+//
+//   * a tile row is cut into segments of 16 tiles (8 or 4 where the lists are long: segment_shift());
+//   * bin_segments (K1): workgroup w takes a contiguous range of Gaussians.  A Gaussian whose tile rectangle covers rows
+//     y0..y1 and columns x0..x1 becomes one PAIR per (row, segment) it touches: {key = depth bits << 32 | id, the column
+//     range inside the segment as one byte} -- 9 bytes for on average ~1.6 instances.  Two passes over the workgroup's
+//     rectangles (they stay in L2): count per segment in LDS, scan, then place every pair with a returning LDS atomic
+//     into the workgroup's OWN region of the pair array, ordered by segment.  The region starts at the instance prefix
+//     of the workgroup's first Gaussian (from preprocess_fwd's per-block totals; pairs <= instances, so regions never
+//     overlap): no global cursor, nothing to clear.  All writes of a region come from one workgroup within microseconds,
+//     so its lines leave the L2 complete.  Also per workgroup: the start of each segment's run (pair_off[segment][w]) and
+//     the running instance count per segment (inst_pre[segment][w]);
+//   * bin_tiles (K2): one 512-thread workgroup per segment.  Its list start is the sum over w of inst_pre[s - 1][w] (the
+//     range table needs no device-wide scan).  The segment's pairs -- one short run per K1 workgroup -- are fetched with
+//     ALL loads in flight at once (a flat pair index -> source address map is built in LDS first; walking the runs one
+//     after the other cost sixteen dependent memory round trips per wave and 56 us), held in registers, counted per tile
+//     and placed INTO LDS with LDS atomics; the 16 ranges are written, and every wave sorts whole tile lists in its
+//     registers (tile_sort.h: no barrier, no LDS traffic beyond one read) and writes the sorted ids: point_list is written
+//     once, coalesced, and keys never exist in global memory.
+//     Tile lists above 1024 entries, segments above the LDS budget or with more pairs than the registers hold take a
+//     per-tile path (whole workgroup: LDS sort up to 4096 keys, in-place global sort above, in the `keys` scratch array).
+//
+// HBM traffic per view at config 3: 9 B x 1.0 M pairs written and read once, 4 B x R written -- against 4 + 8 + 4 B written,
+// 8 + 4 + 8 + 4 B read per instance plus the 8 MB table three times before.
+#include "dgr_common.h"
+#include "kernels.h"
+#include "tile_sort.h"
+#include <mutex>
+
+namespace dgr {
+namespace {
+
+constexpr int K1_THREADS = 1024;
+constexpr int K2_THREADS = 512;
+constexpr int K2_WAVES = K2_THREADS / 64;
+constexpr int SEG_MAX = SEG_TILES_MAX;      // tiles per segment: 16, 8 or 4 (chosen per call from the expected list lengths)
+constexpr int K2_PPT = 12;                   // pairs a bin_tiles thread holds in registers: 6144 per segment (= K2_CAP; 16 spill)
+constexpr int K2_CAP = 6144;        // keys of one segment held in LDS (48 KB: three workgroups per CU)
+constexpr int K2_LDS_SORT_MAX = 4096;  // per-tile path: workgroup sort in LDS up to here (np2 <= K2_CAP), global above
+constexpr int REG_SORT_MAX = 1024;  // a wave sorts a tile list in registers up to here (16 chunks of 64)
+
+// exclusive (inclusive) scan of a[0..n) in place by the whole workgroup; returns the total.  NT threads, all call it.
+template <int NT>
+__device__ __forceinline__ uint32_t block_scan(uint32_t* a, int n, bool inclusive, uint32_t* wsum, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per = (n + NT - 1) / NT;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    uint32_t s = 0;
+    for (int i = lo; i < hi; i++) s += a[i];
+    uint32_t incl = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    __syncthreads();  // (wsum may still be read from a previous call)
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+#pragma unroll
+    for (int ww = 0; ww < NT / 64; ww++) {
+        const uint32_t v = wsum[ww];
+        if (ww < wave) before += v;
+        total += v;
+    }
+    uint32_t run = before + incl - s;
+    for (int i = lo; i < hi; i++) {
+        const uint32_t c = a[i];
+        a[i] = inclusive ? run + c : run;
+        run += c;
+    }
+    __syncthreads();
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------------ K1
+// Every thread handles its Gaussians four at a time with the four loads issued together (the kernel is a latency
+// skeleton: one memory round trip per group instead of one per Gaussian); a range of at most 4096 Gaussians keeps its
+// rectangles and depths in registers between the two passes, longer ranges re-read them (from L2) in pass B.
+__global__ void __launch_bounds__(K1_THREADS) bin_segments_kernel(int P, int per_wg, GeometryView geom, SegmentTables tb,
+                                                                  uint64_t* __restrict__ pair_keys, uint8_t* __restrict__ pair_cov,
+                                                                  int grid_x, int grid_y, int seg_shift, int capacity, int prefixed) {
+    // both[nseg]: pairs (low word) and instances (high word) per segment, one 64-bit LDS atomic per pair | cnt[nseg]
+    // (pairs; then the start of each segment's run, then the fill cursors) | inst[nseg]
+    extern __shared__ unsigned long long lds64[];
+    __shared__ uint32_t wsum[K1_THREADS / 64];
+    __shared__ uint32_t s_base;
+    const int SEG = 1 << seg_shift;
+    const int sgx = (grid_x + SEG - 1) >> seg_shift;
+    const int nseg = grid_y * sgx;
+    unsigned long long* both = lds64;
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(lds64 + nseg);
+    uint32_t* inst = cnt + nseg;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    const int g0 = wg * per_wg, g1 = min(P, g0 + per_wg);
+    constexpr int NH = 4;
+    const bool hold = per_wg <= NH * K1_THREADS;
+    ushort4 hr[NH];
+    float hd[NH];
+    auto load_group = [&](int first, bool with_depth) {
+#pragma unroll
+        for (int k = 0; k < NH; k++) {
+            const int idx = first + tid + k * K1_THREADS;
+            hr[k] = make_ushort4(0, 0, 0, 0);
+            hd[k] = 0.f;
+            if (idx < g1) {
+                hr[k] = geom.rect[idx];
+                if (with_depth) hd[k] = geom.depths[idx];
+            }
+        }
+    };
+    if (hold) load_group(g0, true);
+    for (int i = tid; i < nseg; i += K1_THREADS) both[i] = 0ull;
+    // instances of all Gaussians in front of this workgroup's range = where its region of the pair array starts
+    uint32_t part = 0;
+    if (prefixed) {
+        if (tid == 0) part = geom.block_tiles[g0 >> 8];  // (callback path: scan_blocks left the exclusive prefix)
+    } else {
+        for (int b = tid; b < (g0 >> 8); b += K1_THREADS) part += geom.block_tiles[b] & 0x7fffffffu;
+    }
+    __syncthreads();
+    // ---- pass A: pairs and instances per segment
+    auto count = [&](ushort4 r) {
+        if (r.z <= r.x || r.w <= r.y) return;
+        const int sx0 = r.x >> seg_shift, sx1 = (r.z - 1) >> seg_shift;
+        for (int y = r.y; y < r.w; y++)
+            for (int sx = sx0; sx <= sx1; sx++)
+                atomicAdd(&both[y * sgx + sx],
+                          1ull | ((unsigned long long)(min((int)r.z, sx * SEG + SEG) - max((int)r.x, sx * SEG)) << 32));
+    };
+    for (int first = g0; first < g1; first += NH * K1_THREADS) {
+        if (!hold) load_group(first, false);
+#pragma unroll
+        for (int k = 0; k < NH; k++) count(hr[k]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+    if (tid == 0) s_base = 0u;
+    __syncthreads();
+    if (lane == 0 && part) atomicAdd(&s_base, part);
+    for (int i = tid; i < nseg; i += K1_THREADS) {
+        const unsigned long long v = both[i];
+        cnt[i] = (uint32_t)v;
+        inst[i] = (uint32_t)(v >> 32);
+    }
+    __syncthreads();
+    const uint32_t base = s_base;
+    const uint32_t total_pairs = block_scan<K1_THREADS>(cnt, nseg, false, wsum, tid);
+    block_scan<K1_THREADS>(inst, nseg, true, wsum, tid);
+    // tables, transposed so that bin_tiles reads rows of nwg consecutive words
+    for (int s = tid; s < nseg; s += K1_THREADS) {
+        tb.pair_off[(size_t)s * nwg + wg] = base + cnt[s];
+        tb.inst_pre[(size_t)s * nwg + wg] = inst[s];
+    }
+    if (tid == 0) tb.pair_off[(size_t)nseg * nwg + wg] = base + total_pairs;
+    __syncthreads();
+    // ---- pass B: place the pairs; cnt[] now serves as the fill cursors
+    auto place = [&](ushort4 r, float depth, int idx) {
+        if (r.z <= r.x || r.w <= r.y) return;
+        const uint64_t key = ((uint64_t)__float_as_uint(depth) << 32) | (uint32_t)idx;
+        const int sx0 = r.x >> seg_shift, sx1 = (r.z - 1) >> seg_shift;
+        for (int y = r.y; y < r.w; y++)
+            for (int sx = sx0; sx <= sx1; sx++) {
+                const uint32_t slot = base + atomicAdd(&cnt[y * sgx + sx], 1u);
+                const int x0 = max((int)r.x, sx * SEG) - sx * SEG, x1 = min((int)r.z, sx * SEG + SEG) - sx * SEG;  // 0 <= x0 < x1 <= 16
+                if (slot < (uint32_t)capacity) {  // (past the capacity bin_tiles flags the overflow and reads nothing)
+                    pair_keys[slot] = key;
+                    pair_cov[slot] = (uint8_t)(x0 | ((x1 - 1) << 4));
+                }
+            }
+    };
+    for (int first = g0; first < g1; first += NH * K1_THREADS) {
+        if (!hold) load_group(first, true);
+#pragma unroll
+        for (int k = 0; k < NH; k++) place(hr[k], hd[k], first + tid + k * K1_THREADS);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K2
+struct K2Shared {
+    union {
+        uint64_t keys[K2_CAP];           // the segment's keys, grouped by tile
+        uint32_t src[K2_PPT * K2_THREADS];  // before that: flat pair index -> index into the pair array
+    };
+    uint32_t run_a[SEG_MAX_WGS], run_start[SEG_MAX_WGS + 1];
+    uint32_t tcnt[SEG_MAX], tbase[SEG_MAX], tfill[SEG_MAX];
+    uint32_t red[4][K2_WAVES];
+    uint32_t wsum[K2_WAVES];
+    uint32_t counter;
+};
+
+// every pair of the segment's runs: f(index into the pair array).  One wave per run, four runs in flight (the per-tile
+// path; the fast path fetches through the flat map instead).
+template <typename F>
+__device__ __forceinline__ void for_each_pair(const K2Shared& sh, int nwg, int wave, int lane, F f) {
+    for (int r = wave; r < nwg; r += K2_WAVES) {
+        const uint32_t a = sh.run_a[r], len = sh.run_start[r + 1] - sh.run_start[r];
+        for (uint32_t j = lane; j < len; j += 64) f(a + j);
+    }
+}
+
+__device__ __forceinline__ void sort_tile_in_wave(const uint64_t* src, int n, uint32_t* dst, int lane) {
+    if (n <= 64) sort_wave_regs<1>(src, n, dst, lane);
+    else if (n <= 128) sort_wave_regs<2>(src, n, dst, lane);
+    else if (n <= 256) sort_wave_regs<4>(src, n, dst, lane);
+    else if (n <= 512) sort_wave_regs<8>(src, n, dst, lane);
+    else sort_wave_regs<16>(src, n, dst, lane);
+}
+
+// bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of segments
+__device__ __forceinline__ int xcd_contiguous(int b, int n) {
+    const int xcd = b & 7, local = b >> 3;
+    const int q = n >> 3, r = n & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+__global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img, uint32_t* __restrict__ point_list,
+                                                                  uint64_t* __restrict__ key_scratch, SegmentTables tb,
+                                                                  const uint64_t* __restrict__ pair_keys,
+                                                                  const uint8_t* __restrict__ pair_cov,
+                                                                  const uint32_t* __restrict__ block_tiles, int nblocks, int nwg,
+                                                                  int grid_x, int grid_y, int seg_shift, int capacity, int prefixed) {
+    __shared__ K2Shared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int SEG = 1 << seg_shift;
+    const int sgx = (grid_x + SEG - 1) >> seg_shift;
+    const int nseg = grid_y * sgx;
+    const int s = xcd_contiguous(blockIdx.x, nseg);
+    const int ty = s / sgx, sx = s - ty * sgx;
+    const int ntl = min(SEG, grid_x - sx * SEG);             // tiles of this segment (the last one of a row may be short)
+    const int tile0 = ty * grid_x + sx * SEG;
+
+    // ---- list start, size of the segment, grand total: column sums of the per-workgroup running counts; the runs
+    uint32_t before = 0, upto = 0, total = 0, flag = 0;
+    for (int w = tid; w < nwg; w += K2_THREADS) {
+        if (s > 0) before += tb.inst_pre[(size_t)(s - 1) * nwg + w];
+        upto += tb.inst_pre[(size_t)s * nwg + w];
+        total += tb.inst_pre[(size_t)(nseg - 1) * nwg + w];
+        const uint32_t a = tb.pair_off[(size_t)s * nwg + w];
+        sh.run_a[w] = a;
+        sh.run_start[w] = tb.pair_off[(size_t)(s + 1) * nwg + w] - a;  // (length; scanned below)
+    }
+    if (s == 0 && !prefixed)  // the `prefiltered` violation flag of preprocess_fwd's blocks (callback path: scan_blocks took it)
+        for (int i = tid; i < nblocks; i += K2_THREADS) flag |= block_tiles[i] >> 31;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        before += __shfl_xor(before, off, 64);
+        upto += __shfl_xor(upto, off, 64);
+        total += __shfl_xor(total, off, 64);
+        flag |= __shfl_xor(flag, off, 64);
+    }
+    if (lane == 0) { sh.red[0][wave] = before; sh.red[1][wave] = upto; sh.red[2][wave] = total; sh.red[3][wave] = flag; }
+    if (tid < SEG_MAX) { sh.tcnt[tid] = 0u; sh.tfill[tid] = 0u; }
+    if (tid == 0) sh.run_start[nwg] = 0u;
+    __syncthreads();
+    before = 0; upto = 0; total = 0; flag = 0;
+#pragma unroll
+    for (int ww = 0; ww < K2_WAVES; ww++) { before += sh.red[0][ww]; upto += sh.red[1][ww]; total += sh.red[2][ww]; flag |= sh.red[3][ww]; }
+    const bool overflow = total > (uint32_t)capacity;
+    const uint32_t gcount = upto - before;
+    if (s == 0 && tid == 0) {
+        img.status[0] = (int)total;
+        img.status[1] = overflow ? 1 : 0;
+        if (!prefixed) {
+            img.status[2] = (int)flag;  // prefiltered violation
+            img.status[3] = 0;          // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
+        }
+        img.cursor[2] = (uint32_t)capacity;
+    }
+    if (overflow || gcount == 0u) {  // (empty tiles keep {0, 0}: the reference clears the table and writes only tiles that own instances)
+        if (tid < ntl) img.ranges[tile0 + tid] = make_uint2(0u, 0u);
+        return;
+    }
+    const uint32_t n_pairs = block_scan<K2_THREADS>(sh.run_start, nwg + 1, false, sh.wsum, tid);  // run_start[w] = pairs of the runs < w
+    const bool in_regs = n_pairs <= (uint32_t)(K2_PPT * K2_THREADS);
+
+    // ---- the segment's pairs into registers: flat index -> source map in LDS (one thread per run), then every load at once
+    uint64_t pk[K2_PPT];
+    uint32_t pc[K2_PPT];
+    if (in_regs) {
+        for (int w = tid; w < nwg; w += K2_THREADS) {
+            const uint32_t a = sh.run_a[w], b0 = sh.run_start[w], len = sh.run_start[w + 1] - b0;
+            for (uint32_t j = 0; j < len; j++) sh.src[b0 + j] = a + j;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K2_PPT; k++) {
+            const uint32_t i = (uint32_t)(tid + k * K2_THREADS);
+            pc[k] = 0xffffffffu;
+            pk[k] = 0ull;
+            if (i < n_pairs) {
+                const uint32_t a = sh.src[i];
+                pc[k] = pair_cov[a];
+                pk[k] = pair_keys[a];
+            }
+        }
+        // ---- pass A: instances per tile
+#pragma unroll
+        for (int k = 0; k < K2_PPT; k++)
+            if (pc[k] != 0xffffffffu)
+                for (uint32_t x = pc[k] & 15u; x <= (pc[k] >> 4); x++) atomicAdd(&sh.tcnt[x], 1u);
+    } else {
+        for_each_pair(sh, nwg, wave, lane, [&](uint32_t a) {
+            const uint32_t c = pair_cov[a];
+            for (uint32_t x = c & 15u; x <= (c >> 4); x++) atomicAdd(&sh.tcnt[x], 1u);
+        });
+    }
+    __syncthreads();  // (also: every thread is done with sh.src, which shares its bytes with sh.keys)
+    if (wave == 0) {
+        const uint32_t c = (lane < SEG_MAX) ? sh.tcnt[lane] : 0u;
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < SEG_MAX; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane < SEG_MAX) sh.tbase[lane] = incl - c;
+        if (lane < ntl) img.ranges[tile0 + lane] = c ? make_uint2(before + incl - c, before + incl) : make_uint2(0u, 0u);
+    }
+    __syncthreads();
+    uint32_t tmax = 0;
+#pragma unroll
+    for (int t = 0; t < SEG_MAX; t++) tmax = max(tmax, sh.tcnt[t]);
+
+    if (in_regs && gcount <= (uint32_t)K2_CAP && tmax <= (uint32_t)REG_SORT_MAX) {
+        // ---- pass B: the segment's keys into LDS, grouped by tile
+#pragma unroll
+        for (int k = 0; k < K2_PPT; k++)
+            if (pc[k] != 0xffffffffu)
+                for (uint32_t x = pc[k] & 15u; x <= (pc[k] >> 4); x++) sh.keys[sh.tbase[x] + atomicAdd(&sh.tfill[x], 1u)] = pk[k];
+        __syncthreads();
+        // ---- every wave sorts whole tile lists in its registers and writes the ids
+        for (int t = wave; t < ntl; t += K2_WAVES) {
+            const int n = (int)sh.tcnt[t];
+            if (n > 0) sort_tile_in_wave(sh.keys + sh.tbase[t], n, point_list + before + sh.tbase[t], lane);
+        }
+        return;
+    }
+    // ---- per-tile path (a list above REG_SORT_MAX entries, more keys in the segment than LDS holds, or more pairs than the
+    // registers hold): one tile at a time, the pairs re-read from the pair array
+    for (int t = 0; t < ntl; t++) {
+        const int n = (int)sh.tcnt[t];
+        if (n == 0) continue;
+        uint64_t* gk = key_scratch + before + sh.tbase[t];
+        uint32_t* pl = point_list + before + sh.tbase[t];
+        const bool in_lds = n <= K2_LDS_SORT_MAX;
+        if (tid == 0) sh.counter = 0u;
+        __syncthreads();
+        for_each_pair(sh, nwg, wave, lane, [&](uint32_t a) {
+            const uint32_t c = pair_cov[a];
+            if ((c & 15u) <= (uint32_t)t && (uint32_t)t <= (c >> 4)) {
+                const uint32_t pos = atomicAdd(&sh.counter, 1u);
+                const uint64_t key = pair_keys[a];
+                if (in_lds) sh.keys[pos] = key; else gk[pos] = key;
+            }
+        });
+        __syncthreads();
+        if (in_lds) {
+            wg_sort_lds<K2_THREADS>(sh.keys, n, tid);
+            for (int i = tid; i < n; i += K2_THREADS) pl[i] = (uint32_t)sh.keys[i];
+        } else {
+            wg_sort_global<K2_THREADS>(gk, n, tid);
+            for (int i = tid; i < n; i += K2_THREADS) pl[i] = (uint32_t)gk[i];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// the segment tables must fit one workgroup's LDS in bin_segments (16 bytes per segment, at the smallest segment size)
+bool segment_binning_fits(int W, int H) {
+    const int gx = tiles_x(W), gy = tiles_y(H);
+    if (gx <= 0 || gy <= 0) return false;
+    const size_t nseg = (size_t)gy * ((gx + SEG_TILES_MIN - 1) / SEG_TILES_MIN);
+    return nseg * 16 <= SEG_K1_LDS_MAX;
+}
+// Tiles per segment, as a shift: the largest of 16, 8, 4 for which an average segment stays inside bin_tiles' LDS budget.
+// `capacity` is what the caller expects to render (the lazy bindings size it 1.5x above the largest count seen, the
+// callback path passes the exact count): segments are sized so that capacity / tiles * segment <= 1.5 K2_CAP, i.e. an
+// average segment fills at most two thirds (lazy) or all (exact) of the budget; denser segments take the per-tile path.
+int segment_shift(int W, int H, int capacity) {
+    const long tiles = (long)tiles_x(W) * tiles_y(H);
+    const long per_tile = tiles > 0 ? ((long)(capacity > 0 ? capacity : 0) + tiles - 1) / tiles : 0;
+    for (int sh = 4; sh > 2; sh--)
+        if ((per_tile << sh) * 2 <= (long)K2_CAP * 3) return sh;
+    return 2;
+}
+// Gaussians per bin_segments workgroup (a multiple of 1024, so that workgroup ranges start at a 256-block boundary) and the
+// number of workgroups: at most SEG_MAX_WGS
+int segment_binning_per_wg(int P) {
+    const int chunks = (P + K1_THREADS - 1) / K1_THREADS;
+    const int rounds = (chunks + SEG_MAX_WGS - 1) / SEG_MAX_WGS;
+    return max(1, rounds) * K1_THREADS;
+}
+int segment_binning_workgroups(int P) { return max(1, (P + segment_binning_per_wg(P) - 1) / segment_binning_per_wg(P)); }
+
+hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, SegmentTables tb, int grid_x, int grid_y, int seg_shift,
+                               int capacity, bool prefixed, hipStream_t stream) {
+    const int nseg = grid_y * ((grid_x + (1 << seg_shift) - 1) >> seg_shift);
+    const size_t lds = (size_t)nseg * 16;
+    const int per_wg = segment_binning_per_wg(P);
+    auto kernel = bin_segments_kernel;
+    static std::mutex mu;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc != hipSuccess) return rc;
+    {   // the attribute is per device (and cheap): set it once for each device this process drives
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            rc = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SEG_K1_LDS_MAX);
+            if (rc != hipSuccess) return rc;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
+    launch_shmem(kernel, dim3(segment_binning_workgroups(P)), dim3(K1_THREADS), lds, stream, P, per_wg, geom, tb, bin.pair_keys,
+                 bin.pair_cov, grid_x, grid_y, seg_shift, capacity, prefixed ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
+                            int seg_shift, int capacity, bool prefixed, hipStream_t stream) {
+    const int nseg = grid_y * ((grid_x + (1 << seg_shift) - 1) >> seg_shift);
+    launch(bin_tiles_kernel, dim3(nseg), dim3(K2_THREADS), stream, img, bin.point_list, bin.keys, tb, bin.pair_keys, bin.pair_cov,
+           geom.block_tiles, (P + 255) / 256, segment_binning_workgroups(P), grid_x, grid_y, seg_shift, capacity, prefixed ? 1 : 0);
+    return hipGetLastError();
+}
+
+}  // namespace dgr

@@ -16,6 +16,8 @@ import os
 import weakref
 from typing import NamedTuple
 
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -109,16 +111,33 @@ def check_async_errors():
         _check_oldest()
 
 
-# dgr_amd.multiview.ViewStreams.before_backward(): a (stream, event) the NEXT rasterizer backward makes its stream wait for
-# once its kernels are issued -- i.e. before autograd goes on to the activations' backward and to the accumulation into the
-# leaves' .grad, the only part of a view's backward that touches state shared with the previous view.  Module-level on
-# purpose: it is set by the thread that calls loss.backward() and consumed by the autograd engine's thread.
-_post_backward_wait = None
+# dgr_amd.multiview.ViewStreams.before_backward(): an event the rasterizer backward THAT RUNS ON A GIVEN STREAM makes that
+# stream wait for once its kernels are issued -- i.e. before autograd goes on to the activations' backward and to the
+# accumulation into the leaves' .grad, the only part of a view's backward that touches state shared with the previous view.
+# Keyed by the raw stream handle: the wait is set by the thread that calls loss.backward() and consumed by the autograd
+# engine's thread (which runs the node on the forward's stream), and two ViewStreams objects -- or two threads -- never
+# see each other's entries.  ViewStreams drops a view's entry when the view's block ends (a backward that never reached
+# the rasterizer must not leave a stale wait behind).
+_post_backward_waits = {}
+_post_backward_lock = threading.Lock()
+
+
+def _set_post_backward_wait(stream, event):
+    with _post_backward_lock:
+        _post_backward_waits[int(stream.cuda_stream)] = (stream, event)
+
+
+def _drop_post_backward_wait(stream):
+    with _post_backward_lock:
+        _post_backward_waits.pop(int(stream.cuda_stream), None)
 
 
 def _consume_post_backward_wait():
-    global _post_backward_wait
-    w, _post_backward_wait = _post_backward_wait, None
+    if not _post_backward_waits:
+        return
+    key = int(torch.cuda.current_stream().cuda_stream)
+    with _post_backward_lock:
+        w = _post_backward_waits.pop(key, None)
     if w is not None:
         w[0].wait_event(w[1])
 

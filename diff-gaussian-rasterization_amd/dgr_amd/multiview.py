@@ -86,7 +86,7 @@ class ViewStreams:
       * accumulation in `.grad`: call `views.before_backward()` between a view's forward and its `backward()`.  The
         view's stream then waits for the END of the previous view at the one point where it matters: right after the
         rasterizer's own backward kernels have been issued, before autograd goes on to the activations' backward and
-        the accumulation into the leaves (`dgr_amd.light._post_backward_wait`).  The rasterizer kernels of consecutive
+        the accumulation into the leaves (`dgr_amd.light._set_post_backward_wait`, keyed by the view's stream).  The rasterizer kernels of consecutive
         views keep overlapping; only the short tail that touches shared `.grad` is ordered -- what
         `dgr_amd.slam.render_batch` does.  (If the loss reaches other shared leaves before the rasterizer node, order
         the whole backward instead: `views.before_backward(whole=True)`.)"""
@@ -105,18 +105,12 @@ class ViewStreams:
             done.record(self.stream)
             self.owner._done = done
             self.owner._current = None
+            light._drop_post_backward_wait(self.stream)  # (a backward that never reached the rasterizer leaves nothing behind)
             return self.ctx.__exit__(*exc)
 
-    def __init__(self, n=3, device=None, count_with_atomics=True):
-        """`count_with_atomics`: while views of this object are in flight (first next() .. join()) the forward counts tile
-        instances with global atomics (library option lds_count = 0) instead of in LDS histograms.  With one view at a time
-        the LDS count is 10 % of a view faster; with several in flight the atomics' wait on the memory-side atomic unit is
-        filled by the other views' kernels and the LDS count only competes with them (config 3: 0.415 against 0.424 ms per
-        view, config 4: 1.40 against 1.49; profiles/r3_count_ab.txt).  The option is process-wide."""
+    def __init__(self, n=3, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(n)))]
-        self._atomics = bool(count_with_atomics) and len(self.streams) > 1
-        self._saved_count_mode = None
         self._i = 0
         self._fresh = set()  # streams already ordered after the caller's stream since the last join()
         self._done = None    # event at the end of the most recent view
@@ -129,9 +123,6 @@ class ViewStreams:
         k = self._i % len(self.streams)
         st = self.streams[k]
         self._i += 1
-        if self._atomics and self._saved_count_mode is None and _capi.get_option("lds_count") == 1:
-            self._saved_count_mode = 1  # (only the default "by job size" is overridden: a forced 0 / 2 stays)
-            _capi.set_option("lds_count", 0)
         if k not in self._fresh:
             st.wait_stream(torch.cuda.current_stream(self.device))
             self._fresh.add(k)
@@ -146,7 +137,7 @@ class ViewStreams:
         if whole:
             v.stream.wait_event(v.prev_done)
         else:
-            light._post_backward_wait = (v.stream, v.prev_done)
+            light._set_post_backward_wait(v.stream, v.prev_done)
 
     def join(self):
         """The caller's stream waits for every view issued so far."""
@@ -155,9 +146,6 @@ class ViewStreams:
             cur.wait_stream(st)
         self._fresh.clear()
         self._done = None
-        if self._saved_count_mode is not None:  # (read by the forward at issue time: every view has been issued by now)
-            _capi.set_option("lds_count", self._saved_count_mode)
-            self._saved_count_mode = None
 
 
 class CapturedStep:

@@ -46,6 +46,9 @@ const char* dgr_version(void);
 /* ---- state buffer sizes (the reference's `required<T>(n)`, L/cr/rasterizer_impl.h:66-72) ---- */
 size_t dgr_geometry_bytes(int P);
 size_t dgr_image_bytes(int width, int height);
+/* 24 bytes per instance of capacity (sorted list, key scratch, arrival ranks / pair columns, pair keys) plus the segment
+ * binning's forward-only tables (csrc/segment_binning.hip: 2 KB per 16-tile row segment), i.e. NON-ZERO for a capacity of 0:
+ * the presized entry points need a binning buffer of this size for every P > 0 and reject NULL. */
 size_t dgr_binning_bytes(int num_rendered_capacity, int width, int height);
 /* scratch the backward needs (per-Gaussian accumulator rows + reduction partials) */
 size_t dgr_light_backward_scratch_bytes(int P, int width, int height);
@@ -235,13 +238,15 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle
  *     is cut down to the box where alpha can reach 15/255.  Images and gradients are unchanged, but num_rendered, the
  *     tile lists and n_contrib are NOT the reference's any more -- hence opt-in.
- *  "lds_count" (default 1): how the forward counts a frame's tile instances.  1 = in per-workgroup LDS histograms (no
- *     global atomics, no cleared counters) when the frame's histogram fits LDS (up to 40 000 tiles, i.e. beyond 3840x2160)
- *     and the binning buffer holds at most 4 Mi instances, else with returning global atomics on per-tile counters (round
- *     2's path) -- the LDS count is faster on an otherwise idle GPU at every size, the atomics' wait is filled by other
- *     views' kernels when several views are in flight, and the measured break-even lies between 1.65 M and 6.6 M instances;
- *     2 = LDS whenever the histogram fits; 0 = never.  Results are identical bit for bit.  dgr_binning_bytes() includes the
- *     LDS count's forward-only workspace.
+ *  "lds_count" (default 1): how the forward bins a frame's tile instances.  1 = the two-level segment binning
+ *     (csrc/segment_binning.hip: pairs per 16-, 8- or 4-tile row segment, tile lists built and sorted in LDS; no global
+ *     atomics, no cleared counters) whenever the frame's segment tables fit LDS (up to 8 192 four-tile segments, i.e.
+ *     3840x2160 and a little beyond); 0 = returning global atomics on per-tile counters (csrc/binning.hip, round 2's path),
+ *     which also serves larger frames.  Results are identical bit for bit.  dgr_binning_bytes() includes the segment
+ *     binning's forward-only tables.
+ *  "blend_wgs_per_cu" (default 0 = no cap; 3..7): at most this many blend workgroups per CU (they are padded with unused
+ *     LDS), which leaves wave slots, registers and LDS for kernels of other streams -- collectives, other views' bandwidth-
+ *     bound kernels -- that otherwise enter a CU only as blend workgroups drain.  Costs the blend kernels 3-7 % at 7.
  *  "profile_every": n >= 1 = dgr_profile_* brackets every n-th launch of the selected stage only (default 1).
  *  "batch_streams" (default 2): streams the batched entry points spread the per-view stages of a batch over (1..8).
  *  "batch_order" (default 0): 0 = view v's binning + blend chain on stream v mod batch_streams; 1 = all binning stages on a

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5 (driver round 3), experiment 1: which alpha path meets north_star's 1e-5, and what it costs.
-# Needs the library built with -DDGR_ALPHA_EXPERIMENT (modes 2 = hi/lo-corrected v_exp_f32, 3 = ocml expf + IEEE division
+# Ran at commit a227a54 (the experiment modes were removed afterwards). Needed the library built with -DDGR_ALPHA_EXPERIMENT (modes 2 = hi/lo-corrected v_exp_f32, 3 = ocml expf + IEEE division
 # next to 0 = host-bit-exact exp_ref/div_ref and 1 = fast).  Output: gpurun_out/r5_alpha/.
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r5_alpha; mkdir -p $O

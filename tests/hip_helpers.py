@@ -40,7 +40,7 @@ def hip_forward(s, deg, colors_precomp=None, cov3D_precomp=None, prefiltered=Fal
 
 
 _EXPORT = {  # name -> (numpy dtype, elements per unit, unit)
-    "depths": (np.float32, "P"), "radii": (np.int32, "P"), "cov3D": (np.float32, "6P"), "means2D": (np.float32, "2P"),
+    "depths": (np.float32, "P"), "radii": (np.int32, "P"), "means2D": (np.float32, "2P"),
     "conic_opacity": (np.float32, "4P"), "rgb": (np.float32, "3P"), "clamped": (np.uint8, "3P"),
     "tiles_touched": (np.uint32, "P"), "point_list": (np.uint32, "R"), "keys": (np.uint64, "R"),
     "contribution_tags": (np.uint8, "R1"),
@@ -82,6 +82,13 @@ def binning_capacity(d, W, H):
     # alignment padding can make several capacities share one size (and hence one layout): never report less than R
     R = d["num_rendered"]
     return lo if lo >= R else R
+
+
+def hip_cov3D(s, scale_modifier=1.0):
+    """computeCov3D as the forward and the backward evaluate it (the geometry state does not keep it: csrc/preprocess.hip's
+    compute_cov3d, through dgr_cov3d_forward -- the same device function)."""
+    from dgr_amd.multiview import shared_cov3D
+    return shared_cov3D(T(s.scales), T(s.rots), scale_modifier).detach().cpu().numpy()
 
 
 def hip_backward(s, deg, out, colors_precomp=None, cov3D_precomp=None, track_off=False, map_off=False,

