@@ -45,6 +45,11 @@ WORKLOADS = {
     "config5": (5_000_000, 3840, 2160, 3),   # per-GPU view of BASELINE config 5
 }
 
+WORKLOAD_NAMES = {
+    "config1": "BASELINE config 1's size, on the GPU", "config2": "BASELINE config 2", "config3": "BASELINE config 3, the one the metric is quoted on",
+    "config4": "BASELINE config 4: the per-GPU view of its 8 views over 8 GPUs", "config5": "BASELINE config 5: one view of its 32-view batch over 8 GPUs",
+}
+
 
 def algorithmic_bytes(stage, P, V, R, N, M):
     """Minimum HBM bytes of one launch of `stage`: SURVEY.md s8(d)'s per-view model (every stage reads its inputs once and
@@ -112,6 +117,11 @@ def main():
                     help="the comparison for --batch: the same views one call at a time, .grad accumulating over this many "
                          "views (autograd's `+=`) before it is reset -- what a mapping iteration over a keyframe batch does "
                          "on the one-view surface; implies --views-in-flight 1")
+    ap.add_argument("--blend-wgs-per-cu", type=int, default=0,
+                    help="dgr_set_option('blend_wgs_per_cu'): cap on the blend kernels' workgroups per CU (3..7; 0 = none). They "
+                         "hold every wave slot of a CU otherwise, and kernels of other streams -- RCCL's with --gpus N, other views' "
+                         "front ends -- only get in as blend workgroups drain (one GPU, three views in flight: 0.448 ms per view "
+                         "without, 0.445 at 7, 0.454 at 6; profiles/r5/blend_cap_summary.txt)")
     ap.add_argument("--sync-mode", default="lazy", choices=["lazy", "strict"],
                     help="lazy: forward's status word is checked one step late (no host sync in the step); "
                          "strict: one blocking status read per forward, like the reference")
@@ -154,6 +164,8 @@ def main():
 
     if args.tight_cull:
         _capi.set_option("tight_cull", 1)
+    if args.blend_wgs_per_cu:
+        _capi.set_option("blend_wgs_per_cu", args.blend_wgs_per_cu)
     if args.batch_streams:
         _capi.set_option("batch_streams", args.batch_streams)
     if args.batch_order >= 0:
@@ -365,13 +377,38 @@ def main():
         iso_ms = stage_ms[dominant]  # the kernel with nothing else on the GPU (calibration pass, one view at a time):
         achieved = abytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0  # what a rocprofv3 kernel trace reproduces
         overlap = abytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0   # the same kernel sharing the GPU with the other streams
-        traffic = None
+        # Counter figures come from the committed PMC passes (profiles/pmc_traffic.json; rocprofv3 cannot run inside this
+        # process): HBM bytes per launch, and the vector instructions per launch of the two blend kernels.  They go stale
+        # when a kernel changes, so the commit they were taken at is printed with them.
+        traffic, pmc_commit, pmc = None, None, {}
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):
             try:
-                traffic = json.load(open(pmc_file)).get(args.workload, {}).get(dominant)
+                pmc = json.load(open(pmc_file))
+                traffic = pmc.get(args.workload, {}).get(dominant)
+                pmc_commit = pmc.get("commit")
             except Exception:
-                traffic = None
+                traffic, pmc = None, {}
+        # The blend kernels are bound by vector-instruction issue, not by HBM: SQ_INSTS_VALU per launch x 2
+        # cycles (a wave64 instruction occupies a SIMD-32 for two cycles) against the cycles of the chip's 1024 SIMDs over the
+        # kernel's isolated duration measured in THIS run.  The measured mix averages ~4 cycles per instruction (DPP adds,
+        # compares into SGPR pairs, selects 4.2; double-pipe and transcendental operations 5-8), so ~0.5 is this bound's
+        # practical ceiling.
+        clock_ghz = 2.4  # MI355X nominal shader clock (MI355X_MICROARCH.md); the chip clocks lower under load, which makes `frac` a lower bound
+        roofline_valu = None
+        if args.variant == "light" and args.workload == "config3" and not args.tight_cull:
+            roofline_valu = {}
+            for k in ("render_fwd", "render_bwd"):
+                n_valu = pmc.get("config3_insts", {}).get(k, {}).get("valu")
+                t_ms = stage_ms.get(k)
+                if n_valu and t_ms:
+                    roofline_valu[k] = {"insts_valu_per_launch": n_valu, "issue_cycles_per_inst": 2, "simds": 1024,
+                                        "clock_ghz": clock_ghz, "avg_ms": t_ms,
+                                        "frac": n_valu * 2.0 / (1024 * clock_ghz * 1e9 * t_ms * 1e-3),
+                                        "hbm_frac": algorithmic_bytes(k, P, V, R, N, 16) / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            roofline_valu["note"] = ("which roof binds the blend kernels: `frac` = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x 2.4 GHz "
+                                     "nominal x this run's isolated kernel time), `hbm_frac` = the same kernel against 8 TB/s; counters "
+                                     "from profiles/pmc_traffic.json, commit " + str(pmc_commit))
         line = {
             "metric": "Mviews/sec fwd+bwd @1080p, 500k Gaussians",
             "value": views_per_s / 1e6,
@@ -385,7 +422,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
+            "config": {"workload": f"{args.workload} ({WORKLOAD_NAMES[args.workload]}): synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
                                    f"fwd+bwd incl. viewmatrix gradient, "
                                    + (f"one view per step, {K} independent views in flight per GPU" if not Vb else
                                       f"NOT the headline step: {Vb} camera views of the same Gaussians per step through the batched entry "
@@ -409,11 +446,12 @@ def main():
                                               (f"one fused RCCL sum of 248 B/Gaussian per {G} local view(s)"
                                                + ("" if G > 1 else f" ({args.allreduce})")) if not Vb else
                                               f"one fused RCCL sum of 248 B/Gaussian per batched step of {Vb} local views (blocking)"),
-                       "view_hbm_frac": 0.83e9 * (316 * P + 566 * V + 172 * R + 72 * N) / (316 * 5e5 + 566 * 425824 + 172 * 1654310 + 72 * 2073600)
-                                        * (views_per_s / world) / (HBM_PEAK_GBS * 1e9),
+                       "view_hbm_frac": (316 * P + 566 * V + 172 * R + 72 * N) * (views_per_s / world) / (HBM_PEAK_GBS * 1e9),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes": abytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": None if traffic is None else
+                         "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE), taken at commit " + str(pmc_commit),
+                         "algorithmic_bytes": abytes,
                          "avg_ms": iso_ms, "launches": stage_n[dominant],
                          "how": "HIP events in the kernel's dispatch packet, on the launching stream; `frac` is the kernel alone "
                                 "on the GPU (untimed calibration pass, one view at a time: the figure profiles/*_kernel_stats.txt "
@@ -421,6 +459,7 @@ def main():
                                 "CUs with the other streams' kernels",
                          "frac_under_overlap": overlap / HBM_PEAK_GBS, "avg_ms_under_overlap": dom_ms,
                          "launches_under_overlap": dom_n, "measured_in_timed_region": live},
+            "roofline_valu": roofline_valu,
         }
         if not args.no_cpu_baseline and args.variant == "light" and world == 1:  # (the CPU baseline: rank 0 at N = 1 only)
             line["cpu_baseline"], ref_grads = cpu_baseline(s, deg, args.cpu_runs)
@@ -435,9 +474,10 @@ def main():
                                     - np.asarray(ref_grads[k], np.float64).reshape(-1)).max()) for k, v in pairs.items()}
             line["config"]["grad_max_abs_err"] = dict(
                 errs, max=max(errs.values()), scale={k: float(np.abs(ref_grads[k]).max()) for k in pairs},
-                note="end to end (HIP forward feeding HIP backward) vs the CPU oracle; the light backward derives "
-                     "T_final = 1 - alpha_image, which amplifies one-ulp forward differences (DESIGN.md s5: stage-isolated "
-                     "agreement is ~3e-7 of each tensor's scale; SURVEY s8d expects ~5e-4 abs on the pose gradient)")
+                note="end to end (HIP forward feeding HIP backward) vs the CPU oracle, BASELINE's loss scaling; north_star's "
+                     "tolerance is 1e-5 abs.  The default alpha path carries the host's bits (csrc/exact_math.h): the alpha "
+                     "image IS the oracle's, so the light backward's T_final = 1 - alpha_image amplifies nothing "
+                     "(fast_alpha option: 5.8e-5 on dL_dview; DESIGN.md s5)")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -393,11 +393,16 @@ bool segment_binning_fits(int W, int H) {
 // callback path passes the exact count): segments are sized so that capacity / tiles * segment <= 1.5 K2_CAP, i.e. an
 // average segment fills at most two thirds (lazy) or all (exact) of the budget; denser segments take the per-tile path.
 int segment_shift(int W, int H, int capacity) {
-    const long tiles = (long)tiles_x(W) * tiles_y(H);
+    const int gx = tiles_x(W), gy = tiles_y(H);
+    const long tiles = (long)gx * gy;
     const long per_tile = tiles > 0 ? ((long)(capacity > 0 ? capacity : 0) + tiles - 1) / tiles : 0;
-    for (int sh = 4; sh > 2; sh--)
-        if ((per_tile << sh) * 2 <= (long)K2_CAP * 3) return sh;
-    return 2;
+    int sh = 2;
+    for (int c = 4; c > 2; c--)
+        if ((per_tile << c) * 2 <= (long)K2_CAP * 3) { sh = c; break; }
+    // small frames: bin_tiles is one workgroup per segment and each is a chain of dependent phases -- 90 workgroups on 256
+    // CUs (640x480 at 16 tiles per segment) took as long as 544 (1920x1080); prefer at least two workgroups per CU
+    while (sh > 2 && (long)gy * ((gx + (1 << sh) - 1) >> sh) < 512) sh--;
+    return sh;
 }
 // Gaussians per bin_segments workgroup (a multiple of 1024, so that workgroup ranges start at a 256-block boundary) and the
 // number of workgroups: at most SEG_MAX_WGS
