@@ -359,14 +359,23 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
         const bool in_lds = n <= K2_LDS_SORT_MAX;
         if (tid == 0) sh.counter = 0u;
         __syncthreads();
-        for_each_pair(sh, nwg, wave, lane, [&](uint32_t a) {
-            const uint32_t c = pair_cov[a];
-            if ((c & 15u) <= (uint32_t)t && (uint32_t)t <= (c >> 4)) {
-                const uint32_t pos = atomicAdd(&sh.counter, 1u);
-                const uint64_t key = pair_keys[a];
-                if (in_lds) sh.keys[pos] = key; else gk[pos] = key;
-            }
-        });
+        if (in_regs) {  // (the pairs are still in registers: a long tile list, or more keys than LDS holds, not more pairs)
+#pragma unroll
+            for (int k = 0; k < K2_PPT; k++)
+                if (pc[k] != 0xffffffffu && (pc[k] & 15u) <= (uint32_t)t && (uint32_t)t <= (pc[k] >> 4)) {
+                    const uint32_t pos = atomicAdd(&sh.counter, 1u);
+                    if (in_lds) sh.keys[pos] = pk[k]; else gk[pos] = pk[k];
+                }
+        } else {
+            for_each_pair(sh, nwg, wave, lane, [&](uint32_t a) {
+                const uint32_t c = pair_cov[a];
+                if ((c & 15u) <= (uint32_t)t && (uint32_t)t <= (c >> 4)) {
+                    const uint32_t pos = atomicAdd(&sh.counter, 1u);
+                    const uint64_t key = pair_keys[a];
+                    if (in_lds) sh.keys[pos] = key; else gk[pos] = key;
+                }
+            });
+        }
         __syncthreads();
         if (in_lds) {
             wg_sort_lds<K2_THREADS>(sh.keys, n, tid);

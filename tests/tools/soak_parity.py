@@ -15,6 +15,7 @@ from util import assert_grad_close, assert_image_close, make_scene, mask_flipped
 from oracle import oracle as O  # noqa: E402
 
 O.use_cmath(False)
+FAST = os.environ.get("DGR_FAST_ALPHA") == "1"
 n_light = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_full = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 7)
@@ -65,8 +66,14 @@ for i in range(n_light):
         assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
         assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
         npx = s.W * s.H
-        for k in ("color", "depth", "depth_median", "opacity_map"):
-            assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx))
+        if FAST:
+            for k in ("color", "depth", "depth_median", "opacity_map"):
+                assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx))
+        else:  # the default alpha path carries the host's bits: no pixel decides a threshold differently
+            assert np.array_equal(d["opacity_map"], ref["opacity_map"]) and np.array_equal(d["depth_median"], ref["depth_median"])
+            assert np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
+            for k in ("color", "depth"):
+                assert_image_close(d[k], ref[k], k, tol=1e-6, max_outliers=0.0)
         grads = tuple(g * npx ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
         # pixels on which the two forward passes decided a hard threshold differently get zero incoming gradient on both
         # sides (tests/util.py): every draw is compared, with no outlier allowance beyond the backward's own median test
@@ -78,7 +85,9 @@ for i in range(n_light):
         if only:
             torch.cuda.synchronize()
             print("  exports done", flush=True)
-        g = hh.hip_backward(s, deg, out, grads=grads, alphas=ref["opacity_map"], scale_modifier=sm, track_off=modes[0], map_off=modes[1], **kw)
+        # (default alpha path: END TO END -- the HIP forward's own alpha image, which is the oracle's; fast_alpha: stage-isolated)
+        g = hh.hip_backward(s, deg, out, grads=grads, alphas=ref["opacity_map"] if FAST else None, scale_modifier=sm,
+                            track_off=modes[0], map_off=modes[1], **kw)
         gr = hh.oracle_backward(O, st, s, deg, ref["opacity_map"], grads=grads, scale_modifier=sm, track_off=modes[0], map_off=modes[1], **kw)
         names = ["dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D"]
         names += ["dL_dcolors"] if "colors_precomp" in kw else ["dL_dsh"]
@@ -112,9 +121,12 @@ for i in range(n_full):
         assert np.array_equal(d["radii"], ref["radii"]) and d["num_rendered"] == ref["num_rendered"]
         assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
         for k in ("color", "depth", "uncertainty"):
-            assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx))
-        if not (np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
-                and np.array_equal(hh.hip_state("n_valid", s, d), st.get("n_valid_contrib"))):
+            assert_image_close(d[k], ref[k], k, max_outliers=max(1e-4, 2.0 / npx) if FAST else 0.0, tol=1e-5 if FAST else 1e-6)
+        same = (np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
+                and np.array_equal(hh.hip_state("n_valid", s, d), st.get("n_valid_contrib")))
+        if not FAST:
+            assert same and np.array_equal(d["uncertainty"], ref["uncertainty"])
+        elif not same:
             flips += 1  # a pixel blended a different set of Gaussians (a pair within one ulp of a threshold)
             continue
         for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
