@@ -211,12 +211,22 @@ __device__ __forceinline__ void for_each_pair(const K2Shared& sh, int nwg, int w
     }
 }
 
-__device__ __forceinline__ void sort_tile_in_wave(const uint64_t* src, int n, uint32_t* dst, int lane) {
-    if (n <= 64) sort_wave_regs<1>(src, n, dst, lane);
-    else if (n <= 128) sort_wave_regs<2>(src, n, dst, lane);
-    else if (n <= 256) sort_wave_regs<4>(src, n, dst, lane);
-    else if (n <= 512) sort_wave_regs<8>(src, n, dst, lane);
-    else sort_wave_regs<16>(src, n, dst, lane);
+// LONG_LISTS (chosen per launch from the expected list length): lists of 513 .. 1024 entries are the rule, not the exception
+template <bool LONG_LISTS>
+__device__ __forceinline__ void sort_tile_in_wave(uint64_t* src, int n, uint32_t* dst, int lane) {
+    if (LONG_LISTS) {
+        if (n <= 64) sort_wave_regs<1>(src, n, dst, lane);
+        else if (n <= 128) sort_wave_regs<2>(src, n, dst, lane);
+        else if (n <= 256) sort_wave_regs<4>(src, n, dst, lane);
+        else if (n <= 512) sort_wave_regs<8>(src, n, dst, lane);
+        else sort_wave_regs<16>(src, n, dst, lane);
+    } else {
+        if (n <= 64) sort_wave_trunc<1>(src, n, dst, lane);
+        else if (n <= 128) sort_wave_trunc<2>(src, n, dst, lane);
+        else if (n <= 256) sort_wave_trunc<4>(src, n, dst, lane);
+        else if (n <= 512) sort_wave_trunc<8>(src, n, dst, lane);
+        else sort_wave_trunc_1024(src, n, dst, lane);
+    }
 }
 
 // bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of segments
@@ -227,6 +237,7 @@ __device__ __forceinline__ int xcd_contiguous(int b, int n) {
     return base + local;
 }
 
+template <bool LONG_LISTS>
 __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img, uint32_t* __restrict__ point_list,
                                                                   uint64_t* __restrict__ key_scratch, SegmentTables tb,
                                                                   const uint64_t* __restrict__ pair_keys,
@@ -345,7 +356,7 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
         // ---- every wave sorts whole tile lists in its registers and writes the ids
         for (int t = wave; t < ntl; t += K2_WAVES) {
             const int n = (int)sh.tcnt[t];
-            if (n > 0) sort_tile_in_wave(sh.keys + sh.tbase[t], n, point_list + before + sh.tbase[t], lane);
+            if (n > 0) sort_tile_in_wave<LONG_LISTS>(sh.keys + sh.tbase[t], n, point_list + before + sh.tbase[t], lane);
         }
         return;
     }
@@ -448,7 +459,10 @@ hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, Segmen
 hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
                             int seg_shift, int capacity, bool prefixed, hipStream_t stream) {
     const int nseg = grid_y * ((grid_x + (1 << seg_shift) - 1) >> seg_shift);
-    launch(bin_tiles_kernel, dim3(nseg), dim3(K2_THREADS), stream, img, bin.point_list, bin.keys, tb, bin.pair_keys, bin.pair_cov,
+    // expected entries per tile, from the capacity the caller sized the binning buffer with (segment_shift() uses the same)
+    const long tiles = (long)grid_x * grid_y;
+    const bool long_lists = tiles > 0 && (long)capacity / tiles > 900;
+    launch(long_lists ? bin_tiles_kernel<true> : bin_tiles_kernel<false>, dim3(nseg), dim3(K2_THREADS), stream, img, bin.point_list, bin.keys, tb, bin.pair_keys, bin.pair_cov,
            geom.block_tiles, (P + 255) / 256, segment_binning_workgroups(P), grid_x, grid_y, seg_shift, capacity, prefixed ? 1 : 0);
     return hipGetLastError();
 }

@@ -733,3 +733,35 @@ def test_lds_count_and_global_atomic_count_agree(variant, P, W, H, sm):
             assert_grad_close(d1[k], d0[k], k, rel_to_max=1e-6)
         else:
             assert np.array_equal(d1[k], d0[k]), k
+
+
+@pytest.mark.parametrize("P,W,H,sm", [(40000, 320, 240, 1.0), (70000, 320, 240, 1.0), (9000, 97, 61, 2.0)])
+def test_tile_lists_with_equal_and_nearly_equal_depths(oracle, P, W, H, sm):
+    """The per-tile sort orders a list by ONE 32-bit word per entry -- the depth's upper 22 bits and the entry's slot -- and
+    settles entries that agree in those bits with a fix-up on the full (depth, id) keys (csrc/tile_sort.h).  Here a third of
+    the Gaussians lie on one plane of constant camera depth (identical depth bits: the id decides), a third within 2^-17
+    relative of another (equal upper bits, different full keys), the rest anywhere.  Lists of ~450 entries (one register pass),
+    ~800 (four parts merged by rank) and ~2000-2800 (the workgroup's LDS sort), runs of equal upper bits hundreds long.
+    point_list and ranges must be the oracle's bit for bit."""
+    from dgr_amd.synth import camera
+    s = make_scene(P, W, H, 9)
+    rng = np.random.default_rng(3)
+    _, _, Rm, t, *_ = camera(W, H, 0.05)
+    cam = (s.means.astype(np.float64) @ Rm.T) + t          # camera-space positions of the scene's Gaussians
+    third = P // 3
+    for lo, hi, z in ((0, third, np.full(third, 4.0)), (third, 2 * third, 6.0 * (1.0 + rng.integers(0, 64, third) * 2.0 ** -23))):
+        k = z / cam[lo:hi, 2]
+        cam[lo:hi] *= k[:, None]                           # same pixel, new depth
+    s = s._replace(means=((cam - t) @ Rm).astype(np.float32))
+    _, d = hh.hip_forward(s, 3, scale_modifier=sm)
+    st, ref = hh.oracle_forward(oracle, s, 3, scale_modifier=sm)
+    depths = hh.hip_state("depths", s, d)
+    vis = ref["radii"] > 0
+    assert np.unique(depths[:third][vis[:third]]).size <= 16         # (one plane up to the rounding of the re-projection)
+    assert d["num_rendered"] == ref["num_rendered"] and np.array_equal(d["radii"], ref["radii"])
+    rg = hh.hip_state("ranges", s, d).reshape(-1, 2)
+    assert (rg[:, 1] - rg[:, 0]).max() > 400
+    assert np.array_equal(rg.reshape(-1), st.get("ranges"))
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    assert np.array_equal(hh.hip_state("keys", s, d), st.get("keys"))
+
