@@ -311,6 +311,9 @@ def main():
         if dist is not None:
             raise SystemExit("--graph is a single-GPU mode")
         from dgr_amd.multiview import CapturedStep
+        # (no dispatch-packet events inside a capture: nothing can be bracketed live in a replayed graph, and events on
+        #  EVERY launch of a captured stream -- `profile_every` = 1 below 32 steps -- crash this ROCm's capture)
+        _capi.profile_select("")
         captured.extend(CapturedStep(step, stream=torch.cuda.Stream(device=dev)) for _ in range(K))
     # one view at a time, for reference (short, untimed by the contract)
     serial_ms = None
