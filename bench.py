@@ -465,6 +465,11 @@ def main():
             "roofline_valu": roofline_valu,
         }
         if not args.no_cpu_baseline and args.variant == "light" and world == 1:  # (the CPU baseline: rank 0 at N = 1 only)
+            # Beside the headline (eager: every step goes through the autograd surface on the host): the same K steps with
+            # one captured view per stream replayed from hipGraphs -- what a fixed-shape SLAM loop can do.  Reported, never
+            # `value`; measured in a child process so that nothing of it touches this run.
+            if not args.graph and not Vb and args.group <= 1 and not os.environ.get("DGR_BENCH_NO_GRAPH_LINE"):
+                line["config"]["ms_per_step_hipgraph_replay"] = graph_replay_line(args)
             line["cpu_baseline"], ref_grads = cpu_baseline(s, deg, args.cpu_runs)
             # second half of BASELINE's metric: gradient max-abs-err against the CPU restatement of the reference, same
             # inputs and loss scaling (pixel-gradient images N(0,1)/(H W)); one extra untimed view on the default stream
@@ -491,6 +496,17 @@ def main():
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
+
+
+def graph_replay_line(args):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--graph",
+           "--no-cpu-baseline", "--workload", args.workload, "--variant", args.variant, "--views-in-flight", str(args.views_in_flight)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        return float(json.loads(out.stdout.strip().splitlines()[-1])["ms_per_step"])
+    except Exception:
+        return None
 
 
 def spawn_ranks(n):
