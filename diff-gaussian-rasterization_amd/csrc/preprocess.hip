@@ -432,7 +432,10 @@ __device__ __forceinline__ void fwd_view_colour(const PreprocessFwdArgs& a, int 
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessFwdArgs a) {
+#ifndef DGR_PPF_WAVES
+#define DGR_PPF_WAVES 5
+#endif
+__global__ void __launch_bounds__(256, DGR_PPF_WAVES) preprocess_fwd_kernel(PreprocessFwdArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     FwdGeom g{0, make_ushort4(0, 0, 0, 0), false, false};
     float3 p_orig = make_float3(0.f, 0.f, 0.f);
@@ -899,7 +902,10 @@ __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], doubl
 // Fused per-Gaussian backward.  Order of the dL_dmean3D accumulation follows the reference's kernel
 // order: blend-kernel median term, computeCov2DCUDA, preprocessCUDA (2D mean, depth, SH).
 // (forcing more than 4 waves/SIMD spills: 5 -> 128 us, 6 -> 163 us against 87 us)
-__global__ void __launch_bounds__(256, 4) preprocess_bwd_kernel(PreprocessBwdArgs a) {
+#ifndef DGR_PPB_WAVES
+#define DGR_PPB_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, DGR_PPB_WAVES) preprocess_bwd_kernel(PreprocessBwdArgs a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     float pose[12];
 #pragma unroll
