@@ -122,6 +122,10 @@ def main():
                          "hold every wave slot of a CU otherwise, and kernels of other streams -- RCCL's with --gpus N, other views' "
                          "front ends -- only get in as blend workgroups drain (one GPU, three views in flight: 0.448 ms per view "
                          "without, 0.445 at 7, 0.454 at 6; profiles/r5/blend_cap_summary.txt)")
+    ap.add_argument("--scene", default="synth-v1", choices=["synth-v1", "clustered"],
+                    help="not the headline workload: clustered = dgr_amd.synth.cluster_scene of the same Gaussians (60 %% of them "
+                         "pulled into one region of the frame: tile lists of 51 .. 1135 entries instead of 203 +- 20 %%), the "
+                         "case the blend kernels' heaviest-first tile schedule is for")
     ap.add_argument("--sync-mode", default="lazy", choices=["lazy", "strict"],
                     help="lazy: forward's status word is checked one step late (no host sync in the step); "
                          "strict: one blocking status read per forward, like the reference")
@@ -172,6 +176,9 @@ def main():
         _capi.set_option("batch_order", args.batch_order)
     P, W, H, deg = WORKLOADS[args.workload]
     s = make_scene(P, W, H, seed=0, view_index=rank)  # rank r renders view r of the same Gaussians
+    if args.scene == "clustered":
+        from dgr_amd.synth import cluster_scene
+        s = cluster_scene(s)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     mapping = not args.tracking
     means3D = t(s.means).requires_grad_(mapping)
@@ -425,7 +432,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload} ({WORKLOAD_NAMES[args.workload]}): synth-v1 seed 0, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
+            "config": {"workload": f"{args.workload} ({WORKLOAD_NAMES[args.workload]}): synth-v1 seed 0{' CLUSTERED (not a BASELINE scene: dgr_amd.synth.cluster_scene)' if args.scene == 'clustered' else ''}, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
                                    f"fwd+bwd incl. viewmatrix gradient, "
                                    + (f"one view per step, {K} independent views in flight per GPU" if not Vb else
                                       f"NOT the headline step: {Vb} camera views of the same Gaussians per step through the batched entry "

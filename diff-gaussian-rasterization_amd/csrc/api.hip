@@ -129,9 +129,9 @@ struct StageProf {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
 StageProf g_prof[] = {{"zero_counters"}, {"preprocess_fwd"}, {"scan_blocks"}, {"bin_segments"}, {"bin_tiles"}, {"count_rank"},
-                      {"scan_tiles"}, {"emit_instances"}, {"sort_tiles"}, {"render_fwd"}, {"zero_scratch"}, {"render_bwd"},
+                      {"scan_tiles"}, {"emit_instances"}, {"sort_tiles"}, {"tile_schedule"}, {"render_fwd"}, {"zero_scratch"}, {"render_bwd"},
                       {"preprocess_bwd"}};
-enum { ST_ZERO_FWD, ST_PRE_FWD, ST_SCAN_BLOCKS, ST_BIN_SEGMENTS, ST_BIN_TILES, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_RENDER_FWD,
+enum { ST_ZERO_FWD, ST_PRE_FWD, ST_SCAN_BLOCKS, ST_BIN_SEGMENTS, ST_BIN_TILES, ST_COUNT_RANK, ST_SCAN, ST_EMIT, ST_SORT, ST_TILE_SCHED, ST_RENDER_FWD,
        ST_ZERO, ST_RENDER_BWD, ST_PRE_BWD, ST_COUNT };
 std::mutex g_prof_mu;
 std::atomic<int> g_profile_every{1};
@@ -287,6 +287,7 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
         { ScopedStage t(ST_BIN_SEGMENTS, st); HIP_TRY(dgr::launch_bin_segments(c.P, geom, bin, tb, gx, gy, ss, capacity, cb, st)); }
         { ScopedStage t(ST_BIN_TILES, st); HIP_TRY(dgr::launch_bin_tiles(c.P, geom, img, bin, tb, gx, gy, ss, capacity, cb, st)); }
         if (!cb) { const int rc = early_status_post(img.status, st); if (rc) return rc; }  // (bin_tiles writes the status word)
+        { ScopedStage t(ST_TILE_SCHED, st); HIP_TRY(dgr::launch_tile_schedule(img, tiles, st)); }
         return DGR_OK;
     }
     const bool fused = mode == COUNT_FUSED;
@@ -295,6 +296,7 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
     if (fused) { const int rc = early_status_post(img.status, st); if (rc) return rc; }
     { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
     { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
+    { ScopedStage t(ST_TILE_SCHED, st); HIP_TRY(dgr::launch_tile_schedule(img, tiles, st)); }
     return DGR_OK;
 }
 
@@ -302,7 +304,7 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
     dgr::RenderFwdLightArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
-    r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background; r.gt_depth = c.gt_depth;
+    r.sched = img.tile_sched; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background; r.gt_depth = c.gt_depth;
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_median = c.out_median_depth; r.out_alpha = c.out_alpha;
     r.out_depth_var = c.out_depth_var; r.n_contrib = img.n_contrib; r.gau_uncertainty = c.gau_uncertainty;
     r.gau_related_pixels = c.gau_related_pixels;
@@ -316,7 +318,7 @@ int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryV
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
     dgr::RenderFwdFullArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
-    r.ranges = img.ranges; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background;
+    r.sched = img.tile_sched; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background;
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_uncertainty = out_uncertainty;
     r.n_contrib = img.n_contrib; r.n_valid = img.n_valid; r.first_contrib = img.first_contrib; r.final_T = img.final_T;
     r.status = img.status;
@@ -600,7 +602,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
 
     dgr::RenderBwdLightArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
-    r.ranges = img.ranges; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
+    r.sched = img.tile_sched; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
     r.gt_depth = gt_depth; r.alphas = alphas; r.n_contrib = img.n_contrib; r.dL_dpix = dL_dpix;
     r.dL_dpix_depth = dL_dpix_depth; r.dL_dpix_median = dL_dpix_median_depth; r.dL_dpix_var = dL_dpix_depth_var;
     r.means3D = means3D; r.view = viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
@@ -737,7 +739,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
 
     dgr::RenderBwdFullArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
-    r.ranges = img.ranges; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
+    r.sched = img.tile_sched; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
     r.gt_depth = gt_depth; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.first_contrib = img.first_contrib;
     r.dL_dpix = dL_dpix; r.dL_depths = dL_depths; r.dL_duncertainties = dL_duncertainties; r.acc = sc.acc;
     { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_full(r, g_alpha_mode.load(), st)); }
@@ -890,7 +892,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
         }
         dgr::RenderBwdLightArgs r{};
         r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
-        r.ranges = img.ranges; r.point_list = (const uint32_t*)w.binning_buffer; r.rec = geom.rec; r.bg = background;
+        r.sched = img.tile_sched; r.point_list = (const uint32_t*)w.binning_buffer; r.rec = geom.rec; r.bg = background;
         r.gt_depth = w.gt_depth; r.alphas = w.alphas; r.n_contrib = img.n_contrib; r.dL_dpix = w.dL_dpix;
         r.dL_dpix_depth = w.dL_dpix_depth; r.dL_dpix_median = w.dL_dpix_median_depth; r.dL_dpix_var = w.dL_dpix_depth_var;
         r.means3D = means3D; r.view = w.viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
@@ -1197,6 +1199,7 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
         return num_rendered;
     }
     if (n == "ranges") return copy(img.ranges, 8 * tiles) ? -1 : (long)(2 * tiles);
+    if (n == "tile_sched") return copy(img.tile_sched, 16 * tiles) ? -1 : (long)(4 * tiles);
     if (n == "n_contrib") return copy(img.n_contrib, 4 * N) ? -1 : (long)N;
     if (n == "n_valid") return copy(img.n_valid, 4 * N) ? -1 : (long)N;
     if (n == "final_T") return copy(img.final_T, 4 * N) ? -1 : (long)N;

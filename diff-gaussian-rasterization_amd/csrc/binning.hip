@@ -252,7 +252,85 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_tiles_kernel(ImageView img,
     for (int i = tid; i < n; i += SORT_THREADS) pl[i] = (uint32_t)sk[i];
 }
 
+// ---- tile schedule ------------------------------------------------------------------------------------------------
+// The blend kernels run one workgroup per tile and a workgroup's time grows with its list.  On a scene whose Gaussians
+// cluster, a static block -> tile map hands whole clusters to a few XCDs and starts the longest lists last: on a frame with
+// lists of 51 .. 1135 entries (mean 222) the XCD-band map of rounds 1-5 took 236 / 445 us (forward / backward blend) where
+// heaviest-first takes 124 / 220 (profiles/r6/tile_order_clustered.txt).  One workgroup orders the tiles by descending list
+// length with a counting sort on 256 buckets (bucket = length >> shift, shift from the longest list) and writes, per
+// workgroup slot b of the blend kernels, {tile, list start, list end}: the blend kernels then need no second lookup.
+// Inside a bucket the order is the arrival order of LDS atomics (only scheduling depends on it).
+constexpr int TS_THREADS = 1024;
+__global__ void __launch_bounds__(TS_THREADS) tile_schedule_kernel(const uint2* __restrict__ ranges, int tiles,
+                                                                    uint4* __restrict__ sched) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t s_max;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 256) hist[tid] = 0u;
+    if (tid == 0) s_max = 0u;
+    __syncthreads();
+    constexpr int KEEP = 8;  // ranges kept in registers between the passes (frames up to 8192 tiles need no second read)
+    uint2 rg[KEEP];
+    uint32_t m = 0u;
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) {
+        const int t = tid + k * TS_THREADS;
+        rg[k] = t < tiles ? ranges[t] : make_uint2(0u, 0u);
+        m = max(m, rg[k].y - rg[k].x);
+    }
+    for (int t = tid + KEEP * TS_THREADS; t < tiles; t += TS_THREADS) { const uint2 r = ranges[t]; m = max(m, r.y - r.x); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if (lane == 0 && m) atomicMax(&s_max, m);
+    __syncthreads();
+    const int shift = max(0, 24 - (int)__clz(s_max | 1u));  // (longest list) >> shift < 256
+#pragma unroll
+    for (int k = 0; k < KEEP; k++)
+        if (tid + k * TS_THREADS < tiles) atomicAdd(&hist[255u - ((rg[k].y - rg[k].x) >> shift)], 1u);
+    for (int t = tid + KEEP * TS_THREADS; t < tiles; t += TS_THREADS) { const uint2 r = ranges[t]; atomicAdd(&hist[255u - ((r.y - r.x) >> shift)], 1u); }
+    __syncthreads();
+    // exclusive scan of the 256 bucket counts (bucket 0 = the longest lists)
+    uint32_t n = 0u, incl = 0u;
+    if (tid < 256) {
+        n = hist[tid];
+        incl = n;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wtot[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t before = 0u;
+        for (int w = 0; w < wave; w++) before += wtot[w];
+        hist[tid] = before + incl - n;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KEEP; k++) {
+        const int t = tid + k * TS_THREADS;
+        if (t < tiles) {
+            const uint32_t pos = atomicAdd(&hist[255u - ((rg[k].y - rg[k].x) >> shift)], 1u);
+            sched[pos] = make_uint4((uint32_t)t, rg[k].x, rg[k].y, 0u);
+        }
+    }
+    for (int t = tid + KEEP * TS_THREADS; t < tiles; t += TS_THREADS) {
+        const uint2 r = ranges[t];
+        const uint32_t pos = atomicAdd(&hist[255u - ((r.y - r.x) >> shift)], 1u);
+        sched[pos] = make_uint4((uint32_t)t, r.x, r.y, 0u);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_tile_schedule(ImageView img, int tiles, hipStream_t stream) {
+    if (tiles <= 0) return hipSuccess;
+    launch(tile_schedule_kernel, dim3(1), dim3(TS_THREADS), stream, (const uint2*)img.ranges, tiles, img.tile_sched);
+    return hipGetLastError();
+}
 
 hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, hipStream_t stream) {
     launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, grid_x, capacity, fused ? 1 : 0);

@@ -68,6 +68,8 @@ struct ImageView {
                           //     [2] = capacity the binning buffer was carved with (scan_tiles)
     uint32_t* tile_count; // [tiles * DGR_COUNT_STRIDE] instances per tile (histogram filled by count_rank), one per line
     uint2* ranges;        // [tiles] {start, end} into point_list
+    uint4* tile_sched;    // [tiles] the blend kernels' schedule: workgroup b works on tile .x, whose list is [.y, .z) --
+                          //     heaviest tile first (tile_schedule_kernel, binning.hip)
     uint32_t* n_contrib;  // [N]
     float* final_T;       // [N]   (full variant)
     uint32_t* n_valid;    // [N]   (full variant) valid contributors of the pixel
@@ -84,6 +86,7 @@ __host__ __device__ inline ImageView carve_image(char* base, int W, int H) {
     v.cursor = (uint32_t*)(base + o + 64);  o = align_up(o + 4 * sizeof(int), 256);
     v.tile_count = (uint32_t*)(base + o); o = align_up(o + tiles * 4 * DGR_COUNT_STRIDE, 256);
     v.ranges = (uint2*)(base + o);        o = align_up(o + tiles * 8, 256);
+    v.tile_sched = (uint4*)(base + o);    o = align_up(o + tiles * 16, 256);
     v.n_contrib = (uint32_t*)(base + o);  o = align_up(o + N * 4, 256);
     v.final_T = (float*)(base + o);       o = align_up(o + N * 4, 256);
     v.n_valid = (uint32_t*)(base + o);    o = align_up(o + N * 4, 256);

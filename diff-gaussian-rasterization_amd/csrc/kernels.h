@@ -156,7 +156,7 @@ struct PreprocessBwdBatchArgs {
 
 struct RenderFwdLightArgs {
     int W, H, grid_x, grid_y;
-    const uint2* ranges;
+    const uint4* sched;    // [tiles] {tile, list start, list end, -} of workgroup b (ImageView::tile_sched)
     uint32_t* point_list;  // read; the kernel writes the contribution tags into the top bits
     const float4* rec;
     const float* bg;
@@ -173,7 +173,7 @@ struct RenderFwdLightArgs {
 
 struct RenderBwdLightArgs {
     int W, H, grid_x, grid_y;
-    const uint2* ranges;
+    const uint4* sched;    // [tiles] {tile, list start, list end, -} of workgroup b (ImageView::tile_sched)
     const uint32_t* point_list;
     const float4* rec;
     const float* bg;
@@ -192,7 +192,7 @@ struct RenderBwdLightArgs {
 
 struct RenderFwdFullArgs {
     int W, H, grid_x, grid_y;
-    const uint2* ranges;
+    const uint4* sched;    // [tiles] {tile, list start, list end, -} of workgroup b (ImageView::tile_sched)
     uint32_t* point_list;  // read; the kernel writes the contribution tags into the top bits
     const float4* rec;
     const float* bg;
@@ -208,7 +208,7 @@ struct RenderFwdFullArgs {
 
 struct RenderBwdFullArgs {
     int W, H, grid_x, grid_y;
-    const uint2* ranges;
+    const uint4* sched;    // [tiles] {tile, list start, list end, -} of workgroup b (ImageView::tile_sched)
     const uint32_t* point_list;
     const float4* rec;
     const float* bg;
@@ -270,6 +270,9 @@ hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, Segmen
 hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
                             int seg_shift, int capacity, bool prefixed, hipStream_t stream);
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);
+// ranges -> the blend kernels' schedule (img.tile_sched): tiles by descending list length, so that the longest lists
+// start first and every XCD gets its share of a cluster
+hipError_t launch_tile_schedule(ImageView img, int tiles, hipStream_t stream);
 
 // alpha_mode: render_common.h (0 = ALPHA_REF, the reference's bits; 1 = ALPHA_FAST)
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, hipStream_t stream);

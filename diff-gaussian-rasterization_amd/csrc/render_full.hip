@@ -34,7 +34,8 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     __shared__ uint32_t hit[DGR_TILE_PIX];  // byte w of word j: quadrant wave w blended staged instance j
     __shared__ int s_nvalid;
     __shared__ uint64_t exptab[32];         // ALPHA_REF: exact_math.h
-    const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
+    const uint4 slot = a.sched[blockIdx.x];  // {tile, list start, list end}: heaviest tile first (binning.hip)
+    const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int px = tx * DGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
 
-    const uint2 range = a.ranges[tile];
+    const uint2 range = make_uint2(slot.y, slot.z);
     const int total = (int)(range.y - range.x);
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, U = 0.f, Dd = 0.f;
@@ -142,7 +143,8 @@ template <int AM>
 __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullArgs a) {
     __shared__ StagedBwdFull sb;
     StagedT<BWD_NB>& s = sb.f;
-    const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
+    const uint4 slot = a.sched[blockIdx.x];  // {tile, list start, list end}: heaviest tile first (binning.hip)
+    const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int px = tx * DGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
     const size_t N = (size_t)a.W * a.H;
     const f2 pxy = {(float)px, (float)py};
 
-    const uint2 range = a.ranges[tile];
+    const uint2 range = make_uint2(slot.y, slot.z);
     const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
     const int first_contributor = inside ? (int)a.first_contrib[pix_id] : 0;
 

@@ -65,7 +65,8 @@ template <int AM>
 __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
     __shared__ StagedFwd sf;
     Staged& s = sf.f;
-    const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
+    const uint4 slot = a.sched[blockIdx.x];  // {tile, list start, list end}: heaviest tile first (binning.hip)
+    const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int px = tx * DGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
     const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
 
-    const uint2 range = a.ranges[tile];
+    const uint2 range = make_uint2(slot.y, slot.z);
     const int total = (int)(range.y - range.x);
 
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, weight = 0.f, Dd = 0.f, D_median = 0.f;
@@ -184,7 +185,8 @@ template <int AM, bool DO_MAP, bool DO_POSE>
 __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
     __shared__ StagedBwd sb;
     StagedT<BWD_NB>& s = sb.f;
-    const int tile = xcd_tile(blockIdx.x, a.grid_x * a.grid_y);
+    const uint4 slot = a.sched[blockIdx.x];  // {tile, list start, list end}: heaviest tile first (binning.hip)
+    const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int px = tx * DGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
@@ -195,7 +197,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     const float pxf = (float)px, pyf = (float)py;
     const f2 pxy = {pxf, pyf};
 
-    const uint2 range = a.ranges[tile];
+    const uint2 range = make_uint2(slot.y, slot.z);
     const int last_contributor = inside ? (int)a.n_contrib[pix_id] : 0;
 
     if (tid == 0) {

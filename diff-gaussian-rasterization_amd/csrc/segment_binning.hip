@@ -47,7 +47,6 @@ constexpr int K2_WAVES = K2_THREADS / 64;
 constexpr int SEG_MAX = SEG_TILES_MAX;      // tiles per segment: 16, 8 or 4 (chosen per call from the expected list lengths)
 constexpr int K2_PPT = 12;                   // pairs a bin_tiles thread holds in registers: 6144 per segment (= K2_CAP; 16 spill)
 constexpr int K2_CAP = 6144;        // keys of one segment held in LDS (48 KB: three workgroups per CU)
-constexpr int K2_LDS_SORT_MAX = 4096;  // per-tile path: workgroup sort in LDS up to here (np2 <= K2_CAP), global above
 constexpr int REG_SORT_MAX = 1024;  // a wave sorts a tile list in registers up to here (16 chunks of 64)
 
 // exclusive (inclusive) scan of a[0..n) in place by the whole workgroup; returns the total.  NT threads, all call it.
@@ -201,13 +200,33 @@ struct K2Shared {
     uint32_t counter;
 };
 
-// every pair of the segment's runs: f(index into the pair array).  One wave per run, four runs in flight (the per-tile
-// path; the fast path fetches through the flat map instead).
+// every pair of the segment: f(coverage byte, index into the pair array).  Flat pair index -> run by a binary search in the
+// runs' prefix (LDS), four pairs per thread with their loads issued together: a segment too dense for the registers is read in
+// n_pairs / 2048 memory round trips.  (Walking the runs one after the other, a wave per run, is one DEPENDENT round trip
+// per run: 31 per wave and pass, ~60 us -- and a dense segment makes several passes.)
 template <typename F>
-__device__ __forceinline__ void for_each_pair(const K2Shared& sh, int nwg, int wave, int lane, F f) {
-    for (int r = wave; r < nwg; r += K2_WAVES) {
-        const uint32_t a = sh.run_a[r], len = sh.run_start[r + 1] - sh.run_start[r];
-        for (uint32_t j = lane; j < len; j += 64) f(a + j);
+__device__ __forceinline__ void for_each_pair(const K2Shared& sh, int nwg, uint32_t n_pairs, const uint8_t* __restrict__ pair_cov,
+                                              int tid, F f) {
+    for (uint32_t i0 = (uint32_t)tid; i0 < n_pairs; i0 += 4u * K2_THREADS) {
+        uint32_t a[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)(u * K2_THREADS);
+            c[u] = 0xffffffffu;
+            a[u] = 0u;
+            if (i < n_pairs) {
+                int lo = 0, hi = nwg;  // the run holding flat index i: the last r with run_start[r] <= i
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sh.run_start[mid] <= i) lo = mid; else hi = mid;
+                }
+                a[u] = sh.run_a[lo] + (i - sh.run_start[lo]);
+                c[u] = pair_cov[a[u]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (c[u] != 0xffffffffu) f(c[u], a[u]);
     }
 }
 
@@ -249,7 +268,13 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     const int SEG = 1 << seg_shift;
     const int sgx = (grid_x + SEG - 1) >> seg_shift;
     const int nseg = grid_y * sgx;
-    const int s = xcd_contiguous(blockIdx.x, nseg);
+    // Workgroups 0 .. nseg-1 take a segment each.  Behind them come SEG / 4 - 1 HELPERS per segment, one per further group of
+    // four tiles: a helper leaves at once unless its segment is DENSE (more keys than LDS or more pairs than the registers
+    // hold), in which case the segment's tiles are shared out four to a workgroup instead of being taken in turn by one --
+    // on a clustered frame the dense segments are few and everything else has long finished (profiles/r6/clustered.txt).
+    const int helpers = (SEG >> 2) - 1;
+    const int part = (int)blockIdx.x < nseg ? 0 : 1 + ((int)blockIdx.x - nseg) % max(helpers, 1);
+    const int s = xcd_contiguous((int)blockIdx.x < nseg ? (int)blockIdx.x : ((int)blockIdx.x - nseg) / max(helpers, 1), nseg);
     const int ty = s / sgx, sx = s - ty * sgx;
     const int ntl = min(SEG, grid_x - sx * SEG);             // tiles of this segment (the last one of a row may be short)
     const int tile0 = ty * grid_x + sx * SEG;
@@ -282,7 +307,7 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     for (int ww = 0; ww < K2_WAVES; ww++) { before += sh.red[0][ww]; upto += sh.red[1][ww]; total += sh.red[2][ww]; flag |= sh.red[3][ww]; }
     const bool overflow = total > (uint32_t)capacity;
     const uint32_t gcount = upto - before;
-    if (s == 0 && tid == 0) {
+    if (s == 0 && part == 0 && tid == 0) {
         img.status[0] = (int)total;
         img.status[1] = overflow ? 1 : 0;
         if (!prefixed) {
@@ -292,16 +317,18 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
         img.cursor[2] = (uint32_t)capacity;
     }
     if (overflow || gcount == 0u) {  // (empty tiles keep {0, 0}: the reference clears the table and writes only tiles that own instances)
-        if (tid < ntl) img.ranges[tile0 + tid] = make_uint2(0u, 0u);
+        if (part == 0 && tid < ntl) img.ranges[tile0 + tid] = make_uint2(0u, 0u);
         return;
     }
     const uint32_t n_pairs = block_scan<K2_THREADS>(sh.run_start, nwg + 1, false, sh.wsum, tid);  // run_start[w] = pairs of the runs < w
     const bool in_regs = n_pairs <= (uint32_t)(K2_PPT * K2_THREADS);
+    const bool dense = !in_regs || gcount > (uint32_t)K2_CAP;
+    if (part > 0 && !dense) return;
 
     // ---- the segment's pairs into registers: flat index -> source map in LDS (one thread per run), then every load at once
     uint64_t pk[K2_PPT];
     uint32_t pc[K2_PPT];
-    if (in_regs) {
+    if (!dense) {
         for (int w = tid; w < nwg; w += K2_THREADS) {
             const uint32_t a = sh.run_a[w], b0 = sh.run_start[w], len = sh.run_start[w + 1] - b0;
             for (uint32_t j = 0; j < len; j++) sh.src[b0 + j] = a + j;
@@ -324,8 +351,7 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
             if (pc[k] != 0xffffffffu)
                 for (uint32_t x = pc[k] & 15u; x <= (pc[k] >> 4); x++) atomicAdd(&sh.tcnt[x], 1u);
     } else {
-        for_each_pair(sh, nwg, wave, lane, [&](uint32_t a) {
-            const uint32_t c = pair_cov[a];
+        for_each_pair(sh, nwg, n_pairs, pair_cov, tid, [&](uint32_t c, uint32_t) {
             for (uint32_t x = c & 15u; x <= (c >> 4); x++) atomicAdd(&sh.tcnt[x], 1u);
         });
     }
@@ -339,63 +365,80 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
             if (lane >= off) incl += v;
         }
         if (lane < SEG_MAX) sh.tbase[lane] = incl - c;
-        if (lane < ntl) img.ranges[tile0 + lane] = c ? make_uint2(before + incl - c, before + incl) : make_uint2(0u, 0u);
+        if (part == 0 && lane < ntl) img.ranges[tile0 + lane] = c ? make_uint2(before + incl - c, before + incl) : make_uint2(0u, 0u);
     }
     __syncthreads();
-    uint32_t tmax = 0;
-#pragma unroll
-    for (int t = 0; t < SEG_MAX; t++) tmax = max(tmax, sh.tcnt[t]);
+    // the lists of tiles [ta, tb_) lie in sh.keys from offset tbase[ta] on: lists a wave sorts in its registers are dealt to
+    // the waves round-robin, longer ones are then taken by the whole workgroup one after the other (tile_sort.h).
+    // WAVE_MAX: 512 -- above that a single wave's 32-bit network needs a four-part rank merge (~40 us of dependent LDS reads
+    // against ~7 for the workgroup) -- or REG_SORT_MAX where such lists are the rule and every wave has one (LONG_LISTS: the
+    // 64-bit register network).
+    constexpr int WAVE_MAX = LONG_LISTS ? REG_SORT_MAX : 512;
+    auto sort_lists = [&](int ta, int tb_) {
+        const uint32_t gb = sh.tbase[ta];
+        int w = 0;
+        bool any_long = false;
+        for (int t = ta; t < tb_; t++) {
+            const int n = (int)sh.tcnt[t];
+            if (n > WAVE_MAX) any_long = true;
+            if (n == 0 || n > WAVE_MAX) continue;
+            if ((w++ % K2_WAVES) == wave) sort_tile_in_wave<LONG_LISTS>(sh.keys + (sh.tbase[t] - gb), n, point_list + before + sh.tbase[t], lane);
+        }
+        if (!any_long) return;
+        for (int t = ta; t < tb_; t++) {
+            const int n = (int)sh.tcnt[t];
+            if (n > WAVE_MAX) wg_sort_parts<K2_THREADS>(sh.keys + (sh.tbase[t] - gb), n, point_list + before + sh.tbase[t], tid);
+        }
+    };
 
-    if (in_regs && gcount <= (uint32_t)K2_CAP && tmax <= (uint32_t)REG_SORT_MAX) {
-        // ---- pass B: the segment's keys into LDS, grouped by tile
+    if (!dense) {
+        // ---- pass B: the segment's keys into LDS, grouped by tile; then the sorts
 #pragma unroll
         for (int k = 0; k < K2_PPT; k++)
             if (pc[k] != 0xffffffffu)
                 for (uint32_t x = pc[k] & 15u; x <= (pc[k] >> 4); x++) sh.keys[sh.tbase[x] + atomicAdd(&sh.tfill[x], 1u)] = pk[k];
         __syncthreads();
-        // ---- every wave sorts whole tile lists in its registers and writes the ids
-        for (int t = wave; t < ntl; t += K2_WAVES) {
-            const int n = (int)sh.tcnt[t];
-            if (n > 0) sort_tile_in_wave<LONG_LISTS>(sh.keys + sh.tbase[t], n, point_list + before + sh.tbase[t], lane);
-        }
+        sort_lists(0, ntl);
         return;
     }
-    // ---- per-tile path (a list above REG_SORT_MAX entries, more keys in the segment than LDS holds, or more pairs than the
-    // registers hold): one tile at a time, the pairs re-read from the pair array
-    for (int t = 0; t < ntl; t++) {
-        const int n = (int)sh.tcnt[t];
-        if (n == 0) continue;
-        uint64_t* gk = key_scratch + before + sh.tbase[t];
-        uint32_t* pl = point_list + before + sh.tbase[t];
-        const bool in_lds = n <= K2_LDS_SORT_MAX;
-        if (tid == 0) sh.counter = 0u;
-        __syncthreads();
-        if (in_regs) {  // (the pairs are still in registers: a long tile list, or more keys than LDS holds, not more pairs)
-#pragma unroll
-            for (int k = 0; k < K2_PPT; k++)
-                if (pc[k] != 0xffffffffu && (pc[k] & 15u) <= (uint32_t)t && (uint32_t)t <= (pc[k] >> 4)) {
-                    const uint32_t pos = atomicAdd(&sh.counter, 1u);
-                    if (in_lds) sh.keys[pos] = pk[k]; else gk[pos] = pk[k];
-                }
-        } else {
-            for_each_pair(sh, nwg, wave, lane, [&](uint32_t a) {
-                const uint32_t c = pair_cov[a];
-                if ((c & 15u) <= (uint32_t)t && (uint32_t)t <= (c >> 4)) {
-                    const uint32_t pos = atomicAdd(&sh.counter, 1u);
-                    const uint64_t key = pair_keys[a];
-                    if (in_lds) sh.keys[pos] = key; else gk[pos] = key;
-                }
+    // ---- dense segment: this workgroup's four tiles (the whole segment where it has no helpers), in consecutive GROUPS
+    // whose keys fit LDS together.  Per group ONE pass over the pairs (re-read from the pair array: held in registers across
+    // the sorts they would spill) places the keys; a single list above K2_CAP entries is sorted in place in the `keys`
+    // scratch array.  (Round 5 took every tile of such a segment on its own, in one workgroup -- a pass over the pairs, run by
+    // run, and a padded workgroup network each: 473-514 us for the kernel on a clustered frame.)
+    const int tq0 = helpers > 0 ? part * 4 : 0, tq1 = helpers > 0 ? min(ntl, tq0 + 4) : ntl;
+    for (int t0 = tq0; t0 < tq1;) {
+        const int n0 = (int)sh.tcnt[t0];
+        if (n0 == 0) { t0++; continue; }
+        __syncthreads();  // the previous group's sorts have read sh.keys
+        if (n0 > K2_CAP) {
+            uint64_t* gk = key_scratch + before + sh.tbase[t0];
+            uint32_t* pl = point_list + before + sh.tbase[t0];
+            if (tid == 0) sh.counter = 0u;
+            __syncthreads();
+            for_each_pair(sh, nwg, n_pairs, pair_cov, tid, [&](uint32_t c, uint32_t a) {
+                if ((c & 15u) <= (uint32_t)t0 && (uint32_t)t0 <= (c >> 4)) gk[atomicAdd(&sh.counter, 1u)] = pair_keys[a];
             });
+            __syncthreads();
+            wg_sort_global<K2_THREADS>(gk, n0, tid);
+            for (int i = tid; i < n0; i += K2_THREADS) pl[i] = (uint32_t)gk[i];
+            t0++;
+            continue;
         }
+        int t1 = t0;
+        uint32_t sum = 0;
+        while (t1 < tq1 && sum + sh.tcnt[t1] <= (uint32_t)K2_CAP) sum += sh.tcnt[t1++];
+        const uint32_t gb = sh.tbase[t0];
+        for_each_pair(sh, nwg, n_pairs, pair_cov, tid, [&](uint32_t c, uint32_t a) {
+            if ((c & 15u) < (uint32_t)t1 && (uint32_t)t0 <= (c >> 4)) {
+                const uint32_t xa = max((uint32_t)t0, c & 15u), xb = min((uint32_t)t1 - 1u, c >> 4);
+                const uint64_t key = pair_keys[a];
+                for (uint32_t x = xa; x <= xb; x++) sh.keys[sh.tbase[x] - gb + atomicAdd(&sh.tfill[x], 1u)] = key;
+            }
+        });
         __syncthreads();
-        if (in_lds) {
-            wg_sort_lds<K2_THREADS>(sh.keys, n, tid);
-            for (int i = tid; i < n; i += K2_THREADS) pl[i] = (uint32_t)sh.keys[i];
-        } else {
-            wg_sort_global<K2_THREADS>(gk, n, tid);
-            for (int i = tid; i < n; i += K2_THREADS) pl[i] = (uint32_t)gk[i];
-        }
-        __syncthreads();
+        sort_lists(t0, t1);
+        t0 = t1;
     }
 }
 
@@ -462,7 +505,8 @@ hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView
     // expected entries per tile, from the capacity the caller sized the binning buffer with (segment_shift() uses the same)
     const long tiles = (long)grid_x * grid_y;
     const bool long_lists = tiles > 0 && (long)capacity / tiles > 900;
-    launch(long_lists ? bin_tiles_kernel<true> : bin_tiles_kernel<false>, dim3(nseg), dim3(K2_THREADS), stream, img, bin.point_list, bin.keys, tb, bin.pair_keys, bin.pair_cov,
+    const int helpers = (1 << seg_shift) / 4 - 1;  // per segment (bin_tiles_kernel)
+    launch(long_lists ? bin_tiles_kernel<true> : bin_tiles_kernel<false>, dim3(nseg * (1 + helpers)), dim3(K2_THREADS), stream, img, bin.point_list, bin.keys, tb, bin.pair_keys, bin.pair_cov,
            geom.block_tiles, (P + 255) / 256, segment_binning_workgroups(P), grid_x, grid_y, seg_shift, capacity, prefixed ? 1 : 0);
     return hipGetLastError();
 }

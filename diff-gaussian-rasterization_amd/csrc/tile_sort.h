@@ -205,6 +205,34 @@ __device__ __forceinline__ void sort_wave_trunc_1024(uint64_t* list, int n, uint
     }
 }
 
+// A list above the one-wave limit, whole workgroup of NT threads, n keys in LDS (no padding needed): parts of 512 sorted in
+// place by one wave each (all of them at once), then merged by rank with every thread searching.  1135 entries: ~7 us where the
+// bitonic workgroup network below (padded to 2048: 66 barrier steps) takes ~25; a dense segment runs sixteen of these in a row.
+template <int NT>
+__device__ __forceinline__ void wg_sort_parts(uint64_t* list, int n, uint32_t* __restrict__ dst_ids, int tid) {
+    constexpr int Q = 512;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int parts = (n + Q - 1) / Q;
+    for (int p = wave; p < parts; p += NT / 64) sort_wave_trunc<Q / 64, false>(list + p * Q, min(Q, n - p * Q), nullptr, lane);
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const uint64_t k = list[i];
+        const int mine = i / Q;
+        int pos = i - mine * Q;
+        for (int p = 0; p < parts; p++) {
+            if (p == mine) continue;
+            const uint64_t* other = list + p * Q;
+            int lo = 0, hi = min(Q, n - p * Q);  // lower bound of k in part p (keys are unique)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (other[mid] < k) lo = mid + 1; else hi = mid;
+            }
+            pos += lo;
+        }
+        dst_ids[pos] = (uint32_t)k;
+    }
+}
+
 // ---- the full 64-bit keys in registers: lists of 513 .. 1024 entries where they are the rule (bin_tiles<LONG_LISTS>) --------------
 // (the 32-bit form would hold 16 words + 16 keys per lane around its key fetch, and the four-part merge above is a chain of
 //  dependent LDS reads: 159 against 116 us at config 4's 810 entries per tile)
@@ -248,48 +276,6 @@ __device__ __forceinline__ void sort_wave_regs(const uint64_t* __restrict__ src,
 }
 
 // ---- a tile list sorted by a whole workgroup of NT threads -----------------------------------------------------------------
-// in LDS (n <= the array's size; np2 = n rounded up to a power of two >= 64 must fit too), all-ascending network
-template <int NT>
-__device__ __forceinline__ void wg_sort_lds(uint64_t* sk, int n, int tid) {
-    const int lane = tid & 63, wave = tid >> 6;
-    int np2 = 64;
-    while (np2 < n) np2 <<= 1;
-    const int chunks = np2 >> 6;
-    for (int e = n + tid; e < np2; e += NT) sk[e] = KEY_INF;
-    __syncthreads();
-    for (int c = wave; c < chunks; c += NT / 64) {
-        const int e = c * 64 + lane;
-        sk[e] = chunk_sort64(sk[e], lane);
-    }
-    __syncthreads();
-    const int half = np2 >> 1;
-    for (int size = 128; size <= np2; size <<= 1) {
-        {   // flip across the `size` block: pairs i <-> blk * size + size - 1 - off span all distances (LDS array)
-            const int hs = size >> 1;
-            for (int t = tid; t < half; t += NT) {
-                const int blk = t / hs, off = t - blk * hs;
-                const int i = blk * size + off, j = blk * size + (size - 1 - off);
-                const uint64_t x = sk[i], y = sk[j];
-                if (x > y) { sk[i] = y; sk[j] = x; }
-            }
-            __syncthreads();
-        }
-        for (int d = size >> 2; d >= 64; d >>= 1) {
-            for (int t = tid; t < half; t += NT) {
-                const int blk = t / d, off = t - blk * d;
-                const int i = blk * 2 * d + off, j = i + d;
-                const uint64_t x = sk[i], y = sk[j];
-                if (x > y) { sk[i] = y; sk[j] = x; }
-            }
-            __syncthreads();
-        }
-        for (int c = wave; c < chunks; c += NT / 64) {
-            const int e = c * 64 + lane;
-            sk[e] = chunk_tail64(sk[e], lane);
-        }
-        __syncthreads();
-    }
-}
 // in place in global memory (any n), one barrier per step
 template <int NT>
 __device__ __forceinline__ void wg_sort_global(uint64_t* gk, int n, int tid) {

@@ -86,5 +86,18 @@ def make_scene(P, W, H, seed=0, view_index=0):
                  opac, shs, gt, bg, gC, gD, gM, gV)
 
 
+def cluster_scene(s: Scene, frac=0.6, shrink=0.35, shift=(0.5, 0.3), seed=1) -> Scene:
+    """A non-uniform variant of a synth-v1 scene (not a BASELINE configuration): `frac` of the Gaussians are pulled towards
+    one region of the frame (their x, y scaled by `shrink` about the group's centroid and moved by `shift`), so that tile
+    lists range from a few dozen to over a thousand entries at config 3's size (mean 222, max 1135) instead of 203 +- 20 %.
+    Used by the schedule tests and by `bench.py --scene clustered`."""
+    rng = np.random.default_rng(seed)
+    pick = rng.random(s.P) < frac
+    m = s.means.copy()
+    c = m[pick].mean(axis=0)
+    m[pick, :2] = c[:2] + shrink * (m[pick, :2] - c[:2]) + np.asarray(shift, np.float32)
+    return s._replace(means=m.astype(np.float32))
+
+
 def sha16(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]

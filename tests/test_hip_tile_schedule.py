@@ -1,0 +1,81 @@
+"""The blend kernels' tile schedule (csrc/binning.hip: tile_schedule_kernel) and parity on a NON-UNIFORM scene.
+
+synth-v1 spreads the Gaussians evenly (tile lists of 203 +- 20 % at config 3); a mapped room does not.  The schedule hands
+the blend kernels their tiles heaviest first; it changes nothing but the order in which tiles are worked on, so every
+parity bar of the uniform scenes must hold on a clustered one too (dgr_amd.synth.cluster_scene: lists from a few dozen to
+over a thousand entries), and the table itself must be a permutation of the tiles, carry each tile's own range and be
+ordered by descending list length at the granularity of its 256 buckets.
+"""
+import numpy as np
+import pytest
+
+from dgr_amd.synth import cluster_scene
+from util import make_scene
+import hip_helpers as hh
+from test_hip_light_parity import assert_images_carry_the_references_bits, check_backward
+
+pytestmark = pytest.mark.gpu
+
+
+def check_schedule(s, d):
+    tiles = ((s.W + 15) // 16) * ((s.H + 15) // 16)
+    rg = hh.hip_state("ranges", s, d).reshape(tiles, 2).astype(np.int64)
+    sc = hh.hip_state("tile_sched", s, d).reshape(tiles, 4).astype(np.int64)
+    assert np.array_equal(np.sort(sc[:, 0]), np.arange(tiles)), "not a permutation of the tiles"
+    assert np.array_equal(sc[:, 1:3], rg[sc[:, 0]]), "a slot does not carry its tile's range"
+    n = sc[:, 2] - sc[:, 1]
+    longest = int(n.max())
+    shift = max(0, longest.bit_length() - 8)
+    b = n >> shift
+    assert np.all(b[:-1] >= b[1:]), "slots are not ordered by descending list length (bucket granularity)"
+    return n
+
+
+@pytest.mark.parametrize("case", [(2000, 64, 48, 0, 1), (2000, 70, 45, 3, 2), (100000, 640, 480, 3, 0), (500000, 1920, 1080, 3, 0)])
+@pytest.mark.parametrize("clustered", [False, True])
+def test_schedule_is_a_heaviest_first_permutation(case, clustered):
+    P, W, H, deg, seed = case
+    s = make_scene(P, W, H, seed)
+    if clustered:
+        s = cluster_scene(s)
+    _, d = hh.hip_forward(s, deg)
+    n = check_schedule(s, d)
+    if clustered and P >= 100000:
+        assert n.max() > 3 * max(1.0, n.mean()), "the clustered scene is supposed to have long lists"
+
+
+def test_schedule_of_a_frame_with_more_tiles_than_the_kernel_keeps_in_registers():
+    """3840x2160 has 32 400 tiles: the schedule kernel's second half (tiles beyond 8 per thread) re-reads the ranges."""
+    s = make_scene(50000, 3840, 2160, 3)
+    _, d = hh.hip_forward(s, 1)
+    check_schedule(s, d)
+
+
+def test_schedule_of_an_empty_frame():
+    """No visible Gaussian: every list is empty, the schedule is still a permutation and the blend writes the background."""
+    s = make_scene(500, 100, 60, 4)
+    s = s._replace(means=(s.means * np.float32(0) + np.array([0, 0, -5], np.float32)))  # behind the camera
+    _, d = hh.hip_forward(s, 0)
+    assert d["num_rendered"] == 0
+    check_schedule(s, d)
+    assert np.allclose(d["color"], np.asarray(s.bg)[:, None, None])
+
+
+@pytest.mark.parametrize("case", [(10000, 256, 256, 3, 0), (100000, 640, 480, 3, 0), (500000, 1920, 1080, 3, 0)])
+def test_clustered_scene_forward_against_the_oracle(oracle, case):
+    P, W, H, deg, seed = case
+    s = cluster_scene(make_scene(P, W, H, seed))
+    _, d = hh.hip_forward(s, deg)
+    st, ref = hh.oracle_forward(oracle, s, deg)
+    assert d["num_rendered"] == ref["num_rendered"] and np.array_equal(d["radii"], ref["radii"])
+    assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    assert_images_carry_the_references_bits(d, st, ref, s)
+
+
+@pytest.mark.parametrize("case", [(10000, 256, 256, 3, 0), (100000, 640, 480, 3, 0)])
+@pytest.mark.parametrize("mode", [(False, False), (False, True)])
+def test_clustered_scene_backward_against_the_oracle(oracle, case, mode):
+    P, W, H, deg, seed = case
+    s = cluster_scene(make_scene(P, W, H, seed))
+    check_backward(oracle, s, deg, track_off=mode[0], map_off=mode[1])
