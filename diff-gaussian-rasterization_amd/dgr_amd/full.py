@@ -92,7 +92,7 @@ class _C:
             if _light._sync_mode() == "lazy" and cap > 0:
                 # no host synchronisation (dgr_amd/light.py): the status word is checked one call late; the tuple's
                 # num_rendered / num_related members are the latest values read back for this shape
-                while len(_light._pending_status) > 1 and not torch.cuda.is_current_stream_capturing():
+                while len(_light._pending_status) > _light.lazy_depth() and not torch.cuda.is_current_stream_capturing():
                     _light._check_oldest()
                 cap = int(cap * 1.5) + 4096
                 binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)
@@ -178,7 +178,7 @@ class _CompiledC:
         if os.environ.get("DGR_FORWARD_MODE", "presized") == "callback" or P == 0:
             mode, use = 0, 0
         elif _light._sync_mode() == "lazy" and cap > 0:
-            while len(_light._pending_status) > 1 and not torch.cuda.is_current_stream_capturing():
+            while len(_light._pending_status) > _light.lazy_depth() and not torch.cuda.is_current_stream_capturing():
                 _light._check_oldest()
             mode, use = 2, int(cap * 1.5) + 4096
         else:

@@ -50,6 +50,23 @@ _capacity_cache = {}
 # `prefiltered` violation therefore raises one or two calls late.  Default ("strict"): one status read at the end of
 # every forward, like the reference's blocking copy of num_rendered (L/cuda_rasterizer/rasterizer_impl.cu:287).
 _pending_status = []   # [(ticket of dgr_status_post, key)]
+# Status words left unread when a forward is issued.  1: view i is issued once view i-2's forward has reported -- with several
+# views in flight on several streams (dgr_amd.multiview.ViewStreams) that starves a stream whose previous view has finished
+# while the view whose report the host waits for is still in its blend kernels; ViewStreams raises it to its number of streams
+# (three views in flight, config 3: 0.483 -> 0.473 ms per step over 20 steps, 0.434 -> 0.428 over 100: profiles/r6/lazy_depth.txt).
+# The price: an overflow or a `prefiltered` violation is reported up to depth + 1 calls late instead of two.
+_LAZY_DEPTH = max(1, int(os.environ.get("DGR_LAZY_DEPTH", "1")))
+
+
+def lazy_depth():
+    return _LAZY_DEPTH
+
+
+def set_lazy_depth(n):
+    """See _LAZY_DEPTH above; returns the previous value."""
+    global _LAZY_DEPTH
+    prev, _LAZY_DEPTH = _LAZY_DEPTH, max(1, int(n))
+    return prev
 _last_status = {}      # key -> the most recent status word read back for that shape
 
 
@@ -266,7 +283,7 @@ class _C:
             lazy = _sync_mode() == "lazy" and cap > 0
             if lazy:
                 # status words of earlier calls have long completed: reading them does not stall the pipeline
-                while len(_pending_status) > 1 and not torch.cuda.is_current_stream_capturing():
+                while len(_pending_status) > _LAZY_DEPTH and not torch.cuda.is_current_stream_capturing():
                     _check_oldest()
                 cap = int(cap * 1.5) + 4096
                 binningBuffer = torch.empty((lib.dgr_binning_bytes(cap, W, H),), **u8)
@@ -375,7 +392,7 @@ class _CompiledC:
         if os.environ.get("DGR_FORWARD_MODE", "presized") == "callback" or P == 0:
             mode, use = 0, 0
         elif _sync_mode() == "lazy" and cap > 0:
-            while len(_pending_status) > 1 and not torch.cuda.is_current_stream_capturing():
+            while len(_pending_status) > _LAZY_DEPTH and not torch.cuda.is_current_stream_capturing():
                 _check_oldest()  # status words of earlier calls have long completed: no stall
             mode, use = 2, int(cap * 1.5) + 4096
         else:

@@ -111,6 +111,8 @@ class ViewStreams:
     def __init__(self, n=3, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(n)))]
+        # lazy status mode: let the host run as many forward passes ahead of the status words as there are streams (light.py)
+        light.set_lazy_depth(max(light.lazy_depth(), len(self.streams)))
         self._i = 0
         self._fresh = set()  # streams already ordered after the caller's stream since the last join()
         self._done = None    # event at the end of the most recent view
