@@ -48,14 +48,6 @@ __device__ __forceinline__ float t_div(float T, float om, float& inv) {
     return div_ref(T, om, inv);
 }
 
-// bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of tiles
-__device__ __forceinline__ int xcd_tile(int b, int n) {
-    const int xcd = b & 7, local = b >> 3;
-    const int q = n >> 3, r = n & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + local;
-}
-
 // NB = instances staged per batch (<= 256, one per thread).  The forward uses 256; the light backward 128, which
 // halves its LDS footprint (it is occupancy-bound: see DESIGN.md s4.2).
 template <int NB>

@@ -20,8 +20,9 @@
 //    A skipped (pixel, Gaussian) pair is one the per-pixel test `power > 0 || alpha < 15/255` would have
 //    rejected, so outputs are unchanged; `contributor` (hence n_contrib) is the position in the tile list,
 //    which skipping does not alter.
-//  * XCD-aware block->tile map: block b runs on XCD b%8, so each XCD is handed a contiguous band of
-//    tiles and neighbouring tiles share Gaussian records / accumulator rows in one L2.
+//  * block -> tile through the tile schedule (ImageView::tile_sched, binning.hip): longest list first, consecutive workgroups
+//    going round the XCDs.  (Rounds 1-5 handed every XCD a contiguous band of tiles for L2 reuse between neighbours: no
+//    measurable gain, and a factor of two lost on a frame whose Gaussians cluster -- DESIGN.md s4.8.)
 //
 // alpha: template parameter AM (render_common.h).  ALPHA_REF, the default, evaluates the reference's expression with the
 // host library's bits (exact_math.h): the alpha image, n_contrib and the median depth then equal the CPU restatement's bit

@@ -377,27 +377,45 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     auto sort_lists = [&](int ta, int tb_) {
         const uint32_t gb = sh.tbase[ta];
         int w = 0;
-        bool any_long = false;
+        int parts_seen = 0;  // the parts of the longer lists are dealt to the waves as well ...
         for (int t = ta; t < tb_; t++) {
             const int n = (int)sh.tcnt[t];
-            if (n > WAVE_MAX) any_long = true;
-            if (n == 0 || n > WAVE_MAX) continue;
-            if ((w++ % K2_WAVES) == wave) sort_tile_in_wave<LONG_LISTS>(sh.keys + (sh.tbase[t] - gb), n, point_list + before + sh.tbase[t], lane);
+            if (n == 0) continue;
+            uint64_t* list = sh.keys + (sh.tbase[t] - gb);
+            if (n <= WAVE_MAX) {
+                if ((w++ % K2_WAVES) == wave) sort_tile_in_wave<LONG_LISTS>(list, n, point_list + before + sh.tbase[t], lane);
+            } else {
+                for (int p = 0; p < list_parts(n); p++)
+                    if ((w++ % K2_WAVES) == wave) sort_list_part(list, n, p, lane);
+                parts_seen++;
+            }
         }
-        if (!any_long) return;
+        if (parts_seen == 0) return;
+        __syncthreads();  // ... and every thread then helps merging them, list after list
         for (int t = ta; t < tb_; t++) {
             const int n = (int)sh.tcnt[t];
-            if (n > WAVE_MAX) wg_sort_parts<K2_THREADS>(sh.keys + (sh.tbase[t] - gb), n, point_list + before + sh.tbase[t], tid);
+            if (n > WAVE_MAX) merge_list_parts<K2_THREADS>(sh.keys + (sh.tbase[t] - gb), n, point_list + before + sh.tbase[t], tid);
         }
     };
 
+    uint32_t tmax = 0;
+#pragma unroll
+    for (int t = 0; t < SEG_MAX; t++) tmax = max(tmax, sh.tcnt[t]);
     if (!dense) {
-        // ---- pass B: the segment's keys into LDS, grouped by tile; then the sorts
+        // ---- pass B: the segment's keys into LDS, grouped by tile
 #pragma unroll
         for (int k = 0; k < K2_PPT; k++)
             if (pc[k] != 0xffffffffu)
                 for (uint32_t x = pc[k] & 15u; x <= (pc[k] >> 4); x++) sh.keys[sh.tbase[x] + atomicAdd(&sh.tfill[x], 1u)] = pk[k];
         __syncthreads();
+        if (tmax <= (uint32_t)WAVE_MAX) {
+            // ---- the rule: every wave sorts whole tile lists in its registers and writes the ids
+            for (int t = wave; t < ntl; t += K2_WAVES) {
+                const int n = (int)sh.tcnt[t];
+                if (n > 0) sort_tile_in_wave<LONG_LISTS>(sh.keys + sh.tbase[t], n, point_list + before + sh.tbase[t], lane);
+            }
+            return;
+        }
         sort_lists(0, ntl);
         return;
     }

@@ -205,24 +205,26 @@ __device__ __forceinline__ void sort_wave_trunc_1024(uint64_t* list, int n, uint
     }
 }
 
-// A list above the one-wave limit, whole workgroup of NT threads, n keys in LDS (no padding needed): parts of 512 sorted in
-// place by one wave each (all of them at once), then merged by rank with every thread searching.  1135 entries: ~7 us where the
-// bitonic workgroup network below (padded to 2048: 66 barrier steps) takes ~25; a dense segment runs sixteen of these in a row.
+// Lists above the one-wave limit, whole workgroup of NT threads, keys in LDS (no padding needed): parts of PART_Q entries are
+// sorted in place by one wave each (sort_list_part; the caller deals the parts of ALL its long lists to its waves at once),
+// then, behind a barrier, every list is merged by rank with every thread searching (merge_list_parts).  1135 entries: ~7 us
+// where a bitonic workgroup network (padded to 2048: 66 barrier steps) took ~25.
+constexpr int PART_Q = 512;
+__device__ __forceinline__ int list_parts(int n) { return (n + PART_Q - 1) / PART_Q; }
+__device__ __forceinline__ void sort_list_part(uint64_t* list, int n, int p, int lane) {
+    sort_wave_trunc<PART_Q / 64, false>(list + p * PART_Q, min(PART_Q, n - p * PART_Q), nullptr, lane);
+}
 template <int NT>
-__device__ __forceinline__ void wg_sort_parts(uint64_t* list, int n, uint32_t* __restrict__ dst_ids, int tid) {
-    constexpr int Q = 512;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int parts = (n + Q - 1) / Q;
-    for (int p = wave; p < parts; p += NT / 64) sort_wave_trunc<Q / 64, false>(list + p * Q, min(Q, n - p * Q), nullptr, lane);
-    __syncthreads();
+__device__ __forceinline__ void merge_list_parts(const uint64_t* list, int n, uint32_t* __restrict__ dst_ids, int tid) {
+    const int parts = list_parts(n);
     for (int i = tid; i < n; i += NT) {
         const uint64_t k = list[i];
-        const int mine = i / Q;
-        int pos = i - mine * Q;
+        const int mine = i / PART_Q;
+        int pos = i - mine * PART_Q;
         for (int p = 0; p < parts; p++) {
             if (p == mine) continue;
-            const uint64_t* other = list + p * Q;
-            int lo = 0, hi = min(Q, n - p * Q);  // lower bound of k in part p (keys are unique)
+            const uint64_t* other = list + p * PART_Q;
+            int lo = 0, hi = min(PART_Q, n - p * PART_Q);  // lower bound of k in part p (keys are unique)
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
                 if (other[mid] < k) lo = mid + 1; else hi = mid;
