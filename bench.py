@@ -67,6 +67,7 @@ def algorithmic_bytes(stage, P, V, R, N, M):
         "sort_tiles": 24 * R,                                # one read + one write of the 12-byte pairs
         "scan_tiles": 8 * R,                                 # range detection
         "render_fwd": 44 * R + 36 * N,                       # id, xy, conic+opacity, rgb, depth per instance; gt in, images + n_contrib out
+        "tile_schedule": 0,                                  # (no counterpart: the reference's block -> tile map is its launch grid)
         "zero_scratch": 0,                                   # (no counterpart in the ideal model)
         "zero_counters": 0,                                  # (likewise: the padded tile counters of the fused count)
         "render_bwd": 44 * R + 40 * R + 36 * N,              # instance data again + 10 gradient floats RMW per instance; 9 images in

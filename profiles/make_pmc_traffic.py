@@ -13,7 +13,7 @@ import sys
 STAGE = {"count_rank_kernel": "count_rank", "emit_instances_kernel": "emit_instances", "preprocess_bwd_kernel": "preprocess_bwd",
          "preprocess_fwd_kernel": "preprocess_fwd", "render_bwd_light_kernel": "render_bwd", "render_fwd_light_kernel": "render_fwd",
          "scan_blocks_kernel": "scan_blocks", "scan_tiles_kernel": "scan_tiles", "sort_tiles_kernel": "sort_tiles",
-         "zero_fill_kernel": "zero_scratch", "bin_segments_kernel": "bin_segments", "bin_tiles_kernel": "bin_tiles"}
+         "zero_fill_kernel": "zero_scratch", "bin_segments_kernel": "bin_segments", "bin_tiles_kernel": "bin_tiles", "tile_schedule_kernel": "tile_schedule"}
 src, commit = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "unknown")
 vals = {}
 for line in open(src):

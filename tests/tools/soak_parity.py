@@ -27,6 +27,10 @@ def draw_scene(i):
     H = int(rng.choice([5, 16, 47, 64, 97, 200, 300, 611]))
     P = int(rng.integers(1, 30000)) if rng.random() < 0.9 else int(rng.integers(30000, 200000))
     s = make_scene(P, W, H, 1000 + i)
+    if rng.random() < 0.4:  # round 6: non-uniform scenes (dense segments, helper workgroups, long-list merges, the tile schedule)
+        from dgr_amd.synth import cluster_scene
+        s = cluster_scene(s, frac=float(rng.uniform(0.3, 0.95)), shrink=float(rng.uniform(0.02, 0.5)),
+                          shift=(float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.3, 0.3))), seed=2000 + i)
     mode = rng.choice(["as drawn", "translucent", "opaque"])
     if mode == "translucent":
         s = s._replace(opac=(s.opac * 0.12).astype(np.float32))
