@@ -7,4 +7,4 @@ for seed in 21 22; do
 done
 DGR_LDS_COUNT=0 timeout 1200 python tests/tools/soak_parity.py 100 30 23 2>&1 | grep -v amdgpu.ids | tail -6 > gpurun_out/r6_soak/soak_global_counters_seed23.txt
 timeout 1500 python tests/tools/soak_batch.py 200 27 2>&1 | grep -v amdgpu.ids | tail -6 > gpurun_out/r6_soak/soak_batch_seed27.txt
-tail -5 gpurun_out/r6_soak/*.txt
+for f in gpurun_out/r6_soak/*.txt; do echo "== $f"; tail -n 5 $f; done
