@@ -368,11 +368,13 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
         if (part == 0 && lane < ntl) img.ranges[tile0 + lane] = c ? make_uint2(before + incl - c, before + incl) : make_uint2(0u, 0u);
     }
     __syncthreads();
-    // the lists of tiles [ta, tb_) lie in sh.keys from offset tbase[ta] on: lists a wave sorts in its registers are dealt to
-    // the waves round-robin, longer ones are then taken by the whole workgroup one after the other (tile_sort.h).
-    // WAVE_MAX: 512 -- above that a single wave's 32-bit network needs a four-part rank merge (~40 us of dependent LDS reads
-    // against ~7 for the workgroup) -- or REG_SORT_MAX where such lists are the rule and every wave has one (LONG_LISTS: the
-    // 64-bit register network).
+    // General sorter (dense segments, and segments with a list above REG_SORT_MAX): the lists of tiles [ta, tb_) lie in sh.keys
+    // from offset tbase[ta] on.  Lists up to WAVE_MAX entries are dealt to the waves round-robin (tile_sort.h: one wave's
+    // registers); longer ones are cut into parts of 512, the parts dealt to the waves as well, and every list is then merged
+    // by rank with all threads searching.  WAVE_MAX is 512 here although a wave can take 1024: a workgroup that comes here has
+    // four to six lists for its eight waves, and a single wave's 32-bit network needs a four-part rank merge above 512 entries
+    // (~40 us of dependent LDS reads against ~7 for the workgroup).  Where every wave has a list of its own -- the rule below,
+    // e.g. config 5's 510 +- 20 % entries per tile -- the waves keep whole lists up to REG_SORT_MAX.
     constexpr int WAVE_MAX = LONG_LISTS ? REG_SORT_MAX : 512;
     auto sort_lists = [&](int ta, int tb_) {
         const uint32_t gb = sh.tbase[ta];
@@ -408,7 +410,7 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
             if (pc[k] != 0xffffffffu)
                 for (uint32_t x = pc[k] & 15u; x <= (pc[k] >> 4); x++) sh.keys[sh.tbase[x] + atomicAdd(&sh.tfill[x], 1u)] = pk[k];
         __syncthreads();
-        if (tmax <= (uint32_t)WAVE_MAX) {
+        if (tmax <= (uint32_t)REG_SORT_MAX) {
             // ---- the rule: every wave sorts whole tile lists in its registers and writes the ids
             for (int t = wave; t < ntl; t += K2_WAVES) {
                 const int n = (int)sh.tcnt[t];

@@ -79,3 +79,28 @@ def test_clustered_scene_backward_against_the_oracle(oracle, case, mode):
     P, W, H, deg, seed = case
     s = cluster_scene(make_scene(P, W, H, seed))
     check_backward(oracle, s, deg, track_off=mode[0], map_off=mode[1])
+
+
+@pytest.mark.parametrize("case", [(10000, 256, 256, 0, 0), (100000, 640, 480, 3, 0)])
+def test_clustered_scene_full_variant_against_the_oracle(oracle, case):
+    """The -full variant on a non-uniform frame (its blend kernels walk the same tile schedule): the bars of
+    tests/test_hip_full_parity.py."""
+    from util import assert_grad_close
+    P, W, H, deg, seed = case
+    s = cluster_scene(make_scene(P, W, H, seed))
+    grads = tuple(g * (W * H) ** 0.5 for g in (s.gC, s.gD, s.gV))
+    out, d = hh.hip_full_forward(s, deg)
+    g = hh.hip_full_backward(s, deg, out, grads=grads)
+    st, ref, gr = hh.oracle_full(oracle, s, deg, grads=grads)
+    assert np.array_equal(d["radii"], ref["radii"]) and d["num_rendered"] == ref["num_rendered"]
+    assert d["num_related"] == ref["num_related"]
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    assert np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
+    assert np.array_equal(d["uncertainty"], ref["uncertainty"])
+    for k in ("color", "depth"):
+        a, b = d[k].astype(np.float64), ref[k].astype(np.float64)
+        assert np.all(np.abs(a - b) <= 1e-6 * np.maximum(1.0, np.abs(b))), k
+    tol = dict(rel_to_max=1e-5, elem_rtol=2e-3, elem_frac=1e-3)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
+        assert_grad_close(g[k], gr[k], k, **tol)
+    assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=5e-5, elem_rtol=5e-3, elem_frac=0.1)
