@@ -256,71 +256,116 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_tiles_kernel(ImageView img,
 // The blend kernels run one workgroup per tile and a workgroup's time grows with its list.  On a scene whose Gaussians
 // cluster, a static block -> tile map hands whole clusters to a few XCDs and starts the longest lists last: on a frame with
 // lists of 51 .. 1135 entries (mean 222) the XCD-band map of rounds 1-5 took 236 / 445 us (forward / backward blend) where
-// heaviest-first takes 124 / 220 (profiles/r6/tile_order_clustered.txt).  One workgroup orders the tiles by descending list
-// length with a counting sort on 256 buckets (bucket = length >> shift, shift from the longest list) and writes, per
-// workgroup slot b of the blend kernels, {tile, list start, list end}: the blend kernels then need no second lookup.
-// Inside a bucket the order is the arrival order of LDS atomics (only scheduling depends on it).
+// heaviest-first takes 124 / 220 (profiles/r6/tile_order_clustered.txt).  One workgroup writes, per workgroup slot b of the
+// blend kernels, {tile, list start, list end} (they need no second lookup):
+//   * the tiles go by CLASS of list length, longest first -- two classes per octave (lengths within ~40 % of each other share
+//     one), which is all the balance needs: what matters is that a 1000-entry list does not start behind 200-entry ones;
+//   * inside a class the tiles keep their order in the image, and the class is dealt to the
+//     XCDs in eight CONTIGUOUS parts -- slot b runs on XCD b mod 8 -- so that tiles running together on an XCD are neighbours
+//     and share the Gaussians' records in its L2.  (A fine sort by length scatters neighbours over the XCDs: same kernel
+//     times, but 350 / 359 MB of HBM traffic for the forward / backward blend instead of 188 / 226, profiles/r6_pmc.txt.)
+// On the uniform benchmark scene nine tiles in ten share one class: the schedule is round 5's XCD bands with the few long lists
+// in front.
 constexpr int TS_THREADS = 1024;
+// A class owns the M slots from B on; XCD x = slot mod 8 takes the x-th contiguous part of the class, as many tiles as the class
+// has slots on that XCD.  part_table fills, for one (class, XCD): the class position its part starts at and its first slot.
+__device__ __forceinline__ void part_table(uint32_t B, uint32_t M, uint32_t x, uint32_t& n_x, uint32_t& first) {
+    first = B + ((x + 8u - (B & 7u)) & 7u);  // first slot >= B on XCD x
+    n_x = first < B + M ? (B + M - 1u - first) / 8u + 1u : 0u;
+}
+// Wave w takes the w-th contiguous sixteenth of the tiles, 512 at a time, EIGHT CONSECUTIVE TILES PER LANE: neighbours mostly
+// share a class, so a lane hands in whole runs -- one LDS atomic per run instead of one per tile (same-address LDS atomics retire
+// about one lane per two cycles for the whole CU: 2 x 8160 of them on the uniform scene's one dominant class were 13 of a first
+// version's 16 us).  First every wave counts its tiles per class in its own row of counters; a prefix over the waves turns the
+// rows into each wave's first position inside every class; then every wave places its tiles, drawing positions from its own
+// row: no barrier between the waves, a class's tiles in image order up to the order of the lanes inside one 512-tile block.
 __global__ void __launch_bounds__(TS_THREADS) tile_schedule_kernel(const uint2* __restrict__ ranges, int tiles,
                                                                     uint4* __restrict__ sched) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t wtot[4];
-    __shared__ uint32_t s_max;
+    constexpr int NW = TS_THREADS / 64, NC = DGR_SCHED_CLASSES, PL = 8;
+    __shared__ uint32_t cntw[NW][NC];  // tiles of wave w in class c; then: position of the wave's next tile inside class c
+    __shared__ uint32_t cnt[NC], base[NC];
+    __shared__ uint32_t part_off[NC][8], part_first[NC][8];  // per (class, XCD): first class position / first slot of the part
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 256) hist[tid] = 0u;
-    if (tid == 0) s_max = 0u;
+    for (int i = tid; i < NW * NC; i += TS_THREADS) (&cntw[0][0])[i] = 0u;
     __syncthreads();
-    constexpr int KEEP = 8;  // ranges kept in registers between the passes (frames up to 8192 tiles need no second read)
-    uint2 rg[KEEP];
-    uint32_t m = 0u;
-#pragma unroll
-    for (int k = 0; k < KEEP; k++) {
-        const int t = tid + k * TS_THREADS;
-        rg[k] = t < tiles ? ranges[t] : make_uint2(0u, 0u);
-        m = max(m, rg[k].y - rg[k].x);
-    }
-    for (int t = tid + KEEP * TS_THREADS; t < tiles; t += TS_THREADS) { const uint2 r = ranges[t]; m = max(m, r.y - r.x); }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-    if (lane == 0 && m) atomicMax(&s_max, m);
-    __syncthreads();
-    const int shift = max(0, 24 - (int)__clz(s_max | 1u));  // (longest list) >> shift < 256
-#pragma unroll
-    for (int k = 0; k < KEEP; k++)
-        if (tid + k * TS_THREADS < tiles) atomicAdd(&hist[255u - ((rg[k].y - rg[k].x) >> shift)], 1u);
-    for (int t = tid + KEEP * TS_THREADS; t < tiles; t += TS_THREADS) { const uint2 r = ranges[t]; atomicAdd(&hist[255u - ((r.y - r.x) >> shift)], 1u); }
-    __syncthreads();
-    // exclusive scan of the 256 bucket counts (bucket 0 = the longest lists)
-    uint32_t n = 0u, incl = 0u;
-    if (tid < 256) {
-        n = hist[tid];
-        incl = n;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
+    const int per_wave = ((tiles + NW - 1) / NW + 64 * PL - 1) / (64 * PL) * (64 * PL);  // a multiple of 512
+    const int w0 = wave * per_wave, w1 = min(tiles, w0 + per_wave);
+    // the lane's eight tiles of the block starting at b0: ranges, classes, and the runs of equal class among them
+    struct Block { uint2 r[PL]; uint32_t c[PL]; uint32_t len[PL]; bool valid[PL], start[PL]; };
+    auto load_block = [&](int b0, Block& B) {
+        const int t0 = b0 + lane * PL;
+        const uint4* src = reinterpret_cast<const uint4*>(ranges + t0);  // (16-byte aligned: t0 is a multiple of 8; a block's tail may lie
+#pragma unroll                                                          //  behind `tiles` but inside the image buffer: ignored)
+        for (int k = 0; k < PL; k += 2) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (t0 + k < w1) v = src[k / 2];
+            B.r[k] = make_uint2(v.x, v.y);
+            B.r[k + 1] = make_uint2(v.z, v.w);
         }
-        if (lane == 63) wtot[wave] = incl;
+#pragma unroll
+        for (int k = 0; k < PL; k++) {
+            B.valid[k] = t0 + k < w1;
+            B.c[k] = sched_class(B.r[k].y - B.r[k].x);
+            B.start[k] = B.valid[k] && (k == 0 || B.c[k] != B.c[k - 1]);
+        }
+        B.len[PL - 1] = 1u;
+#pragma unroll
+        for (int k = PL - 2; k >= 0; k--) B.len[k] = (B.valid[k + 1] && B.c[k + 1] == B.c[k]) ? B.len[k + 1] + 1u : 1u;  // run length from k on
+    };
+    for (int b0 = w0; b0 < w1; b0 += 64 * PL) {
+        Block B;
+        load_block(b0, B);
+#pragma unroll
+        for (int k = 0; k < PL; k++)
+            if (B.start[k]) atomicAdd(&cntw[wave][B.c[k]], B.len[k]);
     }
     __syncthreads();
-    if (tid < 256) {
+    {   // every wave's first position inside each class (thread (w, c) sums the rows above its own), the class totals
+        const int w = tid >> 5, c = tid & (NC - 1);
         uint32_t before = 0u;
-        for (int w = 0; w < wave; w++) before += wtot[w];
-        hist[tid] = before + incl - n;
+        if (tid < NW * NC)
+            for (int ww = 0; ww < w; ww++) before += cntw[ww][c];
+        if (tid >= (NW - 1) * NC && tid < NW * NC) cnt[c] = before + cntw[NW - 1][c];
+        __syncthreads();
+        if (tid < NW * NC) cntw[w][c] = before;
     }
     __syncthreads();
+    if (tid < 64) {  // first slot of every class, the class of the longest lists first (lane l holds class NC - 1 - l)
+        const uint32_t v = lane < NC ? cnt[NC - 1 - lane] : 0u;
+        uint32_t incl = v;
 #pragma unroll
-    for (int k = 0; k < KEEP; k++) {
-        const int t = tid + k * TS_THREADS;
-        if (t < tiles) {
-            const uint32_t pos = atomicAdd(&hist[255u - ((rg[k].y - rg[k].x) >> shift)], 1u);
-            sched[pos] = make_uint4((uint32_t)t, rg[k].x, rg[k].y, 0u);
+        for (int off = 1; off < NC; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
         }
+        if (lane < NC) base[NC - 1 - lane] = incl - v;
     }
-    for (int t = tid + KEEP * TS_THREADS; t < tiles; t += TS_THREADS) {
-        const uint2 r = ranges[t];
-        const uint32_t pos = atomicAdd(&hist[255u - ((r.y - r.x) >> shift)], 1u);
-        sched[pos] = make_uint4((uint32_t)t, r.x, r.y, 0u);
+    __syncthreads();
+    if (tid < NC * 8) {  // the XCDs' parts of every class
+        const uint32_t c = (uint32_t)tid >> 3, x = (uint32_t)tid & 7u;
+        uint32_t off = 0u, n_x, first;
+        for (uint32_t xx = 0; xx < x; xx++) { part_table(base[c], cnt[c], xx, n_x, first); off += n_x; }
+        part_table(base[c], cnt[c], x, n_x, first);
+        part_off[c][x] = off;
+        part_first[c][x] = first;
+    }
+    __syncthreads();
+    for (int b0 = w0; b0 < w1; b0 += 64 * PL) {
+        Block B;
+        load_block(b0, B);
+        uint32_t run_base = 0u;
+#pragma unroll
+        for (int k = 0; k < PL; k++) {
+            if (B.start[k]) run_base = atomicAdd(&cntw[wave][B.c[k]], B.len[k]);  // (the wave's own row)
+            else run_base += 1u;                                                     // (next tile of the same run)
+            if (B.valid[k]) {
+                const uint32_t c = B.c[k], p = run_base;  // position inside the class
+                uint32_t x = 0u;  // the part holding it: the last one that starts at or before p (an empty part starts where the next does)
+#pragma unroll
+                for (int j = 1; j < 8; j++) x += p >= part_off[c][j] ? 1u : 0u;
+                sched[part_first[c][x] + 8u * (p - part_off[c][x])] = make_uint4((uint32_t)(b0 + lane * PL + k), B.r[k].x, B.r[k].y, 0u);
+            }
+        }
     }
 }
 

@@ -23,9 +23,21 @@
 #define DGR_COUNT_STRIDE 16
 #endif  // tile counters are padded to one per 64-byte line: returning atomics on one line serialise
 
+#define DGR_SCHED_CLASSES 32
+
 namespace dgr {
 
 __host__ __device__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// list length -> class of the blend kernels' tile schedule (binning.hip): 0 for an empty list, then two classes per octave
+// (lengths within ~40 % of each other share a class), saturating at 31 (>= 23 170 entries).  Monotone in n.
+__device__ inline uint32_t sched_class(uint32_t n) {
+    if (n == 0u) return 0u;
+    const uint32_t l = 31u - (uint32_t)__clz((int)n);
+    const uint32_t half = l ? (n >> (l - 1u)) & 1u : 0u;
+    const uint32_t c = 1u + 2u * l + half;
+    return c < (uint32_t)DGR_SCHED_CLASSES - 1u ? c : (uint32_t)DGR_SCHED_CLASSES - 1u;
+}
 
 // ---- render record ---------------------------------------------------------------------------
 // q0 = {x_pix, y_pix, depth, opacity}   (means2D, depths, conic_opacity.w of the reference)
@@ -69,7 +81,7 @@ struct ImageView {
     uint32_t* tile_count; // [tiles * DGR_COUNT_STRIDE] instances per tile (histogram filled by count_rank), one per line
     uint2* ranges;        // [tiles] {start, end} into point_list
     uint4* tile_sched;    // [tiles] the blend kernels' schedule: workgroup b works on tile .x, whose list is [.y, .z) --
-                          //     heaviest tile first (tile_schedule_kernel, binning.hip)
+                          //     classes of long lists first, neighbours on one XCD (tile_schedule_kernel, binning.hip)
     uint32_t* n_contrib;  // [N]
     float* final_T;       // [N]   (full variant)
     uint32_t* n_valid;    // [N]   (full variant) valid contributors of the pixel

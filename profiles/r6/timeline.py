@@ -17,7 +17,7 @@ with open(path) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?")))
 rows.sort()
 def kind(n):
-    for k in ("render_bwd", "render_fwd", "preprocess_bwd", "preprocess_fwd", "bin_tiles", "bin_segments", "zero_fill"):
+    for k in ("render_bwd", "render_fwd", "preprocess_bwd", "preprocess_fwd", "bin_tiles", "bin_segments", "tile_schedule", "zero_fill"):
         if k in n: return k
     return "other"
 bwd = [i for i, r in enumerate(rows) if kind(r[2]) == "render_bwd"]

@@ -3,8 +3,8 @@
 synth-v1 spreads the Gaussians evenly (tile lists of 203 +- 20 % at config 3); a mapped room does not.  The schedule hands
 the blend kernels their tiles heaviest first; it changes nothing but the order in which tiles are worked on, so every
 parity bar of the uniform scenes must hold on a clustered one too (dgr_amd.synth.cluster_scene: lists from a few dozen to
-over a thousand entries), and the table itself must be a permutation of the tiles, carry each tile's own range and be
-ordered by descending list length at the granularity of its 256 buckets.
+over a thousand entries), and the table itself must be a permutation of the tiles, carry each tile's own range, be ordered
+by descending list-length class and keep a class's tiles in image order, one contiguous part per XCD.
 """
 import numpy as np
 import pytest
@@ -17,6 +17,15 @@ from test_hip_light_parity import assert_images_carry_the_references_bits, check
 pytestmark = pytest.mark.gpu
 
 
+def sched_class(n):
+    """csrc/dgr_common.h: sched_class"""
+    if n == 0:
+        return 0
+    l = int(n).bit_length() - 1
+    half = (n >> (l - 1)) & 1 if l else 0
+    return min(31, 1 + 2 * l + half)
+
+
 def check_schedule(s, d):
     tiles = ((s.W + 15) // 16) * ((s.H + 15) // 16)
     rg = hh.hip_state("ranges", s, d).reshape(tiles, 2).astype(np.int64)
@@ -24,10 +33,18 @@ def check_schedule(s, d):
     assert np.array_equal(np.sort(sc[:, 0]), np.arange(tiles)), "not a permutation of the tiles"
     assert np.array_equal(sc[:, 1:3], rg[sc[:, 0]]), "a slot does not carry its tile's range"
     n = sc[:, 2] - sc[:, 1]
-    longest = int(n.max())
-    shift = max(0, longest.bit_length() - 8)
-    b = n >> shift
-    assert np.all(b[:-1] >= b[1:]), "slots are not ordered by descending list length (bucket granularity)"
+    cls = np.array([sched_class(int(v)) for v in n])
+    assert np.all(cls[:-1] >= cls[1:]), "slots are not ordered by descending list-length class"
+    # inside a class every XCD (slot mod 8) holds a contiguous part of the class in image order, and the parts of successive
+    # XCDs follow each other: walking the XCDs' parts one after the other gives the class's tiles in ascending order (up to the
+    # order inside one 512-tile block of the schedule kernel's waves)
+    slot = np.arange(tiles)
+    per_wave = (((tiles + 15) // 16) + 511) // 512 * 512
+    for c in np.unique(cls):
+        sel = cls == c
+        walk = np.concatenate([sc[sel & (slot % 8 == x), 0] for x in range(8)])
+        group = (walk // per_wave) * per_wave + ((walk % per_wave) // 512) * 512
+        assert np.all(group[:-1] <= group[1:]), f"class {c}: the XCDs' parts are not the class in image order"
     return n
 
 
