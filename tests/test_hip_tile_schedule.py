@@ -121,3 +121,46 @@ def test_clustered_scene_full_variant_against_the_oracle(oracle, case):
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"):
         assert_grad_close(g[k], gr[k], k, **tol)
     assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=5e-5, elem_rtol=5e-3, elem_frac=0.1)
+
+
+def test_clustered_scene_batch_views_are_the_one_view_calls():
+    """The batched entry points on a non-uniform map: every view's images, lists and schedule state as a one-view call's."""
+    import torch
+    import test_hip_batch as tb
+    P, W, H, deg, V = 60000, 480, 320, 3, 3
+    ss = [cluster_scene(x) for x in tb.scenes(P, W, H, V, 0)]
+    out, _ = tb.batch_forward(ss, deg)
+    for v, s in enumerate(ss):
+        one, d1 = hh.hip_forward(s, deg)
+        ov = tb.one_view_dict(out, v)
+        assert ov[0] == one[0]
+        for k in (1, 2, 3, 5, 6):  # colour, depth, median, alpha, radii
+            assert torch.equal(ov[k], one[k]), (v, k)
+        dv = {"num_rendered": ov[0], "geom": ov[7], "binning": ov[8], "img": ov[9]}
+        for name in ("ranges", "point_list", "n_contrib"):
+            assert np.array_equal(hh.hip_state(name, s, dv), hh.hip_state(name, s, d1)), (v, name)
+        check_schedule(s, dv)
+
+
+def test_clustered_scene_with_tight_culling_and_through_the_callback_path(oracle, monkeypatch):
+    """The two other ways into the binning on a non-uniform frame: alpha-aware tile rectangles (fewer, shorter lists) and the
+    callback entry points (binning buffer sized after a host read: COUNT_LDS_CALLBACK)."""
+    from dgr_amd import _capi
+    s = cluster_scene(make_scene(100000, 640, 480, 0))
+    st, ref = hh.oracle_forward(oracle, s, 3)
+    monkeypatch.setenv("DGR_FORWARD_MODE", "callback")
+    _, d = hh.hip_forward(s, 3)
+    monkeypatch.delenv("DGR_FORWARD_MODE")
+    assert d["num_rendered"] == ref["num_rendered"]
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    assert_images_carry_the_references_bits(d, st, ref, s)
+    check_schedule(s, d)
+    _capi.set_option("tight_cull", 1)
+    try:
+        _, dt = hh.hip_forward(s, 3)
+    finally:
+        _capi.set_option("tight_cull", 0)
+    assert dt["num_rendered"] < d["num_rendered"]
+    for k in ("color", "depth", "depth_median", "opacity_map"):
+        assert np.array_equal(dt[k], d[k]), k
+    check_schedule(s, dt)
