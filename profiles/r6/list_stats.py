@@ -1,5 +1,7 @@
+"""Tile-list statistics of BASELINE configs 4 and 5 (per-GPU views): mean / max list, share of lists above 512 / 1024 entries, and per segment
+size (4 / 8 / 16 tiles) the share of segments holding a list above 1024 entries or more than 6144 keys.  Usage (GPU box): python profiles/r6/list_stats.py"""
 import os, sys
-ROOT="/root/repo"
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-gaussian-rasterization_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 from dgr_amd.synth import make_scene
