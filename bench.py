@@ -4,7 +4,8 @@
 One "step" = one view: GaussianRasterizer.forward + backward through the reference-shaped autograd
 surface (light variant, SH degree 3, all four pixel-gradient images non-zero, track_off = map_off =
 False) on the synth-v1 scene of BASELINE config 3, inputs resident in HBM before the timed region.
-By default three independent views are in flight on three HIP streams (--views-in-flight; every view is
+By default seven independent views are in flight on seven HIP streams (--views-in-flight; three in strict / graph / tracking mode
+and with --gpus N; every view is
 a complete forward + backward with its own state) and the forward checks its status word lazily
 (--sync-mode); `config.ms_per_view_one_stream` is the strictly serial figure.
 
@@ -86,10 +87,14 @@ def main():
                     help="light = the headline (config 3); full = the -full flavour (use with --workload config2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=5)
-    ap.add_argument("--views-in-flight", type=int, default=3,
+    ap.add_argument("--views-in-flight", type=int, default=0,
                     help="independent views (forward+backward each) issued round-robin on this many HIP streams: the "
-                         "atomic- and latency-bound binning kernels of one view run under the VALU-bound blend kernels "
-                         "of another; 1 = strictly one view at a time")
+                         "bandwidth- and latency-bound kernels of one view run under the VALU-bound blend kernels of another, and two "
+                         "views' blend kernels fill each other's tails; 1 = strictly one view at a time.  Measured (profiles/r6/"
+                         "views_in_flight.txt, ms per step at 20 / 100 steps): 3 views 0.470-0.487 / 0.431-0.438, 5: 0.458-0.483 / "
+                         "0.426-0.440, 7: 0.443-0.468 / 0.420-0.428, 9-13 as 7; even counts (4, 8) measure worse than their neighbours.  "
+                         "Default (0): 7 for the eager lazy-status mapping step on one GPU, 3 otherwise (strict status, graph replay, tracking step, "
+                         "--gpus N: measured worse with seven, or not measurable here)")
     ap.add_argument("--graph", action="store_true",
                     help="N=1: record one view per stream into a hipGraph (dgr_amd.multiview.CapturedStep) and replay the "
                          "graphs round-robin instead of issuing the views from Python; pays for host-bound sizes (config 2)")
@@ -274,6 +279,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    args.views_in_flight_requested = args.views_in_flight
+    if args.views_in_flight <= 0:
+        # seven where the host issues every launch itself and never waits for a status word (the measurements above); three
+        # where it waits once per forward (strict: 0.478 with three views against 0.563 with seven), where the views are replayed
+        # from graphs (config 2: 0.106 against 0.118), for the tracking step (0.355 against 0.378) and with a collective per view
+        args.views_in_flight = 7 if (dist is None and args.sync_mode == "lazy" and not args.graph and not args.tracking) else 3
     K = 1 if (Vb or args.group > 1) else max(1, args.views_in_flight)  # (a batch spreads its views over streams itself)
     views = ViewStreams(K, dev) if K > 1 else None  # dgr_amd.multiview: independent views on K HIP streams
 
@@ -509,7 +520,7 @@ def main():
 def graph_replay_line(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--graph",
-           "--no-cpu-baseline", "--workload", args.workload, "--variant", args.variant, "--views-in-flight", str(args.views_in_flight)]
+           "--no-cpu-baseline", "--workload", args.workload, "--variant", args.variant, "--views-in-flight", str(args.views_in_flight_requested)]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         return float(json.loads(out.stdout.strip().splitlines()[-1])["ms_per_step"])
