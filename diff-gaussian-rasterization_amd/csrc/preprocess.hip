@@ -181,6 +181,21 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// A 16-byte store that is not kept in the caches: the dL_dsh rows (96 MB per view) are written once and read by nobody here.
+// Left dirty in L2 / the memory-side cache they were written back under the NEXT kernel's reads: preprocess_fwd of the following
+// view 45 -> 39.5 us, the view 0.513 -> 0.508 ms one at a time (profiles/r6/ab_nontemporal.txt).
+__device__ __forceinline__ void store_streaming(float4* dst, float4 v) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f*>(dst));
+}
+// ... and a 16-byte load likewise: the SH rows (96 MB per view, read once by preprocess_fwd) no longer push the render records
+// the same kernel writes out of the caches in front of the forward blend's gathers: one view at a time 0.510 -> 0.501 ms
+// (preprocess_fwd -1 us, bin_tiles -0.7, render_fwd -2.5), several views in flight unchanged.
+__device__ __forceinline__ float4 load_streaming(const float4* src) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void sh_rows_to_lanes(const float* __restrict__ src, size_t g_block, float* lds, float (&f)[48]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* my = lds + wave * (SHT_ROWS * SHT_LD);
@@ -192,7 +207,7 @@ __device__ __forceinline__ void sh_rows_to_lanes(const float* __restrict__ src, 
         for (int i = 0; i < 6; i++) {
             const int e = i * 64 + lane;  // float4 index inside the 32-row slab
             const int g = e / 12, c = e - 12 * g;
-            *reinterpret_cast<float4*>(my + g * SHT_LD + 4 * c) = p[e];
+            *reinterpret_cast<float4*>(my + g * SHT_LD + 4 * c) = load_streaming(p + e);
         }
         wave_sync();
         if ((lane >> 5) == r) {
@@ -224,7 +239,7 @@ __device__ __forceinline__ void lanes_to_sh_rows(const float (&f)[48], float* __
         for (int i = 0; i < 6; i++) {
             const int e = i * 64 + lane;
             const int g = e / 12, c = e - 12 * g;
-            p[e] = *reinterpret_cast<const float4*>(my + g * SHT_LD + 4 * c);
+            store_streaming(p + e, *reinterpret_cast<const float4*>(my + g * SHT_LD + 4 * c));
         }
         wave_sync();
     }
@@ -254,7 +269,7 @@ __device__ __forceinline__ void lanes_to_sh_rows_scaled(const float (&coef)[16],
         for (int i = 0; i < 6; i++) {
             const int e = i * 64 + lane;
             const int g = e / 12, c = e - 12 * g;
-            p[e] = *reinterpret_cast<const float4*>(my + g * SHT_LD + 4 * c);
+            store_streaming(p + e, *reinterpret_cast<const float4*>(my + g * SHT_LD + 4 * c));
         }
         wave_sync();
     }
