@@ -931,7 +931,7 @@ __global__ void __launch_bounds__(256, DGR_PPB_WAVES) preprocess_bwd_kernel(Prep
         // `if (vis)` / `if (do_map)` the loads formed a chain of three dependent round trips per wave, and this kernel
         // spends 60 % of its wave-cycles waiting for memory.
         const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)idx * DGR_ACC_STRIDE);
-        const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];
+        const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];  // (nontemporal loads here: 45 -> 49 us -- the rows sit in L2, where the blend's atomics left them)
         const int rad = a.radii[idx];
         const float3 m = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
         float c3[6];

@@ -221,13 +221,15 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     float T = T_final;
     float dpix0 = 0.f, dpix1 = 0.f, dpix2 = 0.f, dpix_depth = 0.f, dpix_median = 0.f, dpix_var = 0.f, gt_px = 0.f;
     if (inside) {
-        dpix0 = a.dL_dpix[pix_id];
-        dpix1 = a.dL_dpix[N + pix_id];
-        dpix2 = a.dL_dpix[2 * N + pix_id];
-        dpix_depth = a.dL_dpix_depth[pix_id];
-        dpix_median = a.dL_dpix_median[pix_id];
-        dpix_var = a.dL_dpix_var[pix_id];
-        gt_px = a.gt_depth[pix_id];
+        // (single-use images, 28 bytes per pixel: nontemporal, so that they do not push the accumulator rows and render records out of
+        //  the caches -- preprocess_bwd behind this kernel 45 -> 43.5 us, profiles/r6/ab_nontemporal.txt)
+        dpix0 = __builtin_nontemporal_load(a.dL_dpix + pix_id);
+        dpix1 = __builtin_nontemporal_load(a.dL_dpix + N + pix_id);
+        dpix2 = __builtin_nontemporal_load(a.dL_dpix + 2 * N + pix_id);
+        dpix_depth = __builtin_nontemporal_load(a.dL_dpix_depth + pix_id);
+        dpix_median = __builtin_nontemporal_load(a.dL_dpix_median + pix_id);
+        dpix_var = __builtin_nontemporal_load(a.dL_dpix_var + pix_id);
+        gt_px = __builtin_nontemporal_load(a.gt_depth + pix_id);
     }
     // per-pixel constants of the loop: -T_final <bg, dL/dpixel> (the background term of dL/dalpha is this times
     // 1/(1 - alpha)) and 2 dL/dvar
