@@ -163,6 +163,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     os.environ["DGR_SYNC_MODE"] = args.sync_mode
+    # One device, one Python thread: the autograd engine's per-device worker thread only adds a hand-off per backward (the
+    # caller parks until the worker has run the graph: 20-70 us of futex latency per view, profiles/host_breakdown.py --
+    # more than a 640x480 view's kernels leave room for).  With multithreading off the engine runs the graph on the calling
+    # thread, on the same streams.  A switch of PyTorch, not of the rasterizer; DGR_BENCH_AUTOGRAD_THREADS=1 leaves it on.
+    if os.environ.get("DGR_BENCH_AUTOGRAD_THREADS") != "1":
+        torch.autograd.set_multithreading_enabled(False)
     from dgr_amd import _capi, light
     from dgr_amd.multiview import GradientArena, GroupedReduce, ViewStreams, make_settings
     from dgr_amd.synth import make_scene

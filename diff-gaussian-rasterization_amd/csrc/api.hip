@@ -20,6 +20,7 @@
 #include <atomic>
 #include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/dgr_hip.h"
 #include "dgr_common.h"
@@ -109,16 +110,88 @@ hipError_t wait_event_spinning(hipEvent_t ev) {
     }
 }
 
+// ---- resident backward scratch (dgr_backward_scratch_clean_arm): the next backward of this thread finds its scratch all zero and
+// leaves it all zero -- no clearing launch in front of the blend backward.
+thread_local bool g_scratch_clean_armed = false;
+
 // ---- asynchronous status read-back (dgr_status_post / _poll): the lazy mode of the bindings copies a forward's status
 // word to pinned host memory behind an event and looks at it one or two calls later.  Slots are pooled per device.
+// Two ways to fill a slot: dgr_status_post copies a device word behind an event (any status word, after the fact);
+// dgr_status_arm hands the slot to the NEXT presized forward, whose binning kernel writes the word straight into the slot's
+// pinned memory (mapped into the device's address space) with a tag last -- no copy, no event, nothing to wait for on the
+// stream -- and may use three device words owned by the slot (zero between forwards) to gather the frame's longest tile list.
 struct StatusSlot {
     hipEvent_t ev = nullptr;
-    int* pinned = nullptr;
+    int* pinned = nullptr;       // host int[8]: {num_rendered, overflow, prefiltered violation, num_related | tag, longest list, -, -}
+    int* pinned_dev = nullptr;   // the same memory as the device sees it
+    uint32_t* ws = nullptr;      // device uint32[16], zero between forwards
     int device = -1;
     bool busy = false;
+    bool mapped = false;         // this use of the slot: armed (written by the kernels) rather than posted (copied)
+    uint32_t tag = 0;
+    int W = 0, H = 0, P = 0;     // the forward that took the arm (key of the schedule hint below)
 };
 std::mutex g_status_mu;
 std::vector<StatusSlot> g_status_slots;
+uint32_t g_status_tag = 0;
+thread_local long g_armed_slot = -1;
+
+// ---- tile schedule policy (dgr_set_option("tile_schedule", v)): 1 = every forward runs tile_schedule_kernel (the blend kernels
+// take their tiles classes of long lists first), 0 = never (static XCD band map), 2 (default) = by the frame: a forward whose
+// status word came back through an armed slot also reports its longest tile list, and the NEXT forward of that shape
+// (device, P, W, H) skips the schedule when the longest list was within 2x the mean + 32 -- on such a frame the schedule buys
+// nothing (uniform synth-v1 scene: 1 % of the blend time) and costs a launch, a 1024-thread workgroup in front of the blend
+// (11 us at 1080p) and some of the blend's L2 locality; a clustered frame (longest list 5x the mean) gets it back one
+// forward later.  Forwards without a report (callback path, batched entry points, hipGraph capture, direct C-ABI callers that
+// never arm) keep the schedule.  Results do not depend on it: only the order in which tiles are worked on.
+std::atomic<int> g_tile_schedule{[] { const char* e = getenv("DGR_TILE_SCHEDULE"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }()};
+struct SchedHint { int device, W, H, P, on; };
+std::vector<SchedHint> g_sched_hints;  // (under g_status_mu)
+bool want_schedule(int W, int H, int P) {
+    const int mode = g_tile_schedule.load(std::memory_order_relaxed);
+    if (mode != 2) return mode != 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return true;
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    for (const auto& h : g_sched_hints)
+        if (h.device == dev && h.W == W && h.H == H && h.P == P) return h.on != 0;
+    return true;
+}
+void note_schedule_hint(const StatusSlot& sl, const int* word) {  // (g_status_mu held)
+    const long tiles = (long)dgr::tiles_x(sl.W) * dgr::tiles_y(sl.H);
+    if (tiles <= 0 || word[1] /* overflow: the lists were left empty */) return;
+    const long longest = word[5];
+    const int on = (longest >= 0x7fffffff || longest * tiles > 2L * word[0] + 32L * tiles) ? 1 : 0;
+    for (auto& h : g_sched_hints)
+        if (h.device == sl.device && h.W == sl.W && h.H == sl.H && h.P == sl.P) { h.on = on; return; }
+    if (g_sched_hints.size() >= 64) g_sched_hints.erase(g_sched_hints.begin());
+    g_sched_hints.push_back(SchedHint{sl.device, sl.W, sl.H, sl.P, on});
+}
+
+// The armed slot of this thread, taken by a presized forward.  If the call leaves before its binning kernel is enqueued
+// (an error, P == 0) the word is completed from the host -- all zero -- so that a poll never waits for a write that will not come.
+struct ArmedReport {
+    long id = -1;
+    dgr::StatusReport rep{nullptr, 0u, nullptr};
+    bool handed_over = false;
+    ArmedReport(int W, int H, int P) {
+        id = g_armed_slot;
+        g_armed_slot = -1;
+        if (id < 0) return;
+        std::lock_guard<std::mutex> lk(g_status_mu);
+        StatusSlot& sl = g_status_slots[(size_t)id];
+        sl.W = W; sl.H = H; sl.P = P;
+        rep.host = sl.pinned_dev; rep.tag = sl.tag; rep.ws = sl.ws;
+    }
+    ~ArmedReport() {
+        if (id < 0 || handed_over) return;
+        std::lock_guard<std::mutex> lk(g_status_mu);
+        StatusSlot& sl = g_status_slots[(size_t)id];
+        volatile int* w = sl.pinned;
+        w[0] = w[1] = w[2] = w[3] = 0; w[5] = 0x7fffffff;
+        w[4] = (int)sl.tag;
+    }
+};
 
 // ---- optional per-stage timing with HIP events on the launching stream (dgr_profile_* in dgr_hip.h).
 // Disabled by default; when a stage is selected, two events bracket that stage's launch only.
@@ -278,25 +351,30 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
 // (`fused`: preprocess_fwd counted already; the status word is complete after scan_tiles, which is where a caller that
 // armed the early status gets its copy)
 int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, int capacity,
-                   hipStream_t st, int mode = COUNT_CALLBACK, char* binning_base = nullptr) {
+                   hipStream_t st, int mode = COUNT_CALLBACK, char* binning_base = nullptr, ArmedReport* armed = nullptr) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
+    // the tile schedule: always, unless this shape's last reported frame had even lists (want_schedule above)
+    const bool sched_on = !(armed && armed->id >= 0) ? (g_tile_schedule.load(std::memory_order_relaxed) != 0) : want_schedule(c.W, c.H, c.P);
+    const dgr::StatusReport rep = armed ? armed->rep : dgr::StatusReport{nullptr, 0u, nullptr};
     if (mode == COUNT_LDS || mode == COUNT_LDS_CALLBACK) {
         const bool cb = mode == COUNT_LDS_CALLBACK;
         const dgr::SegmentTables tb = dgr::carve_segment_tables(binning_base + bin.bytes, c.W, c.H);
         const int ss = dgr::segment_shift(c.W, c.H, capacity);
         { ScopedStage t(ST_BIN_SEGMENTS, st); HIP_TRY(dgr::launch_bin_segments(c.P, geom, bin, tb, gx, gy, ss, capacity, cb, st)); }
-        { ScopedStage t(ST_BIN_TILES, st); HIP_TRY(dgr::launch_bin_tiles(c.P, geom, img, bin, tb, gx, gy, ss, capacity, cb, st)); }
+        { ScopedStage t(ST_BIN_TILES, st); HIP_TRY(dgr::launch_bin_tiles(c.P, geom, img, bin, tb, gx, gy, ss, capacity, cb, sched_on, rep, st)); }
+        if (armed) armed->handed_over = true;
         if (!cb) { const int rc = early_status_post(img.status, st); if (rc) return rc; }  // (bin_tiles writes the status word)
-        { ScopedStage t(ST_TILE_SCHED, st); HIP_TRY(dgr::launch_tile_schedule(img, tiles, st)); }
+        if (sched_on) { ScopedStage t(ST_TILE_SCHED, st); HIP_TRY(dgr::launch_tile_schedule(img, tiles, st)); }
         return DGR_OK;
     }
     const bool fused = mode == COUNT_FUSED;
     if (!fused) { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_rank(c.P, geom, img, bin, gx, capacity, st)); }
-    { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, gx, capacity, fused, st)); }
+    { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, gx, capacity, fused, sched_on, rep, st)); }
+    if (armed) armed->handed_over = true;
     if (fused) { const int rc = early_status_post(img.status, st); if (rc) return rc; }
     { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
     { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
-    { ScopedStage t(ST_TILE_SCHED, st); HIP_TRY(dgr::launch_tile_schedule(img, tiles, st)); }
+    if (sched_on) { ScopedStage t(ST_TILE_SCHED, st); HIP_TRY(dgr::launch_tile_schedule(img, tiles, st)); }
     return DGR_OK;
 }
 
@@ -304,7 +382,7 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
     dgr::RenderFwdLightArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
-    r.sched = img.tile_sched; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background; r.gt_depth = c.gt_depth;
+    r.sched = img.tile_sched; r.ranges = img.ranges; r.sched_flag = img.cursor + 3; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background; r.gt_depth = c.gt_depth;
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_median = c.out_median_depth; r.out_alpha = c.out_alpha;
     r.out_depth_var = c.out_depth_var; r.n_contrib = img.n_contrib; r.gau_uncertainty = c.gau_uncertainty;
     r.gau_related_pixels = c.gau_related_pixels;
@@ -318,7 +396,7 @@ int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryV
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
     dgr::RenderFwdFullArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
-    r.sched = img.tile_sched; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background;
+    r.sched = img.tile_sched; r.ranges = img.ranges; r.sched_flag = img.cursor + 3; r.point_list = bin.point_list; r.rec = geom.rec; r.bg = c.background;
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_uncertainty = out_uncertainty;
     r.n_contrib = img.n_contrib; r.n_valid = img.n_valid; r.first_contrib = img.first_contrib; r.final_T = img.final_T;
     r.status = img.status;
@@ -505,6 +583,7 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
                 cov3D_precomp, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
                 out_color, out_depth, out_median_depth, out_alpha, gt_depth, out_depth_var, gau_uncertainty,
                 gau_related_pixels, radii};
+    ArmedReport armed(width, height, P);  // (dgr_status_arm: completed from the host on every path that enqueues no binning kernel)
     int rc = check_common(c);
     if (rc) return rc;
     if (P == 0) {
@@ -523,7 +602,7 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
     const int mode = presized_count_mode(width, height, binning_capacity);
     if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer, mode))) return rc;
-    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer))) return rc;
+    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer, &armed))) return rc;
     if ((rc = forward_back(c, geom, img, bin, st))) return rc;
     return DGR_OK;
 }
@@ -585,6 +664,8 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
                        const float* gt_depth, int track_off, int map_off, char* scratch, size_t scratch_bytes) {
     (void)R; (void)dgndcs_dviewmatrix; (void)dg_camd_dviewmatrix; (void)colors_precomp;
     hipStream_t st = (hipStream_t)stream;
+    const bool scratch_clean = g_scratch_clean_armed;
+    g_scratch_clean_armed = false;
     if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
     if (P == 0) {  // L/rasterize_points.cu:188: nothing runs, gradients stay zero
         HIP_TRY(hipMemsetAsync(dL_dview, 0, 16 * 4, st));
@@ -598,11 +679,11 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, st)); }
+    if (!scratch_clean) { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, st)); }
 
     dgr::RenderBwdLightArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
-    r.sched = img.tile_sched; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
+    r.sched = img.tile_sched; r.ranges = img.ranges; r.sched_flag = img.cursor + 3; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
     r.gt_depth = gt_depth; r.alphas = alphas; r.n_contrib = img.n_contrib; r.dL_dpix = dL_dpix;
     r.dL_dpix_depth = dL_dpix_depth; r.dL_dpix_median = dL_dpix_median_depth; r.dL_dpix_var = dL_dpix_depth_var;
     r.means3D = means3D; r.view = viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
@@ -616,7 +697,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     b.focal_y = height / (2.0f * tan_fovy);
     b.focal_x = width / (2.0f * tan_fovx);
     b.sh_vec_ok = aligned16(shs) && aligned16(dL_dsh);
-    b.track_off = track_off; b.map_off = map_off; b.geom = geom; b.acc = sc.acc;
+    b.track_off = track_off; b.map_off = map_off; b.geom = geom; b.acc = sc.acc; b.clear_scratch = scratch_clean ? 1 : 0;
     b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor;
     b.dL_ddepth = dL_ddepth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
     b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part; b.ticket = sc.ticket; b.dL_dview = dL_dview;
@@ -637,6 +718,7 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     FwdCommon c{P, D, M, width, height, background, means3D, shs, colors_precomp, opacities, scales, rotations,
                 cov3D_precomp, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
                 out_color, out_depth, nullptr, out_uncertainty, gt_depth, nullptr, nullptr, nullptr, radii};
+    ArmedReport armed(width, height, P);  // (dgr_status_arm: completed from the host on every path that enqueues no binning kernel)
     int rc = check_common(c);
     if (rc) return rc;
     if (P == 0) {
@@ -655,7 +737,7 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     dgr::BinningView bin = dgr::carve_binning(binning_buffer, (size_t)binning_capacity);
     const int mode = presized_count_mode(width, height, binning_capacity);
     if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer, mode))) return rc;
-    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer))) return rc;
+    if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer, &armed))) return rc;
     if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
     return DGR_OK;
 }
@@ -722,6 +804,8 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     (void)dpixel_dndcs; (void)dgndcs_dviewmatrix; (void)dpixel_dinvcovs; (void)dgc_invcovs_dT; (void)ddepth_dndcs;
     (void)ddepth_dinvcovs;
     hipStream_t st = (hipStream_t)stream;
+    const bool scratch_clean = g_scratch_clean_armed;
+    g_scratch_clean_armed = false;
     if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
     if (P == 0) {
         HIP_TRY(hipMemsetAsync(dL_dview, 0, 16 * 4, st));
@@ -735,11 +819,11 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
-    { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, st)); }
+    if (!scratch_clean) { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, st)); }
 
     dgr::RenderBwdFullArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
-    r.sched = img.tile_sched; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
+    r.sched = img.tile_sched; r.ranges = img.ranges; r.sched_flag = img.cursor + 3; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
     r.gt_depth = gt_depth; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.first_contrib = img.first_contrib;
     r.dL_dpix = dL_dpix; r.dL_depths = dL_depths; r.dL_duncertainties = dL_duncertainties; r.acc = sc.acc;
     { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_full(r, g_alpha_mode.load(), st)); }
@@ -751,7 +835,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     b.focal_y = height / (2.0f * tan_fovy);
     b.focal_x = width / (2.0f * tan_fovx);
     b.sh_vec_ok = aligned16(shs) && aligned16(dL_dsh);
-    b.track_off = 0; b.map_off = 0; b.full_variant = 1; b.geom = geom; b.acc = sc.acc;
+    b.track_off = 0; b.map_off = 0; b.full_variant = 1; b.geom = geom; b.acc = sc.acc; b.clear_scratch = scratch_clean ? 1 : 0;
     b.dL_dmean2D = dL_dmean2D; b.dL_dconic = dL_dconic; b.dL_dopacity = dL_dopacity; b.dL_dcolor = dL_dcolor;
     b.dL_ddepth = dL_dgau_depth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
     b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part; b.ticket = sc.ticket; b.dL_dview = dL_dview;
@@ -892,7 +976,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
         }
         dgr::RenderBwdLightArgs r{};
         r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
-        r.sched = img.tile_sched; r.point_list = (const uint32_t*)w.binning_buffer; r.rec = geom.rec; r.bg = background;
+        r.sched = img.tile_sched; r.ranges = img.ranges; r.sched_flag = img.cursor + 3; r.point_list = (const uint32_t*)w.binning_buffer; r.rec = geom.rec; r.bg = background;
         r.gt_depth = w.gt_depth; r.alphas = w.alphas; r.n_contrib = img.n_contrib; r.dL_dpix = w.dL_dpix;
         r.dL_dpix_depth = w.dL_dpix_depth; r.dL_dpix_median = w.dL_dpix_median_depth; r.dL_dpix_var = w.dL_dpix_depth_var;
         r.means3D = means3D; r.view = w.viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
@@ -1021,40 +1105,88 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
     return DGR_OK;
 }
 
-long dgr_status_post(void* stream, const int* device_status) {
-    if (!device_status) { g_last_error = "dgr_status_post: NULL"; return DGR_ERR_BAD_ARGUMENT; }
+// a free slot of the current device (g_status_mu held); creates one when all are busy
+static long status_slot_acquire() {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(g_status_mu);
-    long id = -1;
     for (size_t i = 0; i < g_status_slots.size(); i++)
-        if (!g_status_slots[i].busy && g_status_slots[i].device == dev) { id = (long)i; break; }
-    if (id < 0) {
-        StatusSlot sl;
-        HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-        HIP_TRY(hipHostMalloc((void**)&sl.pinned, 4 * sizeof(int), hipHostMallocDefault));
-        sl.device = dev;
-        g_status_slots.push_back(sl);
-        id = (long)g_status_slots.size() - 1;
-    }
+        if (!g_status_slots[i].busy && g_status_slots[i].device == dev) return (long)i;
+    StatusSlot sl;
+    HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&sl.pinned, 8 * sizeof(int), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void**)&sl.pinned_dev, sl.pinned, 0));
+    HIP_TRY(hipMalloc((void**)&sl.ws, 16 * sizeof(uint32_t)));
+    HIP_TRY(hipMemset(sl.ws, 0, 16 * sizeof(uint32_t)));  // (once per slot; the kernels keep the words zero between forwards)
+    for (int i = 0; i < 8; i++) sl.pinned[i] = 0;
+    sl.device = dev;
+    g_status_slots.push_back(sl);
+    return (long)g_status_slots.size() - 1;
+}
+
+long dgr_status_post(void* stream, const int* device_status) {
+    if (!device_status) { g_last_error = "dgr_status_post: NULL"; return DGR_ERR_BAD_ARGUMENT; }
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    const long id = status_slot_acquire();
+    if (id < 0) return id;
     StatusSlot& sl = g_status_slots[(size_t)id];
     HIP_TRY(hipMemcpyAsync(sl.pinned, device_status, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipEventRecord(sl.ev, (hipStream_t)stream));
     sl.busy = true;
+    sl.mapped = false;
+    return id;
+}
+
+long dgr_status_arm(void) {
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    if (g_armed_slot >= 0) {  // armed twice without a forward in between: the first arm is withdrawn
+        g_status_slots[(size_t)g_armed_slot].busy = false;
+        g_armed_slot = -1;
+    }
+    const long id = status_slot_acquire();
+    if (id < 0) return id;
+    StatusSlot& sl = g_status_slots[(size_t)id];
+    if (++g_status_tag == 0u) ++g_status_tag;
+    sl.tag = g_status_tag;
+    sl.busy = true;
+    sl.mapped = true;
+    ((volatile int*)sl.pinned)[4] = 0;
+    g_armed_slot = id;
     return id;
 }
 
 int dgr_status_poll(long ticket, int wait, int* host_status4) {
     hipEvent_t ev;
     int* pinned;
+    bool mapped;
+    uint32_t tag;
     {
         std::lock_guard<std::mutex> lk(g_status_mu);
         if (ticket < 0 || (size_t)ticket >= g_status_slots.size() || !g_status_slots[(size_t)ticket].busy || !host_status4) {
             g_last_error = "dgr_status_poll: bad ticket";
             return DGR_ERR_BAD_ARGUMENT;
         }
+        if (ticket == g_armed_slot) { g_last_error = "dgr_status_poll: the slot is armed and no forward has taken it"; return DGR_ERR_BAD_ARGUMENT; }
         ev = g_status_slots[(size_t)ticket].ev;
         pinned = g_status_slots[(size_t)ticket].pinned;
+        mapped = g_status_slots[(size_t)ticket].mapped;
+        tag = g_status_slots[(size_t)ticket].tag;
+    }
+    if (mapped) {  // written by the forward's binning kernel, the tag last: nothing to wait for on a stream
+        const volatile int* w = pinned;
+        if (w[4] != (int)tag) {
+            if (!wait) return 0;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (w[4] != (int)tag)  // (as wait_event_spinning: poll for a while, then stop burning the core)
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        int word[8];
+        for (int i = 0; i < 8; i++) word[i] = w[i];
+        for (int i = 0; i < 4; i++) host_status4[i] = word[i];
+        std::lock_guard<std::mutex> lk(g_status_mu);
+        note_schedule_hint(g_status_slots[(size_t)ticket], word);
+        g_status_slots[(size_t)ticket].busy = false;
+        return 1;
     }
     if (wait) {
         HIP_TRY(wait_event_spinning(ev));
@@ -1073,6 +1205,11 @@ int dgr_stream_is_capturing(void* stream) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return st == hipStreamCaptureStatusActive ? 1 : 0;
+}
+
+int dgr_backward_scratch_clean_arm(void) {
+    g_scratch_clean_armed = true;
+    return DGR_OK;
 }
 
 int dgr_early_status_arm(void) {
@@ -1097,6 +1234,7 @@ int dgr_set_option(const char* name, int value) {
     const std::string n(name ? name : "");
     if (n == "blend_wgs_per_cu") { g_blend_wgs_per_cu.store((value >= 3 && value <= 7) ? value : 0); return DGR_OK; }
     if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }
+    if (n == "tile_schedule") { g_tile_schedule.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
     if (n == "fast_alpha") {
         g_alpha_mode.store(value ? 1 : 0);
         return DGR_OK;
@@ -1112,6 +1250,7 @@ int dgr_get_option(const char* name) {
     const std::string n(name ? name : "");
     if (n == "blend_wgs_per_cu") return g_blend_wgs_per_cu.load();
     if (n == "tight_cull") return g_tight_cull.load();
+    if (n == "tile_schedule") return g_tile_schedule.load();
     if (n == "fast_alpha") return g_alpha_mode.load();
     if (n == "lds_count") return g_lds_count.load();
     if (n == "profile_every") return g_profile_every.load();
@@ -1200,6 +1339,7 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
     }
     if (n == "ranges") return copy(img.ranges, 8 * tiles) ? -1 : (long)(2 * tiles);
     if (n == "tile_sched") return copy(img.tile_sched, 16 * tiles) ? -1 : (long)(4 * tiles);
+    if (n == "sched_flag") return copy(img.cursor + 3, 4) ? -1 : 1L;  // 1: this frame's blend kernels walk tile_sched, 0: the static band map
     if (n == "n_contrib") return copy(img.n_contrib, 4 * N) ? -1 : (long)N;
     if (n == "n_valid") return copy(img.n_valid, 4 * N) ? -1 : (long)N;
     if (n == "final_T") return copy(img.final_T, 4 * N) ? -1 : (long)N;

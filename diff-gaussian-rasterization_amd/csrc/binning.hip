@@ -30,7 +30,8 @@ constexpr int SORT_THREADS = 256;
 constexpr int SORT_LDS_MAX = 2048;  // keys per tile sorted in LDS (16 KB: 8 workgroups per CU; with 4096 keys = 32 KB only
                                     // 5 fit and the latency-bound sort took 37 us instead of 30); larger tiles sort in global memory
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img, int tiles, int grid_x, int capacity, int fused) {
+__global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img, int tiles, int grid_x, int capacity, int fused,
+                                                                  int sched_on, StatusReport rep) {
     const int pairs_x = (grid_x + 1) >> 1;
     // tile i = (ty, tx): half tx & 1 of the 64-bit pair counter (ty, tx / 2), one pair per cache line (count_rank)
     auto count_of = [&](int i) {
@@ -94,10 +95,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img,
         img.status[0] = (int)total;
         img.status[1] = overflow ? 1 : 0;
         img.cursor[2] = (uint32_t)capacity;
+        img.cursor[3] = (uint32_t)sched_on;
         if (fused) {  // (otherwise scan_blocks initialised them)
             img.status[2] = (int)img.cursor[1];  // prefiltered violation
             img.status[3] = 0;                   // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
         }
+        // (this path does not track the longest list: "unknown" keeps the tile schedule on)
+        if (rep.host) report_status(rep, (int)total, overflow ? 1 : 0, fused ? (int)img.cursor[1] : img.status[2], 0x7fffffffu);
     }
 }
 
@@ -377,8 +381,9 @@ hipError_t launch_tile_schedule(ImageView img, int tiles, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, hipStream_t stream) {
-    launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, grid_x, capacity, fused ? 1 : 0);
+hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, bool sched_on, StatusReport rep,
+                             hipStream_t stream) {
+    launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, grid_x, capacity, fused ? 1 : 0, sched_on ? 1 : 0, rep);
     return hipGetLastError();
 }
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,

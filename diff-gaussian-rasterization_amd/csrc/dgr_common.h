@@ -75,9 +75,10 @@ __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
 
 struct ImageView {
     int* status;          // [4] {num_rendered, overflow, prefiltered violation, reserved}
-    uint32_t* cursor;     // [3] presized path: {instances handed out so far (preprocess_fwd's blocks bump it to place their
+    uint32_t* cursor;     // [4] presized path: {instances handed out so far (preprocess_fwd's blocks bump it to place their
                           //     ranks), prefiltered violation seen}; cleared together with the tile counters.
-                          //     [2] = capacity the binning buffer was carved with (scan_tiles)
+                          //     [2] = capacity the binning buffer was carved with (scan_tiles / bin_tiles)
+                          //     [3] = 1: tile_sched holds this frame's schedule, 0: the blend kernels use the static band map
     uint32_t* tile_count; // [tiles * DGR_COUNT_STRIDE] instances per tile (histogram filled by count_rank), one per line
     uint2* ranges;        // [tiles] {start, end} into point_list
     uint4* tile_sched;    // [tiles] the blend kernels' schedule: workgroup b works on tile .x, whose list is [.y, .z) --
@@ -105,6 +106,33 @@ __host__ __device__ inline ImageView carve_image(char* base, int W, int H) {
     v.first_contrib = (uint32_t*)(base + o); o = align_up(o + N * 4, 256);
     v.bytes = o;
     return v;
+}
+
+// bijective XCD-aware remap (workgroup b runs on XCD b % 8): XCD x gets a contiguous run of the n items
+__host__ __device__ inline int xcd_contiguous(int b, int n) {
+    const int xcd = b & 7, local = b >> 3;
+    const int q = n >> 3, r = n & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}
+
+// Where a forward reports its status word when a status slot is armed (api.hip: dgr_status_arm): `host` = pinned host memory
+// mapped into the device's address space, written by the binning kernel that completes the word -- {num_rendered, overflow,
+// prefiltered violation, 0, tag, longest tile list} with `tag` last -- so that the host reads it without a copy, an event or
+// a wait; `ws` = three device words owned by the slot, zero between forwards (bin_tiles: longest list, tickets, flag).
+struct StatusReport {
+    int* host;      // NULL: no report
+    uint32_t tag;
+    uint32_t* ws;
+};
+__device__ __forceinline__ void report_status(const StatusReport& r, int total, int overflow, int flag, uint32_t longest) {
+    __hip_atomic_store(r.host + 0, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(r.host + 1, overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(r.host + 2, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(r.host + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(r.host + 5, (int)longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the word is on its way before the tag that announces it
+    __hip_atomic_store(r.host + 4, (int)r.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct BinningView {

@@ -119,7 +119,9 @@ struct PreprocessBwdArgs {
     int full_variant;   // 1: semantics of F/cuda_rasterizer/backward.cu (computeCov2DCUDA assigns + depth term, pose from
                         //    dgc_dCampos / colour-only ndc sums / front-most depth sums); 0: light
     GeometryView geom;
-    const float* acc;   // [P,16] sums written by the blend backward
+    float* acc;         // [P,16] sums written by the blend backward
+    int clear_scratch;  // 1: leave the scratch as it was found -- all zero: every accumulator row read is cleared by its reader and
+                        //    the block that finishes the pose sum clears the buckets and the ticket (dgr_backward_scratch_clean_arm)
     float* dL_dmean2D;  // [P,3]
     float* dL_dconic;   // [P,4] optional
     float* dL_dopacity; // [P]
@@ -157,6 +159,8 @@ struct PreprocessBwdBatchArgs {
 struct RenderFwdLightArgs {
     int W, H, grid_x, grid_y;
     const uint4* sched;    // [tiles] {tile, list start, list end, -} of workgroup b (ImageView::tile_sched)
+    const uint2* ranges;   // [tiles] ... and without a schedule (ImageView::cursor[3] == 0): block -> tile by the static XCD band
+    const uint32_t* sched_flag;  // map, list from the range table (render_common.h: blend_slot)
     uint32_t* point_list;  // read; the kernel writes the contribution tags into the top bits
     const float4* rec;
     const float* bg;
@@ -174,6 +178,8 @@ struct RenderFwdLightArgs {
 struct RenderBwdLightArgs {
     int W, H, grid_x, grid_y;
     const uint4* sched;    // [tiles] {tile, list start, list end, -} of workgroup b (ImageView::tile_sched)
+    const uint2* ranges;   // [tiles] ... and without a schedule (ImageView::cursor[3] == 0): block -> tile by the static XCD band
+    const uint32_t* sched_flag;  // map, list from the range table (render_common.h: blend_slot)
     const uint32_t* point_list;
     const float4* rec;
     const float* bg;
@@ -193,6 +199,8 @@ struct RenderBwdLightArgs {
 struct RenderFwdFullArgs {
     int W, H, grid_x, grid_y;
     const uint4* sched;    // [tiles] {tile, list start, list end, -} of workgroup b (ImageView::tile_sched)
+    const uint2* ranges;   // [tiles] ... and without a schedule (ImageView::cursor[3] == 0): block -> tile by the static XCD band
+    const uint32_t* sched_flag;  // map, list from the range table (render_common.h: blend_slot)
     uint32_t* point_list;  // read; the kernel writes the contribution tags into the top bits
     const float4* rec;
     const float* bg;
@@ -209,6 +217,8 @@ struct RenderFwdFullArgs {
 struct RenderBwdFullArgs {
     int W, H, grid_x, grid_y;
     const uint4* sched;    // [tiles] {tile, list start, list end, -} of workgroup b (ImageView::tile_sched)
+    const uint2* ranges;   // [tiles] ... and without a schedule (ImageView::cursor[3] == 0): block -> tile by the static XCD band
+    const uint32_t* sched_flag;  // map, list from the range table (render_common.h: blend_slot)
     const uint32_t* point_list;
     const float4* rec;
     const float* bg;
@@ -254,7 +264,8 @@ hipError_t launch_mark_visible(int P, const float* means, const float* view, uin
 // binning: tile_count -> ranges (+ total in status[0], overflow in status[1]); emit keys; sort tiles
 // `fused`: preprocess_fwd counted (no scan_blocks ran): scan_tiles then also fills status[2] (from the cursor's violation
 // word) and status[3]
-hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, hipStream_t stream);
+hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, bool sched_on, StatusReport rep,
+                             hipStream_t stream);
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,
                              hipStream_t stream);
 hipError_t launch_scan_blocks(int P, GeometryView geom, ImageView img, hipStream_t stream);
@@ -268,7 +279,7 @@ int segment_shift(int W, int H, int capacity);  // log2 of the tiles per segment
 hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, SegmentTables tb, int grid_x, int grid_y, int seg_shift,
                                int capacity, bool prefixed, hipStream_t stream);
 hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
-                            int seg_shift, int capacity, bool prefixed, hipStream_t stream);
+                            int seg_shift, int capacity, bool prefixed, bool sched_on, StatusReport rep, hipStream_t stream);
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);
 // ranges -> the blend kernels' schedule (img.tile_sched): tiles by descending list length, so that the longest lists
 // start first and every XCD gets its share of a cluster

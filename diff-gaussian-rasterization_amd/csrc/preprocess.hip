@@ -885,16 +885,22 @@ __device__ __forceinline__ void pose_add_partial(double (*red)[12], double* pose
 }
 // Step 3 (wave 0, once its adds are acknowledged and it has drawn ticket `t`): the block that draws the last ticket finds
 // every partial delivered and finishes the sum -- no separate reduction kernel, no fence that writes back an L2.
-__device__ __forceinline__ void pose_finish_if_last(uint32_t t, const double* pose_part, float* dL_dview) {
+// `clear` (resident scratch, dgr_backward_scratch_clean_arm): the finisher leaves buckets and ticket as it found them at the start
+// of the call -- zero -- for the next backward that uses this scratch.
+__device__ __forceinline__ void pose_finish_if_last(uint32_t t, double* pose_part, float* dL_dview, uint32_t* ticket = nullptr,
+                                                    bool clear = false) {
     if (t != gridDim.x - 1) return;
     if (threadIdx.x < 16) {
         float out = 0.0f;
         if (threadIdx.x < 12) {
             double tot = 0.0;
-            for (int g = 0; g < DGR_POSE_BUCKETS; g++)  // (agent-scope loads: served by L2, where the adds were performed)
+            for (int g = 0; g < DGR_POSE_BUCKETS; g++) {  // (agent-scope loads: served by L2, where the adds were performed)
                 tot += __hip_atomic_load(pose_part + (size_t)g * 12 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (clear) __hip_atomic_store(pose_part + (size_t)g * 12 + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             out = (float)tot;
         }
+        if (clear && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // slot order v0,v1,v2,v4,v5,v6,v8,v9,v10,v12,v13,v14 (L/cuda_rasterizer/backward.cu:723)
         if (threadIdx.x < 12) dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
         if (threadIdx.x < 4) dL_dview[threadIdx.x * 4 + 3] = 0.0f;
@@ -903,7 +909,7 @@ __device__ __forceinline__ void pose_finish_if_last(uint32_t t, const double* po
 // One view: the delivery is wave 0's alone (no workgroup barrier after the first): two L2 round trips -- the bucket adds,
 // then the ticket -- during which the other three waves would only hold their registers.
 __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], double* pose_part, uint32_t* ticket, float* dL_dview,
-                                                  double (*red)[12]) {
+                                                  double (*red)[12], bool clear = false) {
     pose_rows_to_lds(pose, red);
     __syncthreads();
     if (threadIdx.x >= 64) return;
@@ -911,7 +917,7 @@ __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], doubl
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the adds are acknowledged before the ticket is taken
     uint32_t t = 0u;
     if (threadIdx.x == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pose_finish_if_last((uint32_t)__builtin_amdgcn_readfirstlane((int)t), pose_part, dL_dview);
+    pose_finish_if_last((uint32_t)__builtin_amdgcn_readfirstlane((int)t), pose_part, dL_dview, ticket, clear);
 }
 
 // Fused per-Gaussian backward.  Order of the dL_dmean3D accumulation follows the reference's kernel
@@ -930,9 +936,10 @@ __global__ void __launch_bounds__(256, DGR_PPB_WAVES) preprocess_bwd_kernel(Prep
         // Every per-Gaussian input is requested up front, unconditionally (a culled Gaussian wastes ~130 bytes): behind
         // `if (vis)` / `if (do_map)` the loads formed a chain of three dependent round trips per wave, and this kernel
         // spends 60 % of its wave-cycles waiting for memory.
-        const float4* ap = reinterpret_cast<const float4*>(a.acc + (size_t)idx * DGR_ACC_STRIDE);
+        float4* ap = reinterpret_cast<float4*>(a.acc + (size_t)idx * DGR_ACC_STRIDE);
         const float4 a0 = ap[0], a1 = ap[1], a2 = ap[2], a3 = ap[3];  // (nontemporal loads here: 45 -> 49 us -- the rows sit in L2, where the blend's atomics left them)
         const int rad = a.radii[idx];
+
         const float3 m = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
         float c3[6];
         {
@@ -1042,6 +1049,13 @@ __global__ void __launch_bounds__(256, DGR_PPB_WAVES) preprocess_bwd_kernel(Prep
             a.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
         }
         if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
+        // Resident scratch: the reader clears the row it has read (only rows of visible Gaussians were ever touched by the blend
+        // kernel's atomics).  Down here, with the kernel's other stores: right behind the loads of the row the stores put a wait
+        // for those loads in front of every other input's request (44 -> 75 us at config 3).
+        if (a.clear_scratch && vis) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            ap[0] = z; ap[1] = z; ap[2] = z; ap[3] = z;
+        }
     }
 
     if (a.track_off) {  // no pose gradient asked for: zeros (L/rasterize_points.cu:186)
@@ -1049,7 +1063,7 @@ __global__ void __launch_bounds__(256, DGR_PPB_WAVES) preprocess_bwd_kernel(Prep
         return;
     }
     __shared__ double red[16][12];
-    pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red);
+    pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red, a.clear_scratch != 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1066,7 +1080,7 @@ __device__ __forceinline__ PreprocessBwdArgs batch_view_args(const PreprocessBwd
     PreprocessBwdArgs a = b.base;
     const BwdViewPart& p = b.v[v];
     a.view = p.view; a.proj = p.proj; a.campos = p.campos; a.perspec = p.perspec; a.radii = p.radii; a.geom = p.geom;
-    a.acc = p.acc; a.dL_dmean2D = p.dL_dmean2D; a.pose_part = p.pose_part; a.ticket = p.ticket; a.dL_dview = p.dL_dview;
+    a.acc = const_cast<float*>(p.acc); a.dL_dmean2D = p.dL_dmean2D; a.pose_part = p.pose_part; a.ticket = p.ticket; a.dL_dview = p.dL_dview;
     return a;
 }
 __global__ void __launch_bounds__(256, DGR_BWD_BATCH_WAVES) preprocess_bwd_batch_kernel(PreprocessBwdBatchArgs b) {

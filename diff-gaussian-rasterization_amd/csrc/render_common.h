@@ -8,6 +8,20 @@
 
 namespace dgr {
 
+// Workgroup b of a blend kernel -> {tile, list start, list end}.  With a schedule (tile_schedule_kernel, binning.hip: classes of
+// long lists first, neighbours on one XCD) that is one 16-byte entry.  A frame whose lists are even needs none -- the schedule
+// then is the static map with extra steps: a launch, 11 us in front of the blend at 1080p, and neighbours spread a little --
+// so the forward skips the kernel (api.hip: the policy) and the workgroups fall back on the band map of rounds 1-5: workgroup
+// b runs on XCD b % 8, every XCD takes a contiguous band of the image (neighbouring tiles share the records in its L2).
+// Which of the two a frame uses is recorded in its image state by the binning kernel (cursor[3]) for forward and backward alike.
+__device__ __forceinline__ uint4 blend_slot(const uint4* __restrict__ sched, const uint2* __restrict__ ranges,
+                                            const uint32_t* __restrict__ sched_flag, int tiles) {
+    if (__builtin_amdgcn_readfirstlane((int)*sched_flag)) return sched[blockIdx.x];
+    const int tile = xcd_contiguous((int)blockIdx.x, tiles);
+    const uint2 r = ranges[tile];
+    return make_uint4((uint32_t)tile, r.x, r.y, 0u);
+}
+
 // wave-uniform "any lane": one v_cmp into an SGPR pair + s_cmp (HIP's __any() goes through v_cndmask + v_cmp)
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 

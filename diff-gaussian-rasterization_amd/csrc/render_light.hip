@@ -66,7 +66,7 @@ template <int AM>
 __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
     __shared__ StagedFwd sf;
     Staged& s = sf.f;
-    const uint4 slot = a.sched[blockIdx.x];  // {tile, list start, list end}: heaviest tile first (binning.hip)
+    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -186,7 +186,7 @@ template <int AM, bool DO_MAP, bool DO_POSE>
 __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
     __shared__ StagedBwd sb;
     StagedT<BWD_NB>& s = sb.f;
-    const uint4 slot = a.sched[blockIdx.x];  // {tile, list start, list end}: heaviest tile first (binning.hip)
+    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;

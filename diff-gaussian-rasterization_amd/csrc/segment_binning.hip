@@ -248,13 +248,40 @@ __device__ __forceinline__ void sort_tile_in_wave(uint64_t* src, int n, uint32_t
     }
 }
 
-// bijective XCD-aware remap (block b runs on XCD b % 8): XCD x gets a contiguous run of segments
-__device__ __forceinline__ int xcd_contiguous(int b, int n) {
-    const int xcd = b & 7, local = b >> 3;
-    const int q = n >> 3, r = n & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + local;
-}
+// (xcd_contiguous, dgr_common.h: XCD x gets a contiguous run of segments)
+// A workgroup's part in the frame's status report (StatusReport, dgr_common.h).  note(): the longest of its tile lists into
+// ws[0] and the `prefiltered` flag into ws[2], atomics without a return value, issued where the counts are known and not waited
+// for.  When thread 0 leaves the kernel -- whichever return it takes: the destructor -- it draws a ticket from ws[1]; the
+// workgroup that draws the last of the `nseg` tickets has every other one's contribution in front of it (the atomics are
+// performed at L2, agent scope, and acknowledged before the ticket), writes the word to the host and leaves the three words
+// zero for the slot's next forward.  (The ticket in the middle of the kernel, in front of the sorts, cost wave 0 of every
+// workgroup two memory round trips: bin_tiles 27 -> 37 us at config 3.)
+struct ReportAtExit {
+    StatusReport rep;
+    int nseg;
+    bool mine;  // thread 0 of a segment's own workgroup (helpers of dense segments do not report)
+    uint32_t total = 0;
+    bool overflow = false;
+    __device__ __forceinline__ ReportAtExit(const StatusReport& r, int n, bool m) : rep(r), nseg(n), mine(m && r.host != nullptr) {}
+    __device__ __forceinline__ void note(uint32_t tmax, uint32_t flag, uint32_t tot, bool ovf) {
+        total = tot; overflow = ovf;
+        if (!mine) return;
+        if (tmax) __hip_atomic_fetch_max(rep.ws + 0, tmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (flag) __hip_atomic_fetch_or(rep.ws + 2, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ ~ReportAtExit() {
+        if (!mine) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(rep.ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t != (uint32_t)nseg - 1u) return;
+        const uint32_t longest = __hip_atomic_load(rep.ws + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t any = __hip_atomic_load(rep.ws + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rep.ws + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rep.ws + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rep.ws + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        report_status(rep, (int)total, overflow ? 1 : 0, (int)any, longest);
+    }
+};
 
 template <bool LONG_LISTS>
 __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img, uint32_t* __restrict__ point_list,
@@ -262,7 +289,8 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
                                                                   const uint64_t* __restrict__ pair_keys,
                                                                   const uint8_t* __restrict__ pair_cov,
                                                                   const uint32_t* __restrict__ block_tiles, int nblocks, int nwg,
-                                                                  int grid_x, int grid_y, int seg_shift, int capacity, int prefixed) {
+                                                                  int grid_x, int grid_y, int seg_shift, int capacity, int prefixed,
+                                                                  int sched_on, StatusReport rep) {
     __shared__ K2Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int SEG = 1 << seg_shift;
@@ -278,6 +306,7 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     const int ty = s / sgx, sx = s - ty * sgx;
     const int ntl = min(SEG, grid_x - sx * SEG);             // tiles of this segment (the last one of a row may be short)
     const int tile0 = ty * grid_x + sx * SEG;
+    ReportAtExit tail(rep, nseg, part == 0 && tid == 0);
 
     // ---- list start, size of the segment, grand total: column sums of the per-workgroup running counts; the runs
     uint32_t before = 0, upto = 0, total = 0, flag = 0;
@@ -315,9 +344,11 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
             img.status[3] = 0;          // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
         }
         img.cursor[2] = (uint32_t)capacity;
+        img.cursor[3] = (uint32_t)sched_on;
     }
     if (overflow || gcount == 0u) {  // (empty tiles keep {0, 0}: the reference clears the table and writes only tiles that own instances)
         if (part == 0 && tid < ntl) img.ranges[tile0 + tid] = make_uint2(0u, 0u);
+        tail.note(0u, flag, total, overflow);
         return;
     }
     const uint32_t n_pairs = block_scan<K2_THREADS>(sh.run_start, nwg + 1, false, sh.wsum, tid);  // run_start[w] = pairs of the runs < w
@@ -403,6 +434,7 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     uint32_t tmax = 0;
 #pragma unroll
     for (int t = 0; t < SEG_MAX; t++) tmax = max(tmax, sh.tcnt[t]);
+    tail.note(tmax, flag, total, overflow);
     if (!dense) {
         // ---- pass B: the segment's keys into LDS, grouped by tile
 #pragma unroll
@@ -520,14 +552,15 @@ hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, Segmen
     return hipGetLastError();
 }
 hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
-                            int seg_shift, int capacity, bool prefixed, hipStream_t stream) {
+                            int seg_shift, int capacity, bool prefixed, bool sched_on, StatusReport rep, hipStream_t stream) {
     const int nseg = grid_y * ((grid_x + (1 << seg_shift) - 1) >> seg_shift);
     // expected entries per tile, from the capacity the caller sized the binning buffer with (segment_shift() uses the same)
     const long tiles = (long)grid_x * grid_y;
     const bool long_lists = tiles > 0 && (long)capacity / tiles > 900;
     const int helpers = (1 << seg_shift) / 4 - 1;  // per segment (bin_tiles_kernel)
     launch(long_lists ? bin_tiles_kernel<true> : bin_tiles_kernel<false>, dim3(nseg * (1 + helpers)), dim3(K2_THREADS), stream, img, bin.point_list, bin.keys, tb, bin.pair_keys, bin.pair_cov,
-           geom.block_tiles, (P + 255) / 256, segment_binning_workgroups(P), grid_x, grid_y, seg_shift, capacity, prefixed ? 1 : 0);
+           geom.block_tiles, (P + 255) / 256, segment_binning_workgroups(P), grid_x, grid_y, seg_shift, capacity, prefixed ? 1 : 0,
+           sched_on ? 1 : 0, rep);
     return hipGetLastError();
 }
 

@@ -52,8 +52,10 @@ _SIGS = {
     "dgr_last_error": (C.c_char_p, []),
     "dgr_status_post": (C.c_long, [_vp, _vp]),
     "dgr_status_poll": (_i, [C.c_long, _i, _vp]),
+    "dgr_status_arm": (C.c_long, []),
     "dgr_stream_is_capturing": (_i, [_vp]),
     "dgr_early_status_arm": (_i, []),
+    "dgr_backward_scratch_clean_arm": (_i, []),
     "dgr_early_status_wait": (_i, [_vp]),
     "dgr_pose_forward": (_i, [_vp] * 7),
     "dgr_pose_backward": (_i, [_vp] * 5),

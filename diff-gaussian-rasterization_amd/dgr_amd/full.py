@@ -174,15 +174,7 @@ class _CompiledC:
                             gt_depth, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered):
         P, H, W = means3D.size(0) if means3D.dim() else 0, int(image_height), int(image_width)
         key = (means3D.device.index, P, H, W)
-        cap = _capacity_cache.get(key, 0)
-        if os.environ.get("DGR_FORWARD_MODE", "presized") == "callback" or P == 0:
-            mode, use = 0, 0
-        elif _light._sync_mode() == "lazy" and cap > 0:
-            while len(_light._pending_status) > _light.lazy_depth() and not torch.cuda.is_current_stream_capturing():
-                _light._check_oldest()
-            mode, use = 2, int(cap * 1.5) + 4096
-        else:
-            mode, use = 1, (int(cap * 1.25) + 4096 if cap else 4 * P + 4096)
+        mode, use, cap = _light._binning_policy(key, P)
         (rendered, related, ticket, _, status, color, depth, unc, radii, geom, binning, img) = _CompiledC.ext.full_forward(
             background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix,
             gt_depth, projmatrix, float(tan_fovx), float(tan_fovy), H, W, sh, int(degree), campos, bool(prefiltered), use, mode)
@@ -220,8 +212,35 @@ if _light._C is getattr(_light, "_CompiledC", None):  # the light module decided
     _C = _CompiledC
 
 
+def _rasterize_compiled(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
+                        gt_depth, rs):
+    """`_RasterizeGaussians.apply` through the autograd node compiled into the extension (csrc/torch_ext.cpp: FullNode); see
+    dgr_amd.light._rasterize_compiled."""
+    P, H, W = (means3D.size(0) if means3D.dim() == 2 else 0), rs.image_height, rs.image_width
+    key = (means3D.device.index, P, H, W)
+    mode, use, cap = _light._binning_policy(key, P)
+    out, rendered, related, ticket, _, status = _CompiledC.ext.full_apply(
+        means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix, gt_depth, rs.bg,
+        rs.projmatrix, rs.campos, rs.perspec_matrix, rs.scale_modifier, rs.tanfovx, rs.tanfovy, H, W, rs.sh_degree,
+        rs.prefiltered, use, mode)
+    if mode == 2:
+        if ticket >= 0:
+            _light._pending_status.append((ticket, key))
+        else:
+            import weakref
+            _light._captured_status.append(weakref.ref(status))
+            _light._capture_keepalive.append(status)
+    elif mode == 1:
+        _capacity_cache[key] = max(cap, rendered)
+        _light._last_status[key] = [rendered, 0, 0, related]
+    return tuple(out)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         viewmatrix, gt_depth, raster_settings):
+    if _C is _CompiledC and _light._USE_NODE:
+        return _rasterize_compiled(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                   viewmatrix, gt_depth, raster_settings)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, viewmatrix, gt_depth, raster_settings)
 
@@ -362,15 +381,15 @@ class GaussianRasterizer(nn.Module):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
         if shs is None:
-            shs = torch.Tensor([])
+            shs = _light._EMPTY
         if colors_precomp is None:
-            colors_precomp = torch.Tensor([])
+            colors_precomp = _light._EMPTY
         if scales is None:
-            scales = torch.Tensor([])
+            scales = _light._EMPTY
         if rotations is None:
-            rotations = torch.Tensor([])
+            rotations = _light._EMPTY
         if cov3D_precomp is None:
-            cov3D_precomp = torch.Tensor([])
+            cov3D_precomp = _light._EMPTY
 
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    viewmatrix, gt_depth, raster_settings)

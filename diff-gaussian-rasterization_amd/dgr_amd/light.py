@@ -141,12 +141,18 @@ _post_backward_lock = threading.Lock()
 
 def _set_post_backward_wait(stream, event):
     with _post_backward_lock:
-        _post_backward_waits[int(stream.cuda_stream)] = (stream, event)
+        _post_backward_waits[int(stream.cuda_stream)] = (stream, event)  # (also keeps both objects alive)
+    if _CompiledC.ext is not None:  # the compiled autograd node consumes the wait inside the engine, without Python
+        _CompiledC.ext.set_post_backward_wait(int(stream.cuda_stream), int(event.cuda_event))
 
 
 def _drop_post_backward_wait(stream):
+    if not _post_backward_waits:
+        return
     with _post_backward_lock:
         _post_backward_waits.pop(int(stream.cuda_stream), None)
+    if _CompiledC.ext is not None:
+        _CompiledC.ext.drop_post_backward_wait(int(stream.cuda_stream))
 
 
 def _consume_post_backward_wait():
@@ -388,15 +394,7 @@ class _CompiledC:
         ext = _CompiledC.ext
         P, H, W = means3D.size(0) if means3D.dim() else 0, int(image_height), int(image_width)
         key = (means3D.device.index, P, H, W)
-        cap = _capacity_cache.get(key, 0)
-        if os.environ.get("DGR_FORWARD_MODE", "presized") == "callback" or P == 0:
-            mode, use = 0, 0
-        elif _sync_mode() == "lazy" and cap > 0:
-            while len(_pending_status) > _LAZY_DEPTH and not torch.cuda.is_current_stream_capturing():
-                _check_oldest()  # status words of earlier calls have long completed: no stall
-            mode, use = 2, int(cap * 1.5) + 4096
-        else:
-            mode, use = 1, (int(cap * 1.25) + 4096 if cap else 4 * P + 4096)
+        mode, use, cap = _binning_policy(key, P)
         (rendered, ticket, _, status, color, depth, median, var, alpha, radii, geom, binning, img, unc, px) = ext.light_forward(
             background, means3D, colors, opacity, scales, rotations, float(scale_modifier), cov3D_precomp, viewmatrix,
             gt_depth, projmatrix, float(tan_fovx), float(tan_fovy), H, W, sh, int(degree), campos, bool(prefiltered),
@@ -430,6 +428,8 @@ class _CompiledC:
         return _CompiledC.ext.mark_visible(means3D, viewmatrix, projmatrix)
 
 
+# DGR_AUTOGRAD=python keeps the Python autograd.Function over the compiled `_C` (the A/B for profiles/host_breakdown.py)
+_USE_NODE = os.environ.get("DGR_AUTOGRAD", "compiled") != "python"
 _CtypesC = _C
 # (DGR_HIP_LIB selects another build of the C ABI for the ctypes loader; the extension is linked against the in-tree one)
 if os.environ.get("DGR_BINDING", "compiled") != "ctypes" and not os.environ.get("DGR_HIP_LIB"):
@@ -439,6 +439,42 @@ if os.environ.get("DGR_BINDING", "compiled") != "ctypes" and not os.environ.get(
         _C = _CompiledC
     except ImportError:  # the extension is optional (make -C diff-gaussian-rasterization_amd builds it); ctypes still binds the C ABI
         pass
+
+
+def _binning_policy(key, P):
+    """(mode, capacity) of the next forward of shape `key` = (device, P, H, W); see csrc/torch_ext.cpp: light_forward_core."""
+    cap = _capacity_cache.get(key, 0)
+    if os.environ.get("DGR_FORWARD_MODE", "presized") == "callback" or P == 0:
+        return 0, 0, cap
+    if _sync_mode() == "lazy" and cap > 0:
+        while len(_pending_status) > _LAZY_DEPTH and not torch.cuda.is_current_stream_capturing():
+            _check_oldest()  # status words of earlier calls have long completed: no stall
+        return 2, int(cap * 1.5) + 4096, cap
+    return 1, (int(cap * 1.25) + 4096 if cap else 4 * P + 4096), cap
+
+
+def _rasterize_compiled(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix,
+                        gt_depth, rs):
+    """`_RasterizeGaussians.apply` through the autograd node compiled into the extension (csrc/torch_ext.cpp: LightNode):
+    one Python -> C++ crossing per forward, the backward runs inside the autograd engine without the interpreter.  Same
+    inputs, outputs, saved state and gradients as the Python Function below, which stays for the debug path and the ctypes
+    binding."""
+    P, H, W = (means3D.size(0) if means3D.dim() == 2 else 0), rs.image_height, rs.image_width
+    key = (means3D.device.index, P, H, W)
+    mode, use, cap = _binning_policy(key, P)
+    out, rendered, ticket, _, status = _CompiledC.ext.light_apply(
+        means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, viewmatrix, gt_depth, rs.bg,
+        rs.projmatrix, rs.campos, rs.perspec_matrix, rs.scale_modifier, rs.tanfovx, rs.tanfovy, H, W, rs.sh_degree,
+        rs.prefiltered, rs.track_off, rs.map_off, use, mode)
+    if mode == 2:
+        if ticket >= 0:
+            _pending_status.append((ticket, key))
+        else:  # recorded into a hipGraph: nothing can be read back now
+            _captured_status.append(weakref.ref(status))
+            _capture_keepalive.append(status)
+    elif mode == 1:
+        _capacity_cache[key] = max(cap, rendered)
+    return tuple(out)
 
 
 def rasterize_gaussians(
@@ -454,6 +490,9 @@ def rasterize_gaussians(
     gt_depth,
     raster_settings,
 ):
+    if _C is _CompiledC and not raster_settings.debug and _USE_NODE:
+        return _rasterize_compiled(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                   viewmatrix, gt_depth, raster_settings)
     return _RasterizeGaussians.apply(
         means3D,
         means2D,
@@ -600,6 +639,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         return grads
 
 
+_EMPTY = torch.Tensor([])  # stands for "None" at the C++ boundary (L/__init__.py:223-232)
+
+
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
     image_width: int
@@ -644,16 +686,17 @@ class GaussianRasterizer(nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
+        # (the reference builds a fresh `torch.Tensor([])` per missing input and call; one shared empty tensor says the same)
         if shs is None:
-            shs = torch.Tensor([])
+            shs = _EMPTY
         if colors_precomp is None:
-            colors_precomp = torch.Tensor([])
+            colors_precomp = _EMPTY
         if scales is None:
-            scales = torch.Tensor([])
+            scales = _EMPTY
         if rotations is None:
-            rotations = torch.Tensor([])
+            rotations = _EMPTY
         if cov3D_precomp is None:
-            cov3D_precomp = torch.Tensor([])
+            cov3D_precomp = _EMPTY
 
         return rasterize_gaussians(
             means3D,

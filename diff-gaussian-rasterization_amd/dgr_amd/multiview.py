@@ -92,54 +92,74 @@ class ViewStreams:
         the whole backward instead: `views.before_backward(whole=True)`.)"""
 
     class _View:
-        def __init__(self, owner, stream, prev_done):
-            self.owner, self.stream, self.prev_done = owner, stream, prev_done
-            self.ctx = torch.cuda.stream(stream)
+        """The context manager next() hands out: makes one of the streams current for the block.  One object per stream,
+        reused (a view costs two `set_stream` calls on the host, no Stream / Event / context objects)."""
+
+        def __init__(self, owner, stream):
+            self.owner, self.stream = owner, stream
+            self.prev_stream = None   # the stream of the view issued before this one (before_backward orders after its end)
+            self.outer = None         # the caller's stream, restored on exit
 
         def __enter__(self):
             self.owner._current = self
-            return self.ctx.__enter__()
+            self.outer = torch.cuda.current_stream(self.owner.device)
+            torch.cuda.set_stream(self.stream)
+            return self.stream
 
         def __exit__(self, *exc):
-            done = torch.cuda.Event()
-            done.record(self.stream)
-            self.owner._done = done
+            self.owner._last_stream = self.stream
             self.owner._current = None
             light._drop_post_backward_wait(self.stream)  # (a backward that never reached the rasterizer leaves nothing behind)
-            return self.ctx.__exit__(*exc)
+            torch.cuda.set_stream(self.outer)
+            return False
 
-    def __init__(self, n=3, device=None):
+    def __init__(self, n=3, device=None, count_with_atomics=None):
+        if count_with_atomics is not None:  # (rounds 2-4 switched the binning path by the number of views in flight)
+            import warnings
+            warnings.warn("ViewStreams(count_with_atomics=...) is ignored: the segment binning serves every case",
+                          DeprecationWarning, stacklevel=2)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(n)))]
-        # lazy status mode: let the host run as many forward passes ahead of the status words as there are streams (light.py)
-        light.set_lazy_depth(max(light.lazy_depth(), len(self.streams)))
+        self._views = [ViewStreams._View(self, st) for st in self.streams]
+        # Lazy status mode: while views are in flight the host may run as many forward passes ahead of the status words as
+        # there are streams (light.py: _LAZY_DEPTH) -- raised by the first next(), put back by join(), so that code outside
+        # the in-flight window sees a binning overflow one or two calls late as documented, not n + 1.
+        self._saved_depth = None
         self._i = 0
-        self._fresh = set()  # streams already ordered after the caller's stream since the last join()
-        self._done = None    # event at the end of the most recent view
+        self._fresh = set()       # streams already ordered after the caller's stream since the last join()
+        self._last_stream = None  # stream of the most recent view (nothing else is enqueued on it until its next turn)
         self._current = None
 
     def next(self):
         """Context manager: the next stream.  The first use of a stream after construction or join() is ordered after
         everything the caller's stream has issued (input preparation, an optimiser step); later uses are not, so that
         views keep overlapping -- call join() before changing the inputs."""
+        if self._saved_depth is None:
+            self._saved_depth = light.set_lazy_depth(max(light.lazy_depth(), len(self.streams)))
         k = self._i % len(self.streams)
         st = self.streams[k]
         self._i += 1
         if k not in self._fresh:
             st.wait_stream(torch.cuda.current_stream(self.device))
             self._fresh.add(k)
-        return ViewStreams._View(self, st, self._done)
+        v = self._views[k]
+        v.prev_stream = self._last_stream
+        return v
 
     def before_backward(self, whole=False):
         """Inside a `with views.next():` block, before `backward()`: orders the part of this view's backward that
         accumulates into shared `.grad` after the end of the previous view (see the class docstring)."""
         v = self._current
-        if v is None or v.prev_done is None:
+        if v is None or v.prev_stream is None or v.prev_stream is v.stream:
             return
+        # the end of the previous view: its stream has had nothing enqueued since (streams take turns), so an event recorded
+        # on it now marks that point -- and views that never call this pay for no event at all
+        prev_done = torch.cuda.Event()
+        prev_done.record(v.prev_stream)
         if whole:
-            v.stream.wait_event(v.prev_done)
+            v.stream.wait_event(prev_done)
         else:
-            light._set_post_backward_wait(v.stream, v.prev_done)
+            light._set_post_backward_wait(v.stream, prev_done)
 
     def join(self):
         """The caller's stream waits for every view issued so far."""
@@ -147,7 +167,10 @@ class ViewStreams:
         for st in self.streams:
             cur.wait_stream(st)
         self._fresh.clear()
-        self._done = None
+        self._last_stream = None
+        if self._saved_depth is not None:
+            light.set_lazy_depth(self._saved_depth)
+            self._saved_depth = None
 
 
 class CapturedStep:

@@ -114,6 +114,13 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
                        const float* perspec_matrix, float* dL_dview, float* dg_camd_dviewmatrix,
                        const float* gt_depth, int track_off, int map_off, char* scratch, size_t scratch_bytes);
 
+/* Resident scratch.  dgr_light_backward / dgr_full_backward clear `scratch` with one launch before the blend backward.  A caller
+ * that keeps a scratch buffer across calls (one per stream: calls that share one must be ordered on a stream) can skip that launch:
+ * after dgr_backward_scratch_clean_arm() the NEXT backward call of this thread takes `scratch` as ALL ZERO on entry and leaves it
+ * all zero when its kernels have completed -- the per-Gaussian kernel clears every accumulator row it reads, the block that
+ * finishes the pose sum clears the partials.  Start from a zero-filled buffer; after a call that returned an error, zero it again. */
+int dgr_backward_scratch_clean_arm(void);
+
 /* ---- -full variant -------------------------------------------------------------------------------
  * Replaces CudaRasterizer::Rasterizer::forward of the full variant (F/cr/rasterizer.h:31-62,
  * F/cr/rasterizer_impl.cu:349-500): returns num_rendered; the tuple's second member (num_related_primitives,
@@ -160,8 +167,9 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
 
 /* ---- stage-wise access for tests and profiling (views into the opaque state buffers) ---- */
 /* Copies one named array of a state buffer to `dst` (device or host pointer).  Names: "depths", "radii",
- * "means2D", "cov3D", "conic_opacity", "rgb", "clamped", "tiles_touched" (geometry); "point_list", "keys" (binning);
- * "ranges", "n_contrib", "n_valid", "final_T" (image; the last two: full variant).  Layout conversion to the reference's element types is done on the fly.
+ * "means2D", "conic_opacity", "rgb", "clamped", "tiles_touched" (geometry); "point_list", "keys" (binning);
+ * "ranges", "tile_sched", "sched_flag" (one word: whether this frame's blend kernels use the schedule), "n_contrib", "n_valid",
+ * "final_T" (image; the last two: full variant).  Layout conversion to the reference's element types is done on the fly.
  * `num_rendered` instances are exported; `binning_capacity` is the capacity the binning buffer was carved with
  * (= num_rendered after dgr_*_forward, the caller's capacity after *_presized).  Returns the element count, or < 0. */
 long dgr_state_export(void* stream, const char* name, int P, int width, int height, int num_rendered,
@@ -181,6 +189,15 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
  * back then). */
 long dgr_status_post(void* stream, const int* device_status);
 int dgr_status_poll(long ticket, int wait, int* host_status4);
+/* The same read-back without the copy and the event: dgr_status_arm() returns a ticket and hands its slot to the NEXT
+ * *_forward_presized call of this thread (whichever stream it runs on).  That forward's binning kernel writes {num_rendered,
+ * overflow, prefiltered violation, 0} straight into the slot's pinned host memory (mapped into the device's address space),
+ * a tag last; dgr_status_poll on the ticket then reads host memory -- no HIP call unless it has to wait.  num_related_primitives
+ * (full variant; completed by the forward blend, later than the rest) is NOT reported this way: read the device word when it
+ * is needed.  A forward that enqueues no binning kernel (P == 0, an argument error) completes the word itself, all zero.  The
+ * armed forward also reports its longest tile list, which feeds the "tile_schedule" policy below.  Not while `stream` records
+ * a hipGraph (nothing can be read back then: do not arm). */
+long dgr_status_arm(void);
 int dgr_stream_is_capturing(void* stream);
 int dgr_early_status_arm(void);
 int dgr_early_status_wait(int* host_status4);
@@ -238,6 +255,12 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle
  *     is cut down to the box where alpha can reach 15/255.  Images and gradients are unchanged, but num_rendered, the
  *     tile lists and n_contrib are NOT the reference's any more -- hence opt-in.
+ *  "tile_schedule" (default 2): whether the forward builds the blend kernels' tile schedule (classes of long lists first, so that
+ *     a cluster's long lists start first and every XCD gets its share of them: 2x on the blend kernels of a clustered frame).
+ *     1 = always, 0 = never (static map: every XCD a contiguous band of the image), 2 = by the frame: a forward whose status
+ *     came back through dgr_status_arm also reports its longest tile list, and the next forward of that shape (device, P, width,
+ *     height) skips the schedule kernel when that list was within twice the mean + 32 -- on an even frame the schedule is a
+ *     launch and 11 us in front of the blend for nothing.  Forwards that report nothing keep it.  Results never depend on it.
  *  "lds_count" (default 1): how the forward bins a frame's tile instances.  1 = the two-level segment binning
  *     (csrc/segment_binning.hip: pairs per 16-, 8- or 4-tile row segment, tile lists built and sorted in LDS; no global
  *     atomics, no cleared counters) whenever the frame's segment tables fit LDS (up to 8 192 four-tile segments, i.e.

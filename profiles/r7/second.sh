@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round 7, second GPU call: suite, host breakdown, config 2 / config 3 lines after the front-end changes.
+cd "$(dirname "$0")/../.."
+O=gpurun_out/r7_second; mkdir -p $O
+timeout 1800 python -m pytest tests -q -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" | tail -40 > $O/pytest.log
+for v in light full; do
+  python profiles/host_breakdown.py $v 2>&1 | grep -v amdgpu.ids > $O/host_${v}_node.txt
+done
+B="python bench.py --no-cpu-baseline --workload config2 --variant full"
+$B --views-in-flight 1 2>/dev/null | tail -1 > $O/c2_full_one.json
+$B 2>/dev/null | tail -1 > $O/c2_full_seven.json
+$B --views-in-flight 3 2>/dev/null | tail -1 > $O/c2_full_three.json
+DGR_BENCH_AUTOGRAD_THREADS=1 $B 2>/dev/null | tail -1 > $O/c2_full_seven_threads.json
+$B --graph 2>/dev/null | tail -1 > $O/c2_full_graph.json
+python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/c3_driver.json
+python bench.py --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/c3_driver_b.json
+python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/c3_200.json
+python bench.py --no-cpu-baseline --views-in-flight 1 2>/dev/null | tail -1 > $O/c3_one.json
+DGR_TILE_SCHEDULE=1 python bench.py --no-cpu-baseline --views-in-flight 1 2>/dev/null | tail -1 > $O/c3_one_sched_always.json
+DGR_TILE_SCHEDULE=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $O/c3_200_sched_always.json
+python bench.py --no-cpu-baseline --scene clustered --views-in-flight 1 2>/dev/null | tail -1 > $O/c3_clustered_one.json
+for f in $O/*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.load(open(sys.argv[1])); c=d["config"]
+    print(sys.argv[1].split('/')[-1], "ms/step", round(d["ms_per_step"],4), "one_stream", c.get("ms_per_view_one_stream") and round(c["ms_per_view_one_stream"],4), "K", c["views_in_flight"], {k:round(v*1e3,1) for k,v in c["stage_ms"].items()})
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+done > $O/summary.txt
+cat $O/pytest.log $O/host_*.txt $O/summary.txt

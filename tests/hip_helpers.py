@@ -44,7 +44,7 @@ _EXPORT = {  # name -> (numpy dtype, elements per unit, unit)
     "conic_opacity": (np.float32, "4P"), "rgb": (np.float32, "3P"), "clamped": (np.uint8, "3P"),
     "tiles_touched": (np.uint32, "P"), "point_list": (np.uint32, "R"), "keys": (np.uint64, "R"),
     "contribution_tags": (np.uint8, "R1"),
-    "ranges": (np.uint32, "2T"), "tile_sched": (np.uint32, "4T"), "n_contrib": (np.uint32, "N"), "n_valid": (np.uint32, "N"), "final_T": (np.float32, "N"),
+    "ranges": (np.uint32, "2T"), "tile_sched": (np.uint32, "4T"), "sched_flag": (np.uint32, "1"), "n_contrib": (np.uint32, "N"), "n_valid": (np.uint32, "N"), "final_T": (np.float32, "N"),
 }
 
 
@@ -54,7 +54,7 @@ def hip_state(name, s, d, capacity=None):
     P, W, H, R = s.P, s.W, s.H, d["num_rendered"]
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     dt, unit = _EXPORT[name]
-    n = {"P": P, "6P": 6 * P, "2P": 2 * P, "4P": 4 * P, "3P": 3 * P, "R": R, "R1": R, "2T": 2 * tiles, "4T": 4 * tiles, "N": W * H}[unit]
+    n = {"P": P, "6P": 6 * P, "2P": 2 * P, "4P": 4 * P, "3P": 3 * P, "R": R, "R1": R, "1": 1, "2T": 2 * tiles, "4T": 4 * tiles, "N": W * H}[unit]
     torch_dt = {np.float32: torch.float32, np.int32: torch.int32, np.uint8: torch.uint8, np.uint32: torch.int32,
                 np.uint64: torch.int64, np.uint16: torch.int16}[dt]
     dst = torch.zeros(max(n, 1), dtype=torch_dt, device=dev())

@@ -1,0 +1,245 @@
+"""Round 7: the launches that left the one-view path, each against the path it replaces.
+
+  * status word through pinned host memory written by the binning kernel (dgr_status_arm) instead of a copy behind an event;
+  * tile schedule by policy: a frame with even tile lists skips tile_schedule_kernel and its blend kernels walk the static
+    XCD band map -- same results, bit for bit where the path is bit-exact;
+  * resident backward scratch (dgr_backward_scratch_clean_arm): no clearing launch, the per-Gaussian kernel clears what it reads.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from dgr_amd import _capi
+from dgr_amd.synth import cluster_scene
+from util import make_scene
+import hip_helpers as hh
+
+pytestmark = pytest.mark.gpu
+T, E = hh.T, hh.E
+
+
+def presized_forward(s, deg, cap, arm=False, P=None):
+    """dgr_light_forward_presized through ctypes with every buffer allocated here; returns (ticket, dict of tensors)."""
+    lib = _capi.load()
+    P = s.P if P is None else P
+    dev = hh.dev()
+    u8 = dict(dtype=torch.uint8, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    b = dict(geom=torch.empty((max(lib.dgr_geometry_bytes(P), 1),), **u8), img=torch.empty((lib.dgr_image_bytes(s.W, s.H),), **u8),
+             binning=torch.empty((lib.dgr_binning_bytes(cap, s.W, s.H),), **u8), status=torch.full((4,), -7, **i32),
+             color=torch.empty((3, s.H, s.W), **f32), depth=torch.empty((1, s.H, s.W), **f32),
+             median=torch.empty((1, s.H, s.W), **f32), var=torch.empty((1, s.H, s.W), **f32), alpha=torch.empty((1, s.H, s.W), **f32),
+             radii=torch.empty((max(P, 1),), **i32), unc=torch.empty((max(P, 1), 1), **f32), px=torch.empty((max(P, 1), 1), **i32))
+    inp = [T(a) for a in (s.bg, s.means[:P], s.shs[:P], s.opac[:P], s.scales[:P], s.rots[:P], s.view, s.proj, s.campos, s.gt)]
+    b["inputs"] = inp
+    p = _capi.ptr
+    ticket = lib.dgr_status_arm() if arm else -1
+    rc = lib.dgr_light_forward_presized(
+        _capi.stream_handle(), p(b["geom"]), p(b["binning"]), cap, p(b["img"]), p(b["status"]), P, deg, 16, p(inp[0]), s.W, s.H,
+        p(inp[1]), p(inp[2]), None, p(inp[3]), p(inp[4]), 1.0, p(inp[5]), None, p(inp[6]), p(inp[7]), p(inp[8]), s.tanfovx,
+        s.tanfovy, 0, p(b["color"]), p(b["depth"]), p(b["median"]), p(b["alpha"]), p(inp[9]), p(b["var"]), p(b["unc"]),
+        p(b["px"]), p(b["radii"]))
+    b["rc"] = rc
+    return ticket, b
+
+
+def poll(ticket, wait=1):
+    buf = (C.c_int * 4)()
+    rc = _capi.load().dgr_status_poll(ticket, wait, buf)
+    return rc, list(buf)
+
+
+@pytest.mark.parametrize("case", [(3000, 96, 64, 3, 1), (100000, 640, 480, 3, 0), (20000, 4000, 2300, 1, 2)])
+def test_armed_status_word_is_the_device_word(case):
+    """(the last shape is too large for the segment tables: the global-counter path's scan_tiles reports)"""
+    P, W, H, deg, seed = case
+    s = make_scene(P, W, H, seed)
+    ticket, b = presized_forward(s, deg, 8 * P + 4096, arm=True)
+    assert b["rc"] >= 0 and ticket >= 0
+    rc, word = poll(ticket)
+    torch.cuda.synchronize()
+    dev_word = b["status"].tolist()
+    assert rc == 1 and word[:3] == dev_word[:3] and word[0] > 0 and word[1] == 0
+    assert _capi.load().dgr_status_poll(ticket, 0, (C.c_int * 4)()) < 0  # the ticket was released by the read
+
+
+def test_armed_status_reports_an_overflow_and_the_slot_is_reusable():
+    s = make_scene(20000, 320, 200, 5)
+    t1, b = presized_forward(s, 3, 64, arm=True)  # far too small
+    rc, word = poll(t1)
+    torch.cuda.synchronize()
+    assert rc == 1 and word[1] == 1 and word[0] == b["status"].tolist()[0] > 64
+    t2, b2 = presized_forward(s, 3, word[0] + 10, arm=True)
+    rc, word2 = poll(t2)
+    assert rc == 1 and word2[1] == 0 and word2[0] == word[0]
+    # many in flight before any is read: distinct slots, each with its own forward's word
+    tickets = [presized_forward(make_scene(1000 + 500 * i, 64, 48, i), 1, 40000, arm=True) for i in range(6)]
+    torch.cuda.synchronize()
+    for t, bb in tickets:
+        rc, w = poll(t, wait=0)
+        assert rc == 1 and w[:3] == bb["status"].tolist()[:3]
+
+
+def test_armed_slot_is_completed_by_the_library_when_no_kernel_runs():
+    s = make_scene(500, 64, 48, 1)
+    t0, b = presized_forward(s, 3, 100, arm=True, P=0)   # nothing to render: no binning kernel
+    assert b["rc"] == 0 and poll(t0, wait=0) == (1, [0, 0, 0, 0])
+    lib = _capi.load()
+    t1 = lib.dgr_status_arm()
+    rc = lib.dgr_light_forward_presized(_capi.stream_handle(), None, None, 10, None, None, 5, 0, 0, None, 64, 48, *([None] * 5), 1.0,
+                                        *([None] * 5), 0.5, 0.5, 0, *([None] * 9))
+    assert rc == _capi.DGR_ERR_BAD_ARGUMENT and poll(t1, wait=0) == (1, [0, 0, 0, 0])
+    t2 = lib.dgr_status_arm()
+    assert lib.dgr_status_poll(t2, 0, (C.c_int * 4)()) < 0   # armed, not yet taken by a forward: not pollable
+    t3, b3 = presized_forward(s, 3, 4000, arm=False)          # (this forward takes t2's arm)
+    assert poll(t2)[0] == 1
+
+
+def forward_under(option, s, deg):
+    _capi.set_option("tile_schedule", option)
+    try:
+        return hh.hip_forward(s, deg)
+    finally:
+        _capi.set_option("tile_schedule", 2)
+
+
+@pytest.mark.parametrize("case", [(3000, 96, 64, 3, 7, False), (100000, 640, 480, 3, 0, False), (100000, 640, 480, 3, 0, True),
+                                  (500000, 1920, 1080, 3, 0, False)])
+def test_static_band_map_and_tile_schedule_give_the_same_frame(oracle, case):
+    """tile_schedule = 0 (blend workgroups find their tile through the static XCD band map) against 1 (through the schedule):
+    images, n_contrib, contribution tags and the median statistics identical; the backward of either state within the float
+    atomics' noise of the other and at the 1e-5 bar against the oracle."""
+    from test_hip_light_parity import check_backward
+    P, W, H, deg, seed, clustered = case
+    s = make_scene(P, W, H, seed)
+    if clustered:
+        s = cluster_scene(s)
+    out1, d1 = forward_under(1, s, deg)
+    out0, d0 = forward_under(0, s, deg)
+    assert hh.hip_state("sched_flag", s, d1)[0] == 1 and hh.hip_state("sched_flag", s, d0)[0] == 0
+    for k in ("color", "depth", "depth_median", "opacity_map", "radii", "gau_related_pixels"):
+        assert np.array_equal(d0[k], d1[k]), k
+    for name in ("n_contrib", "point_list", "contribution_tags", "ranges"):
+        assert np.array_equal(hh.hip_state(name, s, d0), hh.hip_state(name, s, d1)), name
+    g0, g1 = hh.hip_backward(s, deg, out0), hh.hip_backward(s, deg, out1)
+    for k in g0:
+        scale = max(np.abs(g1[k]).max(), 1e-30)
+        assert np.abs(g0[k] - g1[k]).max() <= 2e-5 * scale, k
+    if P <= 100000:
+        _capi.set_option("tile_schedule", 0)
+        try:
+            check_backward(oracle, s, deg)
+        finally:
+            _capi.set_option("tile_schedule", 2)
+
+
+def test_schedule_policy_follows_the_frame():
+    """tile_schedule = 2: a forward that reports through an armed slot tells the library its longest list, and the next forward
+    of that shape drops the schedule on an even frame and keeps it on a clustered one; forwards that report nothing keep it."""
+    s = make_scene(60000, 480, 320, 3)
+    c = cluster_scene(s)
+    cap = 12 * s.P
+    assert _capi.get_option("tile_schedule") == 2
+
+    def flag(b):
+        return hh.hip_state("sched_flag", s, {"num_rendered": 0, "geom": b["geom"], "binning": b["binning"], "img": b["img"]}, capacity=cap)[0]
+
+    for scene, want in ((s, 0), (c, 1), (s, 0)):
+        t, b = presized_forward(scene, 3, cap, arm=True)
+        assert poll(t)[0] == 1                 # the report of THIS frame decides the NEXT forward of the shape
+        t, b = presized_forward(scene, 3, cap, arm=True)
+        assert poll(t)[0] == 1
+        assert flag(b) == want, (want,)
+    _, b = presized_forward(s, 3, cap, arm=False)
+    assert flag(b) == 1                         # no report asked for: the schedule stays
+
+
+def test_full_variant_walks_the_static_map_too(oracle):
+    s = make_scene(30000, 320, 240, 2)
+    _capi.set_option("tile_schedule", 0)
+    try:
+        out0, d0 = hh.hip_full_forward(s, 3)
+        g0 = hh.hip_full_backward(s, 3, out0)
+    finally:
+        _capi.set_option("tile_schedule", 2)
+    out1, d1 = hh.hip_full_forward(s, 3)
+    g1 = hh.hip_full_backward(s, 3, out1)
+    assert hh.hip_state("sched_flag", s, d0)[0] == 0 and hh.hip_state("sched_flag", s, d1)[0] == 1
+    for k in ("color", "depth", "uncertainty", "radii"):
+        assert np.array_equal(d0[k], d1[k]), k
+    assert d0["num_related"] == d1["num_related"]
+    for k in g0:
+        assert np.abs(g0[k] - g1[k]).max() <= 2e-5 * max(np.abs(g1[k]).max(), 1e-30), k
+
+
+@pytest.mark.parametrize("mode", [(False, False), (True, False), (False, True)])
+def test_resident_scratch_backward_equals_the_cleared_one_and_leaves_the_scratch_zero(mode):
+    lib = _capi.load()
+    s = make_scene(40000, 400, 300, 9)
+    out, d = hh.hip_forward(s, 3)
+    ref = hh.hip_backward(s, 3, out, track_off=mode[0], map_off=mode[1])
+    (R, color, depth, median, var, alpha, radii, geom, binning, img, _, _) = out
+    dev = hh.dev()
+    P = s.P
+    n = lib.dgr_light_backward_scratch_bytes(P, s.W, s.H)
+    scratch = torch.zeros((n,), dtype=torch.uint8, device=dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    p = _capi.ptr
+    inp = [T(a) for a in (s.bg, s.means, s.shs, s.scales, s.rots, s.view, s.proj, s.campos, s.gt, s.persp, s.gC, s.gD[None], s.gM[None], s.gV[None])]
+    for rep in range(3):  # the second and third call run on what the call before left behind
+        g = dict(m2=torch.empty((P, 3), **f32), op=torch.empty((P, 1), **f32), col=torch.empty((P, 3), **f32), m3=torch.empty((P, 3), **f32),
+                 cov=torch.empty((P, 6), **f32), sh=torch.empty((P, 16, 3), **f32), sc=torch.empty((P, 3), **f32), rot=torch.empty((P, 4), **f32),
+                 view=torch.empty((16,), **f32))
+        assert lib.dgr_backward_scratch_clean_arm() == 0
+        rc = lib.dgr_light_backward(
+            _capi.stream_handle(), P, 3, 16, int(R), p(inp[0]), s.W, s.H, p(inp[1]), p(inp[2]), None, p(alpha), p(inp[3]), 1.0, p(inp[4]),
+            None, p(inp[5]), p(inp[6]), p(inp[7]), s.tanfovx, s.tanfovy, p(radii), p(geom), p(binning), p(img), p(inp[10]), p(inp[11]),
+            p(inp[12]), p(inp[13]), p(g["m2"]), None, p(g["op"]), p(g["col"]), None, p(g["m3"]), p(g["cov"]), p(g["sh"]), p(g["sc"]),
+            p(g["rot"]), 0, None, p(inp[9]), p(g["view"]), None, p(inp[8]), int(mode[0]), int(mode[1]), p(scratch), n)
+        assert rc == 0, _capi.last_error()
+        torch.cuda.synchronize()
+        assert int(scratch.count_nonzero()) == 0, f"call {rep}: the scratch is not all zero again"
+        got = {"dL_dmeans2D": g["m2"], "dL_dopacity": g["op"], "dL_dmeans3D": g["m3"], "dL_dcov3D": g["cov"], "dL_dsh": g["sh"],
+               "dL_dscales": g["sc"], "dL_drotations": g["rot"], "dL_dview": g["view"].view(4, 4)}
+        for k, v in got.items():
+            a, b_ = v.cpu().numpy(), ref[k]
+            assert np.abs(a - b_).max() <= 2e-5 * max(np.abs(b_).max(), 1e-30), (rep, k)
+
+
+def test_compiled_node_keeps_its_scratch_and_agrees_with_the_python_function():
+    """The autograd node of the compiled extension (resident scratch, armed status, arena outputs) against the Python
+    autograd.Function over `_C` -- the reference-shaped path -- on the same inputs: identical images, gradients within the
+    float atomics' noise; repeated, so that the resident scratch is reused."""
+    from dgr_amd import light as L
+    from dgr_amd.multiview import make_settings
+    if L._C is not L._CompiledC:
+        pytest.skip("ctypes binding selected")
+    s = make_scene(30000, 320, 240, 4)
+    dev = hh.dev()
+    rast = L.GaussianRasterizer(make_settings(s, 3, dev))
+
+    def run(use_node):
+        leaves = [T(a).requires_grad_() for a in (s.means, s.shs, s.opac, s.scales, s.rots, s.view)]
+        m2 = torch.zeros((s.P, 3), device=dev, requires_grad=True)
+        old = L._USE_NODE
+        L._USE_NODE = use_node
+        try:
+            o = rast(means3D=leaves[0], means2D=m2, opacities=leaves[2], shs=leaves[1], scales=leaves[3], rotations=leaves[4],
+                     viewmatrix=leaves[5], gt_depth=T(s.gt))
+        finally:
+            L._USE_NODE = old
+        torch.autograd.backward([o[0], o[2], o[3], o[4]], [T(s.gC), T(s.gD[None]), T(s.gM[None]), T(s.gV[None])])
+        torch.cuda.synchronize()
+        return [x.detach().cpu().numpy() for x in o], [x.grad.cpu().numpy() for x in leaves + [m2]]
+
+    o_ref, g_ref = run(False)
+    for rep in range(3):
+        o, g = run(True)
+        for a, b in zip(o, o_ref):
+            assert np.array_equal(a, b)
+        for a, b in zip(g, g_ref):
+            assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), rep
+    L.check_async_errors()
