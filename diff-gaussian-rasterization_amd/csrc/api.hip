@@ -117,9 +117,9 @@ thread_local bool g_scratch_clean_armed = false;
 // ---- asynchronous status read-back (dgr_status_post / _poll): the lazy mode of the bindings copies a forward's status
 // word to pinned host memory behind an event and looks at it one or two calls later.  Slots are pooled per device.
 // Two ways to fill a slot: dgr_status_post copies a device word behind an event (any status word, after the fact);
-// dgr_status_arm hands the slot to the NEXT presized forward, whose binning kernel writes the word straight into the slot's
-// pinned memory (mapped into the device's address space) with a tag last -- no copy, no event, nothing to wait for on the
-// stream -- and may use three device words owned by the slot (zero between forwards) to gather the frame's longest tile list.
+// dgr_status_arm hands the slot to the NEXT presized forward, whose forward blend (workgroup 0, first thing) writes the word
+// straight into the slot's pinned memory (mapped into the device's address space) with a tag last -- no copy, no event, nothing
+// to wait for on the stream.  One device word owned by the slot (zero between forwards) gathers the frame's longest tile list.
 struct StatusSlot {
     hipEvent_t ev = nullptr;
     int* pinned = nullptr;       // host int[8]: {num_rendered, overflow, prefiltered violation, num_related | tag, longest list, -, -}
@@ -362,7 +362,6 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
         const int ss = dgr::segment_shift(c.W, c.H, capacity);
         { ScopedStage t(ST_BIN_SEGMENTS, st); HIP_TRY(dgr::launch_bin_segments(c.P, geom, bin, tb, gx, gy, ss, capacity, cb, st)); }
         { ScopedStage t(ST_BIN_TILES, st); HIP_TRY(dgr::launch_bin_tiles(c.P, geom, img, bin, tb, gx, gy, ss, capacity, cb, sched_on, rep, st)); }
-        if (armed) armed->handed_over = true;
         if (!cb) { const int rc = early_status_post(img.status, st); if (rc) return rc; }  // (bin_tiles writes the status word)
         if (sched_on) { ScopedStage t(ST_TILE_SCHED, st); HIP_TRY(dgr::launch_tile_schedule(img, tiles, st)); }
         return DGR_OK;
@@ -370,7 +369,6 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
     const bool fused = mode == COUNT_FUSED;
     if (!fused) { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_rank(c.P, geom, img, bin, gx, capacity, st)); }
     { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, gx, capacity, fused, sched_on, rep, st)); }
-    if (armed) armed->handed_over = true;
     if (fused) { const int rc = early_status_post(img.status, st); if (rc) return rc; }
     { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
     { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
@@ -378,7 +376,8 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
     return DGR_OK;
 }
 
-int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, hipStream_t st) {
+int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img, dgr::BinningView bin, hipStream_t st,
+                 ArmedReport* armed = nullptr) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
     dgr::RenderFwdLightArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
@@ -386,13 +385,16 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_median = c.out_median_depth; r.out_alpha = c.out_alpha;
     r.out_depth_var = c.out_depth_var; r.n_contrib = img.n_contrib; r.gau_uncertainty = c.gau_uncertainty;
     r.gau_related_pixels = c.gau_related_pixels;
+    r.rep = armed ? armed->rep : dgr::StatusReport{nullptr, 0u, nullptr};
+    r.status = img.status;
     { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_light(r, g_alpha_mode.load(), st)); }
+    if (armed) armed->handed_over = true;  // (workgroup 0 of the blend delivers the word)
     return DGR_OK;
 }
 
 // ---- full variant: same front end, different blend
 int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryView geom, dgr::ImageView img,
-                      dgr::BinningView bin, hipStream_t st) {
+                      dgr::BinningView bin, hipStream_t st, ArmedReport* armed = nullptr) {
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H);
     dgr::RenderFwdFullArgs r{};
     r.W = c.W; r.H = c.H; r.grid_x = gx; r.grid_y = gy;
@@ -400,7 +402,9 @@ int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryV
     r.out_color = c.out_color; r.out_depth = c.out_depth; r.out_uncertainty = out_uncertainty;
     r.n_contrib = img.n_contrib; r.n_valid = img.n_valid; r.first_contrib = img.first_contrib; r.final_T = img.final_T;
     r.status = img.status;
+    r.rep = armed ? armed->rep : dgr::StatusReport{nullptr, 0u, nullptr};
     { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_full(r, g_alpha_mode.load(), st)); }
+    if (armed) armed->handed_over = true;
     return DGR_OK;
 }
 
@@ -603,7 +607,7 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
     const int mode = presized_count_mode(width, height, binning_capacity);
     if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer, mode))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer, &armed))) return rc;
-    if ((rc = forward_back(c, geom, img, bin, st))) return rc;
+    if ((rc = forward_back(c, geom, img, bin, st, &armed))) return rc;
     return DGR_OK;
 }
 
@@ -738,7 +742,7 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     const int mode = presized_count_mode(width, height, binning_capacity);
     if ((rc = forward_front(c, geom, img, st, &bin, binning_capacity, image_buffer, mode))) return rc;
     if ((rc = binning_stages(c, geom, img, bin, binning_capacity, st, mode, binning_buffer, &armed))) return rc;
-    if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st))) return rc;
+    if ((rc = forward_back_full(c, out_uncertainty, geom, img, bin, st, &armed))) return rc;
     return DGR_OK;
 }
 

@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img,
             img.status[3] = 0;                   // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
         }
         // (this path does not track the longest list: "unknown" keeps the tile schedule on)
-        if (rep.host) report_status(rep, (int)total, overflow ? 1 : 0, fused ? (int)img.cursor[1] : img.status[2], 0x7fffffffu);
+        if (rep.ws) __hip_atomic_store(rep.ws, 0x7fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

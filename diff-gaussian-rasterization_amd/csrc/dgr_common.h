@@ -117,15 +117,22 @@ __host__ __device__ inline int xcd_contiguous(int b, int n) {
 }
 
 // Where a forward reports its status word when a status slot is armed (api.hip: dgr_status_arm): `host` = pinned host memory
-// mapped into the device's address space, written by the binning kernel that completes the word -- {num_rendered, overflow,
-// prefiltered violation, 0, tag, longest tile list} with `tag` last -- so that the host reads it without a copy, an event or
-// a wait; `ws` = three device words owned by the slot, zero between forwards (bin_tiles: longest list, tickets, flag).
+// mapped into the device's address space.  The word is complete when the binning kernels have finished, so the first workgroup
+// of the forward blend -- the next kernel on the stream -- copies it there: {num_rendered, overflow, prefiltered violation, 0,
+// tag, longest tile list}, `tag` last, and the host reads it without a copy, an event or a wait.  `ws` = a device word owned by
+// the slot, zero between forwards: the binning kernels leave the frame's longest tile list in it (an atomic max per segment).
 struct StatusReport {
     int* host;      // NULL: no report
     uint32_t tag;
     uint32_t* ws;
 };
-__device__ __forceinline__ void report_status(const StatusReport& r, int total, int overflow, int flag, uint32_t longest) {
+// (one thread of the forward blend, before its workgroup does anything else; `status` = the frame's device status word)
+__device__ __forceinline__ void report_status(const StatusReport& r, const int* status) {
+    const int total = __hip_atomic_load(status + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int overflow = __hip_atomic_load(status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int flag = __hip_atomic_load(status + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t longest = __hip_atomic_load(r.ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(r.ws, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(r.host + 0, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(r.host + 1, overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(r.host + 2, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

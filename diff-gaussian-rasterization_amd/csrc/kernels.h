@@ -173,6 +173,8 @@ struct RenderFwdLightArgs {
     uint32_t* n_contrib;
     float* gau_uncertainty;
     int* gau_related_pixels;
+    StatusReport rep;      // armed status slot (dgr_status_arm): workgroup 0 copies the frame's status word to the host
+    const int* status;
 };
 
 struct RenderBwdLightArgs {
@@ -212,6 +214,7 @@ struct RenderFwdFullArgs {
     uint32_t* first_contrib;
     float* final_T;
     int* status;  // status[3] += sum of n_valid (num_related_primitives)
+    StatusReport rep;  // armed status slot (dgr_status_arm): workgroup 0 copies the frame's status word to the host
 };
 
 struct RenderBwdFullArgs {

@@ -894,11 +894,14 @@ __device__ __forceinline__ void pose_finish_if_last(uint32_t t, double* pose_par
         float out = 0.0f;
         if (threadIdx.x < 12) {
             double tot = 0.0;
-            for (int g = 0; g < DGR_POSE_BUCKETS; g++) {  // (agent-scope loads: served by L2, where the adds were performed)
+            for (int g = 0; g < DGR_POSE_BUCKETS; g++)  // (agent-scope loads: served by L2, where the adds were performed)
                 tot += __hip_atomic_load(pose_part + (size_t)g * 12 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (clear) __hip_atomic_store(pose_part + (size_t)g * 12 + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
             out = (float)tot;
+            // (the clearing stores in a loop of their own, behind ALL the loads: a store right behind each load of the same
+            //  address made the 64 round trips of this one wave dependent -- +25 us at the kernel's tail, whatever its size)
+            if (clear)
+                for (int g = 0; g < DGR_POSE_BUCKETS; g++)
+                    __hip_atomic_store(pose_part + (size_t)g * 12 + threadIdx.x, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (clear && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // slot order v0,v1,v2,v4,v5,v6,v8,v9,v10,v12,v13,v14 (L/cuda_rasterizer/backward.cu:723)
@@ -1049,12 +1052,20 @@ __global__ void __launch_bounds__(256, DGR_PPB_WAVES) preprocess_bwd_kernel(Prep
             a.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
         }
         if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
-        // Resident scratch: the reader clears the row it has read (only rows of visible Gaussians were ever touched by the blend
-        // kernel's atomics).  Down here, with the kernel's other stores: right behind the loads of the row the stores put a wait
-        // for those loads in front of every other input's request (44 -> 75 us at config 3).
-        if (a.clear_scratch && vis) {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            ap[0] = z; ap[1] = z; ap[2] = z; ap[3] = z;
+    }
+    // Resident scratch: the readers clear the rows they have read.  The 64 rows of a wave's Gaussians are 4 KB in a row, so the
+    // wave clears them together with four fully coalesced 16-byte stores per lane (rows of Gaussians the view did not see are
+    // zero already; writing them again costs nothing extra).  Every lane's loads of its own row have been consumed by now.
+    // (Each lane clearing its own row -- four stores of 16 bytes at a 64-byte stride, 64 partial lines per instruction -- cost the
+    //  kernel 30 us at config 3, 44 -> 74; right behind the loads, where it also delayed every other input's request, the same.)
+    if (a.clear_scratch) {
+        const size_t wave_row0 = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63u);
+        float4* wbase = reinterpret_cast<float4*>(a.acc + wave_row0 * DGR_ACC_STRIDE);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int piece = k * 64 + (int)(threadIdx.x & 63u);           // 16-byte piece of the wave's 4 KB
+            if (wave_row0 + (size_t)(piece >> 2) < (size_t)a.P) wbase[piece] = z;
         }
     }
 

@@ -66,6 +66,7 @@ template <int AM>
 __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
     __shared__ StagedFwd sf;
     Staged& s = sf.f;
+    if (a.rep.host && blockIdx.x == 0 && threadIdx.x == 0) report_status(a.rep, a.status);
     const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;

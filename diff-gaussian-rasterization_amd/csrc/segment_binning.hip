@@ -249,40 +249,6 @@ __device__ __forceinline__ void sort_tile_in_wave(uint64_t* src, int n, uint32_t
 }
 
 // (xcd_contiguous, dgr_common.h: XCD x gets a contiguous run of segments)
-// A workgroup's part in the frame's status report (StatusReport, dgr_common.h).  note(): the longest of its tile lists into
-// ws[0] and the `prefiltered` flag into ws[2], atomics without a return value, issued where the counts are known and not waited
-// for.  When thread 0 leaves the kernel -- whichever return it takes: the destructor -- it draws a ticket from ws[1]; the
-// workgroup that draws the last of the `nseg` tickets has every other one's contribution in front of it (the atomics are
-// performed at L2, agent scope, and acknowledged before the ticket), writes the word to the host and leaves the three words
-// zero for the slot's next forward.  (The ticket in the middle of the kernel, in front of the sorts, cost wave 0 of every
-// workgroup two memory round trips: bin_tiles 27 -> 37 us at config 3.)
-struct ReportAtExit {
-    StatusReport rep;
-    int nseg;
-    bool mine;  // thread 0 of a segment's own workgroup (helpers of dense segments do not report)
-    uint32_t total = 0;
-    bool overflow = false;
-    __device__ __forceinline__ ReportAtExit(const StatusReport& r, int n, bool m) : rep(r), nseg(n), mine(m && r.host != nullptr) {}
-    __device__ __forceinline__ void note(uint32_t tmax, uint32_t flag, uint32_t tot, bool ovf) {
-        total = tot; overflow = ovf;
-        if (!mine) return;
-        if (tmax) __hip_atomic_fetch_max(rep.ws + 0, tmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (flag) __hip_atomic_fetch_or(rep.ws + 2, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __device__ __forceinline__ ~ReportAtExit() {
-        if (!mine) return;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t t = __hip_atomic_fetch_add(rep.ws + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t != (uint32_t)nseg - 1u) return;
-        const uint32_t longest = __hip_atomic_load(rep.ws + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t any = __hip_atomic_load(rep.ws + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rep.ws + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rep.ws + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rep.ws + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        report_status(rep, (int)total, overflow ? 1 : 0, (int)any, longest);
-    }
-};
-
 template <bool LONG_LISTS>
 __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img, uint32_t* __restrict__ point_list,
                                                                   uint64_t* __restrict__ key_scratch, SegmentTables tb,
@@ -306,7 +272,6 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     const int ty = s / sgx, sx = s - ty * sgx;
     const int ntl = min(SEG, grid_x - sx * SEG);             // tiles of this segment (the last one of a row may be short)
     const int tile0 = ty * grid_x + sx * SEG;
-    ReportAtExit tail(rep, nseg, part == 0 && tid == 0);
 
     // ---- list start, size of the segment, grand total: column sums of the per-workgroup running counts; the runs
     uint32_t before = 0, upto = 0, total = 0, flag = 0;
@@ -348,7 +313,6 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     }
     if (overflow || gcount == 0u) {  // (empty tiles keep {0, 0}: the reference clears the table and writes only tiles that own instances)
         if (part == 0 && tid < ntl) img.ranges[tile0 + tid] = make_uint2(0u, 0u);
-        tail.note(0u, flag, total, overflow);
         return;
     }
     const uint32_t n_pairs = block_scan<K2_THREADS>(sh.run_start, nwg + 1, false, sh.wsum, tid);  // run_start[w] = pairs of the runs < w
@@ -434,7 +398,12 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     uint32_t tmax = 0;
 #pragma unroll
     for (int t = 0; t < SEG_MAX; t++) tmax = max(tmax, sh.tcnt[t]);
-    tail.note(tmax, flag, total, overflow);
+    // the frame's longest tile list, for the forward's status report (StatusReport, dgr_common.h; the forward blend's first
+    // workgroup delivers it): one atomic without a return value per segment, nothing waits for it.  (A ticket here, with the
+    // last workgroup reporting, was built first: in the middle of the kernel it cost wave 0 two memory round trips -- 27 -> 37 us
+    // at config 3 -- and as an object whose destructor ran at every return it made the LONG_LISTS instantiation, which spills,
+    // fault on a reloaded pointer.)
+    if (rep.ws && part == 0 && tid == 0 && tmax) __hip_atomic_fetch_max(rep.ws, tmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!dense) {
         // ---- pass B: the segment's keys into LDS, grouped by tile
 #pragma unroll

@@ -190,7 +190,7 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
 long dgr_status_post(void* stream, const int* device_status);
 int dgr_status_poll(long ticket, int wait, int* host_status4);
 /* The same read-back without the copy and the event: dgr_status_arm() returns a ticket and hands its slot to the NEXT
- * *_forward_presized call of this thread (whichever stream it runs on).  That forward's binning kernel writes {num_rendered,
+ * *_forward_presized call of this thread (whichever stream it runs on).  That forward's blend kernel (its first workgroup, before anything else) writes {num_rendered,
  * overflow, prefiltered violation, 0} straight into the slot's pinned host memory (mapped into the device's address space),
  * a tag last; dgr_status_poll on the ticket then reads host memory -- no HIP call unless it has to wait.  num_related_primitives
  * (full variant; completed by the forward blend, later than the rest) is NOT reported this way: read the device word when it

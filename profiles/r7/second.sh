@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round 7, second GPU call: suite, host breakdown, config 2 / config 3 lines after the front-end changes.
 cd "$(dirname "$0")/../.."
-O=gpurun_out/r7_second; mkdir -p $O
-timeout 1800 python -m pytest tests -q -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" | tail -40 > $O/pytest.log
+O=gpurun_out/r7_fifth; mkdir -p $O
+timeout 900 python -m pytest tests/test_hip_front_end.py tests/test_hip_light_parity.py -q -m gpu 2>&1 | tail -3 > $O/pytest.log; python profiles/r7/pyprof.py 2>&1 | grep -v amdgpu.ids | tail -32 > $O/pyprof.txt
 for v in light full; do
-  python profiles/host_breakdown.py $v 2>&1 | grep -v amdgpu.ids > $O/host_${v}_node.txt
+  DGR_HOST_PROF=1 python profiles/host_breakdown.py $v 2>&1 | grep -v amdgpu.ids > $O/host_${v}_node.txt
 done
 B="python bench.py --no-cpu-baseline --workload config2 --variant full"
 $B --views-in-flight 1 2>/dev/null | tail -1 > $O/c2_full_one.json
@@ -28,4 +28,4 @@ except Exception as e:
     print(sys.argv[1], "ERR", e)
 PY
 done > $O/summary.txt
-cat $O/pytest.log $O/host_*.txt $O/summary.txt
+cat $O/pytest.log $O/pyprof.txt $O/host_*.txt $O/summary.txt

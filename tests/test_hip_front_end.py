@@ -238,8 +238,11 @@ def test_compiled_node_keeps_its_scratch_and_agrees_with_the_python_function():
     o_ref, g_ref = run(False)
     for rep in range(3):
         o, g = run(True)
-        for a, b in zip(o, o_ref):
-            assert np.array_equal(a, b)
+        for i, (a, b) in enumerate(zip(o, o_ref)):
+            if i == 6:  # gau_uncertainty: a sum of float atomics, equal up to their arrival order
+                assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
+            else:
+                assert np.array_equal(a, b), i
         for a, b in zip(g, g_ref):
             assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), rep
     L.check_async_errors()
