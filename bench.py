@@ -442,6 +442,7 @@ def main():
             "value": views_per_s / 1e6,
             "unit": "Mviews/s",
             "n_gpus": world,
+            "views_in_flight": K,  # `value` is a throughput of K independent views in flight; config.ms_per_view_one_stream is the serial figure
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -461,6 +462,8 @@ def main():
                                       f"{'4: one fused all-reduce of the Gaussian gradients after every view' if G == 1 else '5: one fused all-reduce per ' + str(G) + ' local views'}")
                                    + (" -- TRACKING step: pose gradient only (map_off), not the headline mapping step" if args.tracking else ""), "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
+                       "autograd_engine_thread": torch.autograd.is_multithreading_enabled(),
+                       "tile_schedule": {0: "never", 1: "always", 2: "by the frame (skipped on even frames)"}.get(_capi.get_option("tile_schedule")),
                        "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "views_per_step": max(1, Vb),
                        "ms_per_view": 1e3 * elapsed / args.steps / max(1, Vb), "hipgraph_replay": bool(args.graph),
                        "binning": "two-level segment binning (csrc/segment_binning.hip)" if _capi.get_option("lds_count") else "global tile counters (csrc/binning.hip)",
@@ -489,13 +492,15 @@ def main():
                          "launches_under_overlap": dom_n, "measured_in_timed_region": live},
             "roofline_valu": roofline_valu,
         }
-        if not args.no_cpu_baseline and args.variant == "light" and world == 1:  # (the CPU baseline: rank 0 at N = 1 only)
+        if not args.no_cpu_baseline and world == 1:  # (the CPU baseline: rank 0 at N = 1 only)
             # Beside the headline (eager: every step goes through the autograd surface on the host): the same K steps with
             # one captured view per stream replayed from hipGraphs -- what a fixed-shape SLAM loop can do.  Reported, never
             # `value`; measured in a child process so that nothing of it touches this run.
             if not args.graph and not Vb and args.group <= 1 and not os.environ.get("DGR_BENCH_NO_GRAPH_LINE"):
                 line["config"]["ms_per_step_hipgraph_replay"] = graph_replay_line(args)
-            line["cpu_baseline"], ref_grads = cpu_baseline(s, deg, args.cpu_runs)
+            # (a bounded sample: 5 views at configs 1-3, 2 at the 2 M / 5 M Gaussian views, whose oracle pass takes 3-8 s)
+            runs = args.cpu_runs if P <= 500_000 else min(args.cpu_runs, 2)
+            line["cpu_baseline"], ref_grads = cpu_baseline(s, deg, runs, args.variant)
             # second half of BASELINE's metric: gradient max-abs-err against the CPU restatement of the reference, same
             # inputs and loss scaling (pixel-gradient images N(0,1)/(H W)); one extra untimed view on the default stream
             step()
@@ -508,9 +513,10 @@ def main():
             line["config"]["grad_max_abs_err"] = dict(
                 errs, max=max(errs.values()), scale={k: float(np.abs(ref_grads[k]).max()) for k in pairs},
                 note="end to end (HIP forward feeding HIP backward) vs the CPU oracle, BASELINE's loss scaling; north_star's "
-                     "tolerance is 1e-5 abs.  The default alpha path carries the host's bits (csrc/exact_math.h): the alpha "
-                     "image IS the oracle's, so the light backward's T_final = 1 - alpha_image amplifies nothing "
-                     "(fast_alpha option: 5.8e-5 on dL_dview; DESIGN.md s5)")
+                     "tolerance is 1e-5 abs.  The default alpha path evaluates alpha with the oracle's bits (glibc's expf "
+                     "algorithm restated in the double pipe, csrc/exact_math.h): the alpha image IS the oracle's, so the light "
+                     "backward's T_final = 1 - alpha_image amplifies nothing (fast_alpha option: 5.8e-5 on dL_dview; DESIGN.md)"
+                     + ("" if args.variant == "light" else "; full variant: dL_dview follows the well-defined reading of ComputePG"))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -526,7 +532,15 @@ def main():
 def graph_replay_line(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--graph",
-           "--no-cpu-baseline", "--workload", args.workload, "--variant", args.variant, "--views-in-flight", str(args.views_in_flight_requested)]
+           "--no-cpu-baseline", "--workload", args.workload, "--variant", args.variant, "--views-in-flight", str(args.views_in_flight_requested),
+           "--scene", args.scene, "--sync-mode", "lazy"]
+    # (every flag that shapes the workload goes to the child, so that the figure sits beside the line it belongs to)
+    if args.tight_cull:
+        cmd.append("--tight-cull")
+    if args.blend_wgs_per_cu:
+        cmd += ["--blend-wgs-per-cu", str(args.blend_wgs_per_cu)]
+    if args.tracking:
+        cmd.append("--tracking")
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         return float(json.loads(out.stdout.strip().splitlines()[-1])["ms_per_step"])
@@ -587,7 +601,7 @@ def host_cpu():
     return model, sockets, ncores, threads or (os.cpu_count() or 1)
 
 
-def cpu_baseline(s, deg, runs):
+def cpu_baseline(s, deg, runs, variant="light"):
     """The CPU oracle (OpenMP restatement of the reference path) timed on this host as BASELINE.md s3 prescribes: built
     -O3 -march=native here, OMP threads = physical cores, 1 warm-up + `runs` repetitions of the full view, forward and
     backward timed separately.  A reported baseline, not the thing measured above."""
@@ -601,11 +615,18 @@ def cpu_baseline(s, deg, runs):
 
     def once(record):
         t0 = time.perf_counter()
-        st, out = O.light_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj,
-                                  s.tanfovx, s.tanfovy, s.H, s.W, s.shs, deg, s.campos)
-        t1 = time.perf_counter()
-        g = O.light_backward(st, s.bg, s.means, None, s.scales, s.rots, 1.0, None, s.view, s.proj, s.tanfovx, s.tanfovy,
-                             s.gC, s.gD, s.gM, s.gV, s.gt, s.shs, deg, s.campos, out["opacity_map"], s.persp)
+        if variant == "full":
+            st, out = O.full_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj,
+                                     s.tanfovx, s.tanfovy, s.H, s.W, s.shs, deg, s.campos)
+            t1 = time.perf_counter()
+            g = O.full_backward(st, s.bg, s.means, None, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj, s.tanfovx,
+                                s.tanfovy, s.gC, s.gD, s.gV, s.shs, deg, s.campos, s.persp)
+        else:
+            st, out = O.light_forward(s.bg, s.means, None, s.opac, s.scales, s.rots, 1.0, None, s.view, s.gt, s.proj,
+                                      s.tanfovx, s.tanfovy, s.H, s.W, s.shs, deg, s.campos)
+            t1 = time.perf_counter()
+            g = O.light_backward(st, s.bg, s.means, None, s.scales, s.rots, 1.0, None, s.view, s.proj, s.tanfovx, s.tanfovy,
+                                 s.gC, s.gD, s.gM, s.gV, s.gt, s.shs, deg, s.campos, out["opacity_map"], s.persp)
         t2 = time.perf_counter()
         grads.update(g)
         if record:
@@ -623,7 +644,7 @@ def cpu_baseline(s, deg, runs):
     return {"value": 1.0 / med / 1e6, "unit": "Mviews/s", "cores": cores, "kind": "port",
             "host": {"cpu": model, "sockets": sockets, "physical_cores": cores, "hardware_threads": threads,
                      "omp_threads": cores},
-            "sample": f"{len(tot)} full fwd+bwd views of the same workload after 1 warm-up: median {med:.3f} s (min "
+            "sample": f"{len(tot)} complete fwd+bwd views ({variant} variant) of the same workload after 1 warm-up: median {med:.3f} s (min "
                       f"{min(tot):.3f} s; forward median {float(np.median(tf)):.3f} s, backward {float(np.median(tb)):.3f} s), "
                       f"oracle built -O3 -march=native, {cores} OpenMP threads = physical cores of {sockets} x {model}"}, grads
 

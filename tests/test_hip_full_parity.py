@@ -97,11 +97,14 @@ def test_full_precomputed_colors_and_covariances(oracle):
         st, ref, gr = hh.oracle_full(oracle, s, 3, grads=grads, **kw)
         assert np.array_equal(d["radii"], ref["radii"])
         assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
-        for k in ("color", "depth", "uncertainty"):
-            assert_image_close(d[k], ref[k], k)
+        assert np.array_equal(d["uncertainty"], ref["uncertainty"]) and d["num_related"] == ref["num_related"]
+        assert np.array_equal(hh.hip_state("n_contrib", s, d), st.get("n_contrib"))
+        for k in ("color", "depth"):
+            a_, b_ = d[k].astype(np.float64), ref[k].astype(np.float64)
+            assert np.all(np.abs(a_ - b_) <= 1e-6 * np.maximum(1.0, np.abs(b_))), k
         g = hh.hip_full_backward(s, 3, out, grads=grads, **kw)
         names = ["dL_dmeans3D", "dL_dopacity", "dL_dview"]
         names += ["dL_dcolors"] if "colors_precomp" in kw else ["dL_dsh"]
         names += ["dL_dcov3D"] if "cov3D_precomp" in kw else ["dL_dscales", "dL_drotations"]
         for k in names:
-            assert_grad_close(g[k], gr[k], k, rel_to_max=1e-4 if k == "dL_dview" else 2e-5, elem_rtol=2e-3, elem_frac=0.1 if k == "dL_dview" else 2e-3)
+            assert_grad_close(g[k], gr[k], k, rel_to_max=1e-5, elem_rtol=2e-3, elem_frac=0.1 if k == "dL_dview" else 2e-3)

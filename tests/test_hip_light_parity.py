@@ -132,18 +132,20 @@ def test_backward_gradients(oracle, case, mode):
 IMAGES = ("color", "depth", "depth_median", "opacity_map")
 
 
-def check_backward(oracle, s, deg, track_off=False, map_off=False, end_to_end=True):
+def check_backward(oracle, s, deg, track_off=False, map_off=False, end_to_end=True, scale_modifier=1.0, view_rel_to_max=1e-5,
+                   rel_to_max=1e-5, what=None):
     P, W, H = s.P, s.W, s.H
     grads = tuple(g * (W * H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))  # pixel sums of O(1)
-    out, d = hh.hip_forward(s, deg)
-    st, ref = hh.oracle_forward(oracle, s, deg)
+    out, d = hh.hip_forward(s, deg, scale_modifier=scale_modifier)
+    st, ref = hh.oracle_forward(oracle, s, deg, scale_modifier=scale_modifier)
     # pixels where the two forward passes decided a hard threshold differently get zero incoming gradient on both
     # sides (tests/util.py): no skipped comparison, no outlier rows for them
-    grads, _ = mask_flipped_pixels(grads, hh.hip_state("n_contrib", s, d), st.get("n_contrib"), W, H, f"light P={P}",
+    grads, _ = mask_flipped_pixels(grads, hh.hip_state("n_contrib", s, d), st.get("n_contrib"), W, H, what or f"light P={P}",
                                    images=[(d[k], ref[k]) for k in IMAGES], median_margin=oracle.light_median_margin(st, ref["opacity_map"]))
-    gr = hh.oracle_backward(oracle, st, s, deg, ref["opacity_map"], track_off=track_off, map_off=map_off, grads=grads)
+    gr = hh.oracle_backward(oracle, st, s, deg, ref["opacity_map"], track_off=track_off, map_off=map_off, grads=grads,
+                            scale_modifier=scale_modifier)
     for label, alphas in (("isolated", ref["opacity_map"]), ("end-to-end", None))[:2 if end_to_end else 1]:
-        g = hh.hip_backward(s, deg, out, track_off=track_off, map_off=map_off, grads=grads, alphas=alphas)
+        g = hh.hip_backward(s, deg, out, track_off=track_off, map_off=map_off, grads=grads, alphas=alphas, scale_modifier=scale_modifier)
         for k in GRAD_NAMES:
             assert g[k].shape == gr[k].shape, k
             if map_off:
@@ -152,59 +154,47 @@ def check_backward(oracle, s, deg, track_off=False, map_off=False, end_to_end=Tr
                 # no outlier rows: the one threshold no image shows -- the backward's own `T > 0.5` median test on a T
                 # it re-derives by division -- is covered by the mask's median margin (pixels with some T_k within 1e-5
                 # of 0.5 get zero incoming gradient on both sides)
-                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-4,
+                assert_grad_close(g[k], gr[k], f"{k} [{label}]", rel_to_max=rel_to_max, elem_rtol=1e-3, elem_frac=1e-4,
                                   outlier_rows=0)
         assert g["dL_dview"].shape == (4, 4)
         if track_off:
             assert not g["dL_dview"].any()
         else:
             assert not g["dL_dview"].reshape(-1)[[3, 7, 11, 15]].any()
-            assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=1e-5, elem_rtol=1e-3,
+            assert_grad_close(g["dL_dview"], gr["dL_dview"], f"dL_dview [{label}]", rel_to_max=view_rel_to_max, elem_rtol=1e-3,
                               elem_frac=0.0 if P < 200000 else 0.1)
+            err = np.abs(np.asarray(g["dL_dview"], np.float64) - gr["dL_dview"]).max() / max(np.abs(gr["dL_dview"]).max(), 1e-30)
+            print(f"\n[dL_dview, {label}, P={P} {W}x{H}] max |d| / max |ref| = {err:.2e}")
+    return d, st, ref
 
 
 @pytest.mark.parametrize("view", [0, 3])
 def test_config4_view(oracle, view):
-    """BASELINE config 4: 2 M Gaussians at 1920x1080, one of the eight camera views each GPU renders (views 0 and 3).
-    Integer path bit for bit, images, stage-isolated gradients -- the bars of the smaller cases."""
+    """BASELINE config 4: 2 M Gaussians at 1920x1080, one of the eight camera views each GPU renders (views 0 and 3) -- the
+    bars of the smaller cases: integer path and the threshold-carrying images bit for bit, colour and depth to 1e-6 on every
+    value, gradients at 1e-5 of scale stage-isolated and end to end."""
     P, W, H, deg = 2000000, 1920, 1080, 3
     s = make_scene(P, W, H, seed=0, view_index=view)
-    _, d = hh.hip_forward(s, deg)
-    st, ref = hh.oracle_forward(oracle, s, deg)
+    d, st, ref = check_backward(oracle, s, deg)
     assert d["num_rendered"] == ref["num_rendered"] and np.array_equal(d["radii"], ref["radii"])
     assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
     assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
-    for k in IMAGES:
-        assert_image_close(d[k], ref[k], k)
-    del d, st, ref
-    check_backward(oracle, s, deg, end_to_end=False)
+    assert_images_carry_the_references_bits(d, st, ref, s)
 
 
 def test_largest_baseline_view_config5():
-    """One view of BASELINE config 5 (5 M Gaussians at 3840x2160: 16.4 M tile instances, 32 400 tiles) against the oracle:
-    the integer path bit for bit, the images, and the stage-isolated gradients with the bars of the smaller cases."""
+    """One view of BASELINE config 5 (5 M Gaussians at 3840x2160: 16.4 M tile instances, 32 400 tiles) against the oracle, with
+    the bars of the smaller cases, dL_dview included: ONE sum over 4.2 M Gaussians x their pixels, measured 3.2e-7 of the
+    gradient's scale at this size (4e-8 ... 8e-8 at config 3's, 3e-7 ... 4e-7 at config 4's; printed by check_backward) --
+    the 5e-4 this test allowed through round 6 dated from the fast alpha path."""
     P, W, H, deg = 5000000, 3840, 2160, 3
     s = make_scene(P, W, H, 0)
-    out, d = hh.hip_forward(s, deg)
-    st, ref = hh.oracle_forward(oracle_module(), s, deg)
+    O = oracle_module()
+    d, st, ref = check_backward(O, s, deg)
     assert d["num_rendered"] == ref["num_rendered"] and np.array_equal(d["radii"], ref["radii"])
     assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
     assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
-    for k in ("color", "depth", "depth_median", "opacity_map"):
-        assert_image_close(d[k], ref[k], k)
-    assert np.mean(hh.hip_state("n_contrib", s, d) != st.get("n_contrib")) <= 1e-4
-    grads = tuple(g * (W * H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
-    grads, _ = mask_flipped_pixels(grads, hh.hip_state("n_contrib", s, d), st.get("n_contrib"), W, H, "config 5 view",
-                                   images=[(d[k], ref[k]) for k in IMAGES],
-                                   median_margin=oracle_module().light_median_margin(st, ref["opacity_map"]))
-    gr = hh.oracle_backward(oracle_module(), st, s, deg, ref["opacity_map"], grads=grads)
-    g = hh.hip_backward(s, deg, out, grads=grads, alphas=ref["opacity_map"])
-    for k in GRAD_NAMES:
-        assert_grad_close(g[k], gr[k], k, rel_to_max=1e-5, elem_rtol=1e-3, elem_frac=1e-4,
-                          outlier_rows=0)
-    # the pose gradient is ONE sum over 4.2 M Gaussians x their pixels: float summation order (the reference accumulates
-    # per pixel in float) shows up at ~1e-4 of its scale
-    assert_grad_close(g["dL_dview"], gr["dL_dview"], "dL_dview", rel_to_max=5e-4, elem_rtol=1e-2, elem_frac=0.25)
+    assert_images_carry_the_references_bits(d, st, ref, s)
 
 
 def oracle_module():
