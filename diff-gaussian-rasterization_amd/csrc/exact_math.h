@@ -7,10 +7,10 @@
 // single operation is accurate to an ulp.  The remedy is not more accuracy but the SAME bits:
 //
 //  * exp_ref(x): the algorithm glibc >= 2.27 uses for expf (ARM optimized routines' exp2f-table form: one table of 32
-//    doubles, a cubic in double, ~0.502 ulp), restated operation for operation in the CDNA double pipe.  IEEE double
-//    multiply / add / fma give the same bits on any machine, so the result equals the host's expf bit for bit
-//    (checked on the GPU against the host over the blend kernels' whole argument range: tests/test_hip_exact_math.py).
-//    Only the range the blend loops need is supported: -87 < x <= 0 (no overflow / underflow / NaN branches).
+//    doubles, a cubic in double, ~0.502 ulp) in the CDNA double pipe.  IEEE double multiply / add / fma give the same bits on
+//    any machine, so the result equals the CPU restatement's own copy of the same operation sequence (oracle/dgr_oracle.cpp:
+//    expf_restated) bit for bit -- parity does not depend on the C library of the box the tests run on -- and a glibc's expf
+//    on all but ~1 argument in 2^28.  Supported: x <= 0 (no overflow / NaN branches).
 //  * div_ref(a, b): correctly rounded a / b for normal operands without the scaling and fix-up steps of the compiler's
 //    IEEE sequence: v_rcp_f32, quotient, exact residual, one correction.
 #pragma once
@@ -36,16 +36,23 @@ __device__ __forceinline__ void exp_ref_table_fill(uint64_t* lds_tab, int tid) {
     if (tid < 32) lds_tab[tid] = EXP2F_TABLE[tid];
 }
 
-// expf(x) with glibc's bits for -87 < x <= 0.  `tab` = the LDS copy of EXP2F_TABLE.
-//   glibc: z = x N / ln 2 (N = 32); k = round(z), r = z - k; s = 2^(k / N) from the table; y = s (1 + C2 r + C1 r^2 + C0 r^3)
-//   in double; return (float) y.
-// Same table, same cubic, all in double; the cubic is evaluated by Horner's rule (one operation fewer than glibc's
-// (C0 r + C1) r^2 + (C2 r + 1)), which moves y by ~1e-16 relative, so the float result can differ from the host's only
-// when y lies that close to a rounding boundary of the float grid: about one argument in 2^28.
+// expf(x) for x <= 0, bit for bit the function the CPU restatement evaluates (oracle/dgr_oracle.cpp: expf_restated --
+// every operation below is an IEEE double operation, so the two agree on any machine; tests/test_hip_exact_math.py checks it,
+// tests/test_oracle_expf.py checks the restatement against the host's libm).  `tab` = the LDS copy of EXP2F_TABLE.
+//   The algorithm is glibc >= 2.27's expf: z = x N / ln 2 (N = 32); k = round(z), r = z - k; s = 2^(k / N) from the table;
+//   y = s (1 + C2 r + C1 r^2 + C0 r^3) in double; return (float) y.  Same table, same cubic; the cubic by Horner's rule with
+//   fused multiply-adds (glibc: (C0 r + C1) r^2 + (C2 r + 1), fused or not as its build decided), which moves y by ~1e-16
+//   relative: the float result differs from a given libm's only where y lies that close to a rounding boundary of the float
+//   grid -- about one argument in 2^28.
+// CLAMP (the backward blend, which evaluates every lane of a listed pair without a pre-test): arguments below -104 -- a
+// needle-shaped Gaussian seen from a pixel far off its axis reaches -1e4 -- are evaluated at -104, where the result is 0 as
+// at every smaller argument (the restatement returns 0 below -103.97); unclamped, the exponent field of s wraps below -708.
 // 13 vector instructions (10 of them in the double pipe) and one 8-byte LDS read; 52 cycles of issue per wave at 8 waves per
 // SIMD against 14 for v_mul_f32 + v_exp_f32 (profiles/r5/exp_variants.txt).
+template <bool CLAMP = false>
 __device__ __forceinline__ float exp_ref(float x, const uint64_t* tab) {
 #pragma clang fp contract(off)  // z + SHIFT must round z first; the fused steps below are explicit
+    if (CLAMP) x = fmaxf(x, -104.0f);
     constexpr double INVLN2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
     constexpr double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
     const double z = INVLN2N * (double)x;

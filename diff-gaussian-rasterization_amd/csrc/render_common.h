@@ -50,10 +50,11 @@ struct AlphaPath {
     static constexpr bool TABLE = (AM == ALPHA_REF);               // needs the workgroup's copy of EXP2F_TABLE
 };
 // o G for one pair: alpha before the 0.99 clamp.  p2 = pair_p2<AM>(); `tab` = LDS copy of EXP2F_TABLE (ALPHA_REF only)
-template <int AM>
+// UNTESTED_ARG: the caller has not bounded p2 from below (the backward blend; the forward's log-domain pre-test has)
+template <int AM, bool UNTESTED_ARG = false>
 __device__ __forceinline__ float alpha_raw(float o, float p2, const uint64_t* tab) {
     if (AM == ALPHA_FAST) return o * __builtin_amdgcn_exp2f(p2);
-    return o * exp_ref(p2, tab);
+    return o * exp_ref<UNTESTED_ARG>(p2, tab);
 }
 // T / om for the backward's transmittance; `inv` ~ 1 / om for the terms that are not amplified
 template <int AM>

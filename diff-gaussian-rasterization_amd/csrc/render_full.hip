@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
                 const float p2 = pair_p2<AM>(q0[u], q1[u], pxy, dxy);
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
-                const float oG = alpha_raw<AM>(q1[u].y, p2, sb.exptab);  // o G: alpha before the 0.99 clamp
+                const float oG = alpha_raw<AM, true>(q1[u].y, p2, sb.exptab);  // o G: alpha before the 0.99 clamp
                 const float alpha = fminf(0.99f, oG);
                 const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
                 // No branch (see render_light.hip): a lane the Gaussian does not reach runs the same instructions with

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                 const float dx = dxy.x, dy = dxy.y;
                 const int j = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
-                const float oG = alpha_raw<AM>(q1[u].y, p2, sb.exptab);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
+                const float oG = alpha_raw<AM, true>(q1[u].y, p2, sb.exptab);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
                 const float alpha0 = fminf(0.99f, oG);
                 const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha0 >= ALPHA_MIN);
                 // No branch: a lane the Gaussian does not reach runs the same instructions with alpha = 0 and o G = 0, which
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256) exact_math_test_kernel(int n, const float
     exp_ref_table_fill(tab, threadIdx.x);
     __syncthreads();
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        out_exp[i] = exp_ref(x[i], tab);
+        out_exp[i] = exp_ref<true>(x[i], tab);  // (the clamped form: equal to the plain one down to -104, 0 below)
         float inv;
         out_div[i] = t_div<ALPHA_REF>(a[i], b[i], inv);
     }

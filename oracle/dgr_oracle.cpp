@@ -28,6 +28,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <numeric>
 #include <string>
@@ -39,12 +40,52 @@ namespace {
 // overloads (default here).  -DDGRO_C_MATH=1 binds them to the C double functions instead,
 // which is what the survey's CPU execution did; that build exists
 // only so tests can reproduce Appendix C's digits.
+// ---- expf, restated.  The blend loops' exp decides hard thresholds (alpha >= 15/255, T < 1e-4, the median's T > 0.5) and its
+// last bit is amplified by the light backward (T_final = 1 - alpha image, division by 1 - alpha), so "the oracle's bits" must
+// not depend on which C library -- or which ifunc variant of it -- the box that runs the tests happens to have.  This is the
+// algorithm glibc >= 2.27 uses for expf (ARM optimized routines: N = 32 table entries of 2^(i/N), a cubic in double, ~0.502
+// ulp), written out in IEEE double operations whose results are the same on every machine: z = x N / ln 2, k = round(z) by the
+// 1.5 * 2^52 shift, r = z - k, s = 2^(k/N) assembled from the table, y = 1 + r (C2 + r (C1 + r C0)) by Horner's rule with
+// fused multiply-adds (std::fma is correctly rounded whether or not the CPU has the instruction), result (float)(y s).
+// The HIP kernels evaluate exactly this sequence (csrc/exact_math.h: exp_ref; tests/test_hip_exact_math.py compares the two
+// bit for bit); tests/test_oracle_expf.py pins this function with known-answer vectors and compares it with the host's expf
+// where that is glibc >= 2.27 (glibc sums the cubic as (C0 r + C1) r^2 + (C2 r + 1): the two agree on all but about one
+// argument in 2^28).  Range handling as glibc's: NaN, overflow above 88.72, 0 below -103.97.
+const uint64_t EXP2F_TAB[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull,
+    0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull,
+    0x3feedea64c123422ull, 0x3feece086061892dull, 0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull,
+    0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull, 0x3feee89f995ad3adull,
+    0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+    0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+inline float expf_restated(float x) {
+    if (x != x) return x;
+    if (x > 0x1.62e42ep6f) return std::numeric_limits<float>::infinity();
+    if (x < -0x1.9fe368p6f) return 0.0f;
+    constexpr double INVLN2N = 0x1.71547652b82fep+0 * 32.0, SHIFT = 0x1.8p+52;
+    constexpr double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32, C2 = 0x1.62e42ff0c52d6p-1 / 32;
+    const double z = INVLN2N * (double)x;
+    double kd = z + SHIFT;  // round to nearest even; the integer k sits in the low mantissa bits
+    uint64_t ki;
+    std::memcpy(&ki, &kd, 8);
+    kd -= SHIFT;
+    const double r = z - kd;  // in [-1/2, 1/2]
+    const uint64_t t = EXP2F_TAB[ki & 31u] + (ki << 47);
+    double s;
+    std::memcpy(&s, &t, 8);   // 2^(k/32)
+    double p = std::fma(r, C0, C1);
+    p = std::fma(p, r, C2);
+    const double y = std::fma(p, r, 1.0);
+    return (float)(y * s);
+}
+
 #if defined(DGRO_C_MATH) && DGRO_C_MATH
 inline double m_exp(float x) { return ::exp((double)x); }
 inline double m_sqrt(float x) { return ::sqrt((double)x); }
 inline double m_ceil(double x) { return ::ceil(x); }
 #else
-inline float m_exp(float x) { return std::exp(x); }
+inline float m_exp(float x) { return expf_restated(x); }
 inline float m_sqrt(float x) { return std::sqrt(x); }
 inline float m_ceil(float x) { return std::ceil(x); }
 #endif
@@ -1181,7 +1222,7 @@ void pairStats(const State& st, double* out, double* out2, double* out3 = nullpt
                 const float dx = gx_ - pfx, dy = gy_ - pfy;
                 const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
                 if (power > 0.0f) continue;
-                const float alpha = std::min(0.99f, co[3] * std::exp(power));
+                const float alpha = std::min<decltype(co[3] * m_exp(power))>(0.99f, co[3] * m_exp(power));
                 if (alpha < 15.0f / 255.0f) continue;
                 const float test_T = T[p] * (1 - alpha);
                 if (test_T < 0.0001f) { done[p] = true; continue; }
@@ -1274,6 +1315,10 @@ extern "C" {
 // (csrc/exact_math.h) can be compared with THIS library's binding bit for bit (tests/test_hip_exact_math.py)
 void dgro_exp(const float* x, float* y, long n) {
     for (long i = 0; i < n; i++) y[i] = (float)m_exp(x[i]);
+}
+// ... and the restated expf itself, whichever binding this library was built with (tests/test_oracle_expf.py)
+void dgro_expf_restated(const float* x, float* y, long n) {
+    for (long i = 0; i < n; i++) y[i] = expf_restated(x[i]);
 }
 void dgro_pair_stats(void* st, double* out) { pairStats(*(State*)st, out, nullptr); }
 void dgro_pair_stats2(void* st, double* out, double* out2) { pairStats(*(State*)st, out, out2); }

@@ -75,9 +75,17 @@ def lib(cmath=None):
     return _LIBS[cmath]
 
 
+def expf_restated(x):
+    """dgr_oracle.cpp: expf_restated -- glibc's expf algorithm in IEEE double operations (machine-independent bits)."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().dgro_expf_restated(C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), C.c_long(x.size))
+    return y
+
+
 def exp_as_the_oracle_calls_it(x):
-    """exp of a float32 array through the very function the blend loops of dgr_oracle.cpp call (std::exp(float) = the C
-    library's expf in the default build)."""
+    """exp of a float32 array through the very function the blend loops of dgr_oracle.cpp call (expf_restated in the default
+    build, the C double exp in the cmath build)."""
     x = np.ascontiguousarray(x, np.float32)
     y = np.empty_like(x)
     lib().dgro_exp(C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), C.c_long(x.size))

@@ -23,7 +23,9 @@ for line in open(src):
         vals.setdefault(STAGE[m.group(1)], {})[m.group(2)] = float(m.group(3)) * scale
 P = 500000
 zero_expected = 64.0 * P + 256 + 6144  # the backward's accumulator rows + ticket + pose buckets: the one zero_fill launch per view
-write_cal = vals["zero_scratch"]["WRITE_SIZE"] / zero_expected
+# (round 7: the backward keeps its scratch resident and self-clearing, so the default path launches no zero_fill_kernel any more;
+#  the calibration measured 1.000 in rounds 3-6 and is taken as that when the kernel is absent from the trace)
+write_cal = vals["zero_scratch"]["WRITE_SIZE"] / zero_expected if "zero_scratch" in vals else 1.0
 out = {"_comment": f"per launch at config3 (light), from {src} (one view at a time, separate FETCH_SIZE / WRITE_SIZE / SQ passes).  "
                    "'config3': HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE.  FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM) "
                    "prescribes for wide reads on gfx950; WRITE_SIZE needs no correction: zero_fill_kernel writes "
