@@ -109,9 +109,10 @@ def main():
                          "many views per GPU); 1 (default) = BASELINE config 4's pattern, one view per GPU and one fused "
                          "all-reduce after every view; 4 = config 5's (32 views over 8 GPUs)")
     ap.add_argument("--allreduce", default="blocking", choices=["overlap", "blocking"],
-                    help="N>1: blocking = the view's stream waits for its gradient all-reduce (with several views in "
-                         "flight the other streams keep rendering under it); overlap = additionally defer the wait to "
-                         "the next view issued (for --views-in-flight 1)")
+                    help="N>1: blocking (default) = the VIEW'S STREAM waits for its gradient all-reduce, the host does not: with "
+                         "several views in flight (the default: three) the other streams keep rendering under the collective, i.e. "
+                         "it is overlapped; overlap = additionally defer that stream's wait to the next view issued (what "
+                         "--views-in-flight 1 needs to overlap anything)")
     ap.add_argument("--batch", type=int, default=0,
                     help="not the headline workload: a step renders this many camera views (2..8) of the same Gaussians through "
                          "the batched entry points (dgr_amd.batch: one per-Gaussian launch each way for the whole batch, the "
@@ -123,8 +124,10 @@ def main():
                     help="the comparison for --batch: the same views one call at a time, .grad accumulating over this many "
                          "views (autograd's `+=`) before it is reset -- what a mapping iteration over a keyframe batch does "
                          "on the one-view surface; implies --views-in-flight 1")
-    ap.add_argument("--blend-wgs-per-cu", type=int, default=0,
-                    help="dgr_set_option('blend_wgs_per_cu'): cap on the blend kernels' workgroups per CU (3..7; 0 = none). They "
+    ap.add_argument("--blend-wgs-per-cu", type=int, default=-1,
+                    help="dgr_set_option('blend_wgs_per_cu'): cap on the blend kernels' workgroups per CU (3..7; 0 = none; default "
+                         "-1 = none on one GPU, 7 with --gpus N: one wave slot per SIMD, 64 registers per lane and 20 KB of LDS stay "
+                         "free on every CU for the collective's kernels, which otherwise get in only as blend workgroups drain). They "
                          "hold every wave slot of a CU otherwise, and kernels of other streams -- RCCL's with --gpus N, other views' "
                          "front ends -- only get in as blend workgroups drain (one GPU, three views in flight: 0.448 ms per view "
                          "without, 0.445 at 7, 0.454 at 6; profiles/r5/blend_cap_summary.txt)")
@@ -180,6 +183,8 @@ def main():
 
     if args.tight_cull:
         _capi.set_option("tight_cull", 1)
+    if args.blend_wgs_per_cu < 0:
+        args.blend_wgs_per_cu = 7 if dist is not None else 0
     if args.blend_wgs_per_cu:
         _capi.set_option("blend_wgs_per_cu", args.blend_wgs_per_cu)
     if args.batch_streams:
@@ -373,6 +378,22 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # The collective by itself (untimed, after the timed region): the fused span of one view's gradients reduced with nothing
+    # else on the GPUs -- the figure the model below is checked against on the first multi-GPU run.
+    allreduce_alone_ms, payload_bytes = None, None
+    if dist is not None and arena is not None and mapping:
+        step()
+        drain()
+        span = arena.fused_span()
+        if span is not None:
+            payload_bytes = span.numel() * span.element_size()
+            buf = span.clone()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            barrier()
+            allreduce_alone_ms = (time.perf_counter() - t1) / 5 * 1e3
 
     rank_gpus = [torch.cuda.current_device()]
     if dist is not None:
@@ -477,6 +498,8 @@ def main():
                                               (f"one fused RCCL sum of 248 B/Gaussian per {G} local view(s)"
                                                + ("" if G > 1 else f" ({args.allreduce})")) if not Vb else
                                               f"one fused RCCL sum of 248 B/Gaussian per batched step of {Vb} local views (blocking)"),
+                       "allreduce_model": None if dist is None else allreduce_model(payload_bytes, world, 1e3 * elapsed / args.steps * max(1, G if not Vb else 1),
+                                                                                   allreduce_alone_ms, args.blend_wgs_per_cu),
                        "view_hbm_frac": (316 * P + 566 * V + 172 * R + 72 * N) * (views_per_s / world) / (HBM_PEAK_GBS * 1e9),
                        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -527,6 +550,30 @@ def main():
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
+
+
+XGMI_LINK_GBS, XGMI_LINKS = 153.0, 7  # MI355X: seven xGMI links per GPU, ~153 GB/s each way (MI355X_MICROARCH.md)
+
+
+def allreduce_model(payload_bytes, world, ms_per_collective_interval, alone_ms, blend_cap):
+    """What the gradient all-reduce costs on point-to-point xGMI, for the first multi-GPU run to be checked against
+    (SURVEY.md s8(e)): a ring moves 2 (N-1)/N x payload through ONE link per GPU; the direct algorithm (reduce-scatter +
+    all-gather with every peer at once) moves 2 x payload / N through each of the N-1 links.  `ceiling_*` = weak-scaling
+    efficiency if the collective were the only loss: serial = nothing overlaps it, overlapped = it hides under the other
+    views' kernels as long as it is shorter than the interval between collectives."""
+    if not payload_bytes or world < 2:
+        return {"payload_bytes": payload_bytes, "note": "one rank: nothing crosses a link"} if payload_bytes else None
+    bw = XGMI_LINK_GBS * 1e9
+    ring = 2.0 * (world - 1) / world * payload_bytes / bw * 1e3
+    direct = 2.0 * payload_bytes / world / bw * 1e3
+    t = ms_per_collective_interval
+    return {"payload_bytes": payload_bytes, "link_GBps": XGMI_LINK_GBS, "links_per_gpu": XGMI_LINKS,
+            "ring_ms": ring, "direct_ms": direct, "measured_alone_ms": alone_ms, "ms_between_collectives": t,
+            "ceiling_serial": {"ring": t / (t + ring), "direct": t / (t + direct)},
+            "ceiling_overlapped": {"ring": min(1.0, t / ring), "direct": min(1.0, t / direct)},
+            "blend_wgs_per_cu": blend_cap,
+            "note": "ms_between_collectives is THIS run's measured interval (it already contains whatever the collective cost here); "
+                    "an efficiency below ceiling_overlapped.direct means the collective's kernels were starved or serialised"}
 
 
 def graph_replay_line(args):
