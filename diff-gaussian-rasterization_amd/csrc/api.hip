@@ -679,6 +679,10 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
         g_last_error = "backward scratch too small";
         return DGR_ERR_BAD_ARGUMENT;
     }
+    // (the 3D covariance is not kept by the forward: the backward re-forms it from scale and rotation -- the SAME tensors the
+    //  forward saw, or the bits differ -- unless the caller precomputed it)
+    if (!cov3D_precomp && (!scales || !rotations)) { g_last_error = "backward: need scale/rotation or cov3D"; return DGR_ERR_BAD_ARGUMENT; }
+    if (!geom_buffer || !binning_buffer || !image_buffer) { g_last_error = "backward: the forward's three state buffers are required"; return DGR_ERR_BAD_ARGUMENT; }
     dgr::GeometryView geom = dgr::carve_geometry(geom_buffer, P);
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
@@ -819,6 +823,10 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
         g_last_error = "backward scratch too small";
         return DGR_ERR_BAD_ARGUMENT;
     }
+    // (the 3D covariance is not kept by the forward: the backward re-forms it from scale and rotation -- the SAME tensors the
+    //  forward saw, or the bits differ -- unless the caller precomputed it)
+    if (!cov3D_precomp && (!scales || !rotations)) { g_last_error = "backward: need scale/rotation or cov3D"; return DGR_ERR_BAD_ARGUMENT; }
+    if (!geom_buffer || !binning_buffer || !image_buffer) { g_last_error = "backward: the forward's three state buffers are required"; return DGR_ERR_BAD_ARGUMENT; }
     dgr::GeometryView geom = dgr::carve_geometry(geom_buffer, P);
     dgr::ImageView img = dgr::carve_image(image_buffer, width, height);
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
@@ -944,6 +952,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
     if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
     for (int v = 0; v < n_views; v++)
         if (!views[v].dL_dview) { g_last_error = "view without dL_dview"; return DGR_ERR_BAD_ARGUMENT; }
+    if (P > 0 && !cov3D_precomp && (!scales || !rotations)) { g_last_error = "backward: need scale/rotation or cov3D"; return DGR_ERR_BAD_ARGUMENT; }
     if (P == 0) {  // L/rasterize_points.cu:188: nothing runs, gradients stay zero
         for (int v = 0; v < n_views; v++) HIP_TRY(hipMemsetAsync(views[v].dL_dview, 0, 16 * 4, st));
         return DGR_OK;

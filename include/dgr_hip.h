@@ -101,7 +101,10 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
  *  - every per-Gaussian gradient output may be NULL and is then not written.  A tracking step (only `viewmatrix` requires
  *    a gradient) passes them all as NULL together with map_off = 1: the backward then forms the pose gradient alone and
  *    moves no dense per-Gaussian rows (248 bytes per Gaussian at SH degree 3).
- * `R` is the value forward returned; `radii` may be NULL (internal copy is used). */
+ * `R` is the value forward returned; `radii` may be NULL (internal copy is used).
+ * The forward does not keep the 3D covariance: unless `cov3D_precomp` is given, `scales`, `rotations` and `scale_modifier`
+ * must be the forward's (the backward re-forms the covariance from them, same expression, same bits) and may not be NULL
+ * (DGR_ERR_BAD_ARGUMENT); likewise the three state buffers. */
 int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,
                        const float* means3D, const float* shs, const float* colors_precomp, const float* alphas,
                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,

@@ -770,3 +770,32 @@ def test_tile_lists_with_equal_and_nearly_equal_depths(oracle, P, W, H, sm):
     assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
     assert np.array_equal(hh.hip_state("keys", s, d), st.get("keys"))
 
+
+
+def test_backward_rejects_missing_scale_rotation_and_state():
+    """The forward keeps no 3D covariance: a backward without cov3D_precomp needs the forward's scales and rotations, and all
+    three state buffers (a NULL used to be a GPU fault)."""
+    from dgr_amd import _capi
+    lib = _capi.load()
+    s = make_scene(300, 32, 32, 2)
+    out, _ = hh.hip_forward(s, 0)
+    (R, color, depth, median, var, alpha, radii, geom, binning, img, _, _) = out
+    dev = hh.dev()
+    P = s.P
+    p = _capi.ptr
+    t = {k: hh.T(v) for k, v in dict(bg=s.bg, m=s.means, sh=s.shs, sc=s.scales, ro=s.rots, vw=s.view, pj=s.proj, cp=s.campos, gt=s.gt,
+                                     ps=s.persp, gC=s.gC, gD=s.gD[None], gM=s.gM[None], gV=s.gV[None]).items()}
+    scratch = torch.empty((lib.dgr_light_backward_scratch_bytes(P, s.W, s.H),), dtype=torch.uint8, device=dev)
+    dview = torch.empty(16, device=dev)
+
+    def call(scales, rots, geom_):
+        return lib.dgr_light_backward(
+            _capi.stream_handle(), P, 0, 16, int(R), p(t["bg"]), s.W, s.H, p(t["m"]), p(t["sh"]), None, p(alpha), scales, 1.0, rots, None,
+            p(t["vw"]), p(t["pj"]), p(t["cp"]), s.tanfovx, s.tanfovy, p(radii), geom_, p(binning), p(img), p(t["gC"]), p(t["gD"]),
+            p(t["gM"]), p(t["gV"]), *([None] * 10), 0, None, p(t["ps"]), p(dview), None, p(t["gt"]), 0, 1, p(scratch), scratch.numel())
+
+    assert call(None, p(t["ro"]), p(geom)) == _capi.DGR_ERR_BAD_ARGUMENT
+    assert call(p(t["sc"]), None, p(geom)) == _capi.DGR_ERR_BAD_ARGUMENT
+    assert call(p(t["sc"]), p(t["ro"]), None) == _capi.DGR_ERR_BAD_ARGUMENT
+    assert call(p(t["sc"]), p(t["ro"]), p(geom)) == 0
+    torch.cuda.synchronize()
