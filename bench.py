@@ -4,7 +4,7 @@
 One "step" = one view: GaussianRasterizer.forward + backward through the reference-shaped autograd
 surface (light variant, SH degree 3, all four pixel-gradient images non-zero, track_off = map_off =
 False) on the synth-v1 scene of BASELINE config 3, inputs resident in HBM before the timed region.
-By default seven independent views are in flight on seven HIP streams (--views-in-flight; three in strict / graph / tracking mode
+By default 21 independent views are in flight on 21 HIP streams (--views-in-flight; three in strict / graph / tracking mode
 and with --gpus N; every view is
 a complete forward + backward with its own state) and the forward checks its status word lazily
 (--sync-mode); `config.ms_per_view_one_stream` is the strictly serial figure.
@@ -93,8 +93,12 @@ def main():
                          "views' blend kernels fill each other's tails; 1 = strictly one view at a time.  Measured (profiles/r6/"
                          "views_in_flight.txt, ms per step at 20 / 100 steps): 3 views 0.470-0.487 / 0.431-0.438, 5: 0.458-0.483 / "
                          "0.426-0.440, 7: 0.443-0.468 / 0.420-0.428, 9-13 as 7; even counts (4, 8) measure worse than their neighbours.  "
-                         "Default (0): 7 for the eager lazy-status mapping step on one GPU, 3 otherwise (strict status, graph replay, tracking step, "
-                         "--gpus N: measured worse with seven, or not measurable here)")
+                         "Round 7 (profiles/r7/views_in_flight.txt; the host issues a view in 0.1 ms now): the steady state is 0.415 for "
+                         "3 .. 48 views alike, the ends of a short timed region are not -- 20 steps: 3 views 0.476, 7: 0.452-0.463, 11: "
+                         "0.444-0.454, 15: 0.446, 21: 0.431-0.442, 32 / 48: 0.437 (views on one stream run one after the other; a stream "
+                         "per view lets the GPU start every forward at once and pack the tail).  "
+                         "Default (0): 21 for the eager lazy-status mapping step on one GPU, 3 otherwise (strict status, graph replay, tracking step, "
+                         "--gpus N: measured worse with more, or not measurable here)")
     ap.add_argument("--graph", action="store_true",
                     help="N=1: record one view per stream into a hipGraph (dgr_amd.multiview.CapturedStep) and replay the "
                          "graphs round-robin instead of issuing the views from Python; pays for host-bound sizes (config 2)")
@@ -292,10 +296,10 @@ def main():
 
     args.views_in_flight_requested = args.views_in_flight
     if args.views_in_flight <= 0:
-        # seven where the host issues every launch itself and never waits for a status word (the measurements above); three
+        # twenty-one where the host issues every launch itself and never waits for a status word (the measurements above); three
         # where it waits once per forward (strict: 0.478 with three views against 0.563 with seven), where the views are replayed
         # from graphs (config 2: 0.106 against 0.118), for the tracking step (0.355 against 0.378) and with a collective per view
-        args.views_in_flight = 7 if (dist is None and args.sync_mode == "lazy" and not args.graph and not args.tracking) else 3
+        args.views_in_flight = 21 if (dist is None and args.sync_mode == "lazy" and not args.graph and not args.tracking) else 3
     K = 1 if (Vb or args.group > 1) else max(1, args.views_in_flight)  # (a batch spreads its views over streams itself)
     views = ViewStreams(K, dev) if K > 1 else None  # dgr_amd.multiview: independent views on K HIP streams
 
