@@ -121,11 +121,24 @@ class _PoseToCamera(torch.autograd.Function):
         return grads[:4], grads[4:], None
 
 
+_PERSPEC = {}  # (tanfovx, tanfovy, znear, zfar, device) -> Proj^T: a constant of the sensor, built once
+
+
+def _perspec_cached(tanfovx, tanfovy, znear, zfar, device):
+    key = (float(tanfovx), float(tanfovy), float(znear), float(zfar), device)
+    m = _PERSPEC.get(key)
+    if m is None:
+        if len(_PERSPEC) > 32:
+            _PERSPEC.clear()
+        m = _PERSPEC[key] = projection_matrix(tanfovx, tanfovy, znear, zfar, device=device).transpose(0, 1).contiguous()
+    return m
+
+
 def pose_to_camera(q, t, tanfovx, tanfovy, znear=0.01, zfar=100.0):
     """(viewmatrix, projmatrix, perspec_matrix, campos) from a quaternion (r, x, y, z) and a translation, float32 GPU
     tensors: the fused form of `camera_tensors(w2c_from_quat_trans(q, t), tanfovx, tanfovy)` (2 launches for forward +
     backward instead of ~40 elementwise torch kernels)."""
-    perspec = projection_matrix(tanfovx, tanfovy, znear, zfar, device=q.device).transpose(0, 1).contiguous()
+    perspec = _perspec_cached(tanfovx, tanfovy, znear, zfar, q.device)
     view, proj, campos = _PoseToCamera.apply(q, t, perspec)
     return view, proj, perspec, campos
 
@@ -189,14 +202,20 @@ def _campos(vm):
     return torch.addcmul(r, vm[..., :3, 2], nt[..., 2:3]).contiguous()
 
 
+_ZERO_POINTS = {}  # (device, P) -> a [P, 3] zero tensor for calls whose screen-space gradient nobody reads (tracking)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, viewmatrix=None, fov=None,
-           HW=None, gt_depth=None, track_off=False, map_off=False, variant="light"):
+           HW=None, gt_depth=None, track_off=False, map_off=False, variant="light", pose_tensors=None):
     """CG-SLAM's `render()` (reference README.md:33,71).
 
     `pc`: anything with the 3DGS GaussianModel accessors `get_xyz`, `get_opacity`, `get_scaling`, `get_rotation`,
     `get_features` ([P, M, 3]) and `active_sh_degree`.  `viewmatrix` is W2C^T (differentiable for tracking); `fov` the
     two half-angle tangents; `HW` = (H, W).  `viewpoint_camera` may carry `projection_matrix` (Proj^T), `znear`, `zfar`;
     without it a symmetric frustum with znear 0.01 / zfar 100 is used.  `pipe.debug` is honoured.
+    `pose_tensors` = what `pose_to_camera(q, t, ...)` returned for this `viewmatrix` -- (viewmatrix, projmatrix, perspec_matrix,
+    campos): the projection, the full projection and the camera centre are then taken from there instead of being formed again
+    from `viewmatrix` with a dozen small torch kernels (a 640x480 tracking iteration is bound by exactly those).
     Returns the reference's dict (light: render, depth, depth_median, opacity_map, depth_var, gau_uncertainty,
     num_related_pixels; full: render, depth, opacity_map) plus the 3DGS bookkeeping entries viewspace_points,
     visibility_filter, radii."""
@@ -208,14 +227,18 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     dev = viewmatrix.device
     znear = float(_get(viewpoint_camera, "znear", 0.01)) if viewpoint_camera is not None else 0.01
     zfar = float(_get(viewpoint_camera, "zfar", 100.0)) if viewpoint_camera is not None else 100.0
-    with torch.no_grad():
-        perspec = _get(viewpoint_camera, "projection_matrix") if viewpoint_camera is not None else None
-        if perspec is None:
-            perspec = projection_matrix(tanfovx, tanfovy, znear, zfar, device=dev).transpose(0, 1).contiguous()
-        perspec = perspec.to(dev, torch.float32)
+    if pose_tensors is not None:
         vm = viewmatrix.detach()
-        projmatrix = _matmul_fixed_order(vm, perspec).contiguous()
-        campos = _campos(vm)
+        projmatrix, perspec, campos = pose_tensors[1].detach(), pose_tensors[2], pose_tensors[3].detach()
+    else:
+        with torch.no_grad():
+            perspec = _get(viewpoint_camera, "projection_matrix") if viewpoint_camera is not None else None
+            if perspec is None:
+                perspec = _perspec_cached(tanfovx, tanfovy, znear, zfar, dev)
+            perspec = perspec.to(dev, torch.float32)
+            vm = viewmatrix.detach()
+            projmatrix = _matmul_fixed_order(vm, perspec).contiguous()
+            campos = _campos(vm)
 
     means3D = pc.get_xyz
     # 3DGS keeps a zero tensor whose .grad receives the screen-space gradient (densification statistics).  A tracking
@@ -225,7 +248,15 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     opacity, scaling, rotation = pc.get_opacity, pc.get_scaling, pc.get_rotation
     mapping = (variant != "light" or not map_off) and any(
         t.requires_grad for t in (means3D, shs_or_colors, opacity, scaling, rotation))
-    screenspace_points = torch.zeros_like(means3D, requires_grad=mapping)
+    if mapping:
+        screenspace_points = torch.zeros_like(means3D, requires_grad=True)
+    else:  # never read, never written: one shared zero tensor per size instead of a fill per call
+        key = (means3D.device, means3D.shape[0])
+        screenspace_points = _ZERO_POINTS.get(key)
+        if screenspace_points is None:
+            if len(_ZERO_POINTS) > 16:
+                _ZERO_POINTS.clear()
+            screenspace_points = _ZERO_POINTS[key] = torch.zeros_like(means3D)
     debug = bool(getattr(pipe, "debug", False)) if pipe is not None else False
     common = dict(image_height=H, image_width=W, tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color,
                   scale_modifier=scaling_modifier, viewmatrix=vm, projmatrix=projmatrix,

@@ -162,6 +162,8 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--gaussians", type=int, default=100000)
     args = ap.parse_args()
+    import torch as _torch
+    _torch.autograd.set_multithreading_enabled(False)  # one device, one thread: no engine-thread hand-off per backward
     if args.graph:
         os.environ["DGR_SYNC_MODE"] = "lazy"  # a blocking status read cannot be captured
     dev = torch.device("cuda:0")

@@ -32,8 +32,9 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--gaussians", type=int, default=100000)
     args = ap.parse_args()
-    if args.graph:
-        os.environ["DGR_SYNC_MODE"] = "lazy"  # a blocking status read cannot be captured
+    if args.graph or args.fused:
+        # a blocking status read cannot be captured, and a tracking loop has no use for num_rendered on the host: no host wait
+        os.environ.setdefault("DGR_SYNC_MODE", "lazy") if not args.graph else os.environ.__setitem__("DGR_SYNC_MODE", "lazy")
     from dgr_amd import slam
     from dgr_amd.multiview import CapturedStep
     from dgr_amd.synth import camera, make_scene
@@ -47,15 +48,22 @@ def main():
     bg, gt_depth = torch.from_numpy(s.bg).to(dev), torch.from_numpy(s.gt).to(dev)
     kw = dict(fov=(tanfovx, tanfovy), HW=(H, W), gt_depth=gt_depth, track_off=False, map_off=True)
 
+    # one device, one Python thread: the autograd engine's worker thread only adds a hand-off per backward (0.47 -> 0.32 ms per
+    # iteration here); a switch of PyTorch, not of the rasterizer
+    torch.autograd.set_multithreading_enabled(False)
+
     def pose(q, t):
         if args.fused:
-            return slam.pose_to_camera(q, t, tanfovx, tanfovy)[0]
-        return slam.camera_tensors(slam.w2c_from_quat_trans(q, t), tanfovx, tanfovy)[0]
+            return slam.pose_to_camera(q, t, tanfovx, tanfovy)
+        return slam.camera_tensors(slam.w2c_from_quat_trans(q, t), tanfovx, tanfovy)
+
+    def render(cam):  # (fused: projmatrix / campos come from the pose kernel; otherwise render() forms them from the viewmatrix)
+        return slam.render(None, pc, None, bg, viewmatrix=cam[0], pose_tensors=cam if args.fused else None, **kw)
 
     q_true = torch.tensor(rot_to_quat(Rm), dtype=torch.float32, device=dev)
     t_true = torch.tensor(t_true, dtype=torch.float32, device=dev)
     with torch.no_grad():
-        obs = slam.render(None, pc, None, bg, viewmatrix=pose(q_true, t_true), **kw)
+        obs = render(pose(q_true, t_true))
     obs_c, obs_d = obs["render"].detach(), obs["depth"].detach()
 
     q = (q_true + torch.tensor([0.0, 0.004, -0.006, 0.003], device=dev)).requires_grad_()
@@ -69,7 +77,7 @@ def main():
 
     def iteration():
         opt.zero_grad(set_to_none=True)
-        out = slam.render(None, pc, None, bg, viewmatrix=pose(q, t), **kw)
+        out = render(pose(q, t))
         if args.fused:
             loss = slam.l1_loss(out["render"], out["depth"], obs_c, obs_d, 1.0, 0.5)
         else:
