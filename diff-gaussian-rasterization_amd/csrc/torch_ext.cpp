@@ -130,6 +130,25 @@ struct StateArena {
     }
 };
 
+// Strict mode's one host wait: the forward reports through an armed status slot (pinned host memory written by the forward
+// blend's first workgroup, include/dgr_hip.h: dgr_status_arm) and the host polls that memory -- the reference's blocking copy
+// of num_rendered (L/cuda_rasterizer/rasterizer_impl.cu:287) without the copy, the event and the wake-up, and with the
+// longest-list report that lets the next forward of the shape skip the tile schedule.  While a hipGraph is recorded nothing
+// can be read back: strict mode cannot be captured (as before).
+template <typename Run>
+inline void strict_status(Run& run, long cap, int* s) {
+    const long ticket = dgr_status_arm();
+    check(ticket);
+    try {
+        run(cap);
+    } catch (...) {
+        int unused[4];
+        (void)dgr_status_poll(ticket, 1, unused);  // (completed by the library: releases the slot)
+        throw;
+    }
+    check(dgr_status_poll(ticket, 1, s));
+}
+
 // mode: 0 = callback entry point (the strict mirror: allocation callbacks + the reference's blocking read),
 //       1 = presized, strict: one host wait until num_rendered is known; retries a too-small capacity itself,
 //       2 = presized, lazy: no host synchronisation; returns a status ticket (dgr_status_post) or -1 while capturing.
@@ -225,10 +244,8 @@ LightFwd light_forward_core(const Tensor& background, const Tensor& means3D_, co
     }
     long cap = capacity;
     for (;;) {
-        check(dgr_early_status_arm());
-        run(cap);
         int s[4] = {0, 0, 0, 0};
-        check(dgr_early_status_wait(s));  // the one host wait of this forward: until num_rendered is known
+        strict_status(run, cap, s);  // the one host wait of this forward: until num_rendered is known
         if (s[2]) throw std::runtime_error("Point is filtered although prefiltered is set. This shouldn't happen!");
         o.rendered = s[0];
         if (o.rendered <= cap) break;
@@ -454,10 +471,8 @@ FullFwd full_forward_core(const Tensor& background, const Tensor& means3D_, cons
     }
     long cap = capacity;
     for (;;) {
-        check(dgr_early_status_arm());
-        run(cap);
         int s[4] = {0, 0, 0, 0};
-        check(dgr_early_status_wait(s));
+        strict_status(run, cap, s);
         if (s[2]) throw std::runtime_error("Point is filtered although prefiltered is set. This shouldn't happen!");
         o.rendered = s[0];
         if (o.rendered <= cap) break;

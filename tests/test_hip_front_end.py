@@ -165,8 +165,12 @@ def test_full_variant_walks_the_static_map_too(oracle):
         g0 = hh.hip_full_backward(s, 3, out0)
     finally:
         _capi.set_option("tile_schedule", 2)
-    out1, d1 = hh.hip_full_forward(s, 3)
-    g1 = hh.hip_full_backward(s, 3, out1)
+    _capi.set_option("tile_schedule", 1)
+    try:
+        out1, d1 = hh.hip_full_forward(s, 3)
+        g1 = hh.hip_full_backward(s, 3, out1)
+    finally:
+        _capi.set_option("tile_schedule", 2)
     assert hh.hip_state("sched_flag", s, d0)[0] == 0 and hh.hip_state("sched_flag", s, d1)[0] == 1
     for k in ("color", "depth", "uncertainty", "radii"):
         assert np.array_equal(d0[k], d1[k]), k

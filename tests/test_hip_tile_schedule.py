@@ -17,6 +17,16 @@ from test_hip_light_parity import assert_images_carry_the_references_bits, check
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def schedule_always():
+    """This file checks the schedule itself: build it for every frame (the default, "tile_schedule" = 2, skips it for a shape
+    whose last reported frame had even lists -- tests/test_hip_front_end.py covers that policy)."""
+    from dgr_amd import _capi
+    _capi.set_option("tile_schedule", 1)
+    yield
+    _capi.set_option("tile_schedule", 2)
+
+
 def sched_class(n):
     """csrc/dgr_common.h: sched_class"""
     if n == 0:
