@@ -433,13 +433,16 @@ def main():
         # Counter figures come from the committed PMC passes (profiles/pmc_traffic.json; rocprofv3 cannot run inside this
         # process): HBM bytes per launch, and the vector instructions per launch of the two blend kernels.  They go stale
         # when a kernel changes, so the commit they were taken at is printed with them.
-        traffic, pmc_commit, pmc = None, None, {}
+        traffic, pmc_commit, pmc, pmc_current = None, None, {}, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):
             try:
                 pmc = json.load(open(pmc_file))
                 traffic = pmc.get(args.workload, {}).get(dominant)
                 pmc_commit = pmc.get("commit")
+                sys.path.insert(0, os.path.join(ROOT, "profiles"))
+                from make_pmc_traffic_sha import kernel_sources_sha  # noqa: E402
+                pmc_current = pmc.get("kernel_sources_sha16") == kernel_sources_sha()
             except Exception:
                 traffic, pmc = None, {}
         # The blend kernels are bound by vector-instruction issue, not by HBM: SQ_INSTS_VALU per launch x 2
@@ -509,6 +512,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_from": None if traffic is None else
                          "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, 2 x FETCH_SIZE + WRITE_SIZE), taken at commit " + str(pmc_commit),
+                         "traffic_taken_on_these_kernel_sources": pmc_current,
                          "algorithmic_bytes": abytes,
                          "avg_ms": iso_ms, "launches": stage_n[dominant],
                          "how": "HIP events in the kernel's dispatch packet, on the launching stream; `frac` is the kernel alone "

@@ -7,8 +7,14 @@ writes a known 64 * P bytes and nothing else (ratio stored in the file) -- and (
 The file records the commit the counters were taken at: bench.py prints it next to the figures, because they go stale when a
 kernel changes.   usage: make_pmc_traffic.py profiles/r5_pmc.txt <commit>"""
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+from make_pmc_traffic_sha import kernel_sources_sha  # noqa: E402
 
 STAGE = {"count_rank_kernel": "count_rank", "emit_instances_kernel": "emit_instances", "preprocess_bwd_kernel": "preprocess_bwd",
          "preprocess_fwd_kernel": "preprocess_fwd", "render_bwd_light_kernel": "render_bwd", "render_fwd_light_kernel": "render_fwd",
@@ -31,7 +37,7 @@ out = {"_comment": f"per launch at config3 (light), from {src} (one view at a ti
                    "prescribes for wide reads on gfx950; WRITE_SIZE needs no correction: zero_fill_kernel writes "
                    f"{zero_expected / 1e6:.1f} MB per launch and the counter reads {write_cal:.3f} of that.  'config3_detail' keeps "
                    "the raw parts, 'config3_insts' the instruction counts (SQ_INSTS_*).",
-       "commit": commit, "write_calibration": write_cal, "config3": {}, "config3_detail": {}, "config3_insts": {}}
+       "commit": commit, "kernel_sources_sha16": kernel_sources_sha(), "write_calibration": write_cal, "config3": {}, "config3_detail": {}, "config3_insts": {}}
 for k, v in sorted(vals.items()):
     f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
     out["config3"][k] = 2.0 * f + w
