@@ -12,6 +12,7 @@
 // "masquerading" ones)
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPCachingAllocatorMasqueradingAsCUDA.h>
 
 #include <chrono>
 #include <mutex>
@@ -84,6 +85,19 @@ inline T* ptr(const Tensor& t) {
 }
 inline char* bytes(const Tensor& t) { return t.numel() == 0 ? nullptr : reinterpret_cast<char*>(t.data_ptr()); }
 inline void* stream_of(const c10::Device& dev) { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream(); }
+
+// PyTorch's rule for a tensor read on another stream than the one it was allocated on: tell the caching allocator, or
+// the block is handed out again while that stream's kernels still read it.  A forward issued on a side stream (views in
+// flight, dgr_amd.multiview.ViewStreams) does it for its inputs -- a per-view viewmatrix or gt_depth made on the
+// caller's stream and dropped right after the call is the case that bites; the saved inputs are read by the backward
+// on the same stream, so the one record covers both.  On the default stream: one comparison.
+inline void keep_until_read(const c10::Device& dev, std::initializer_list<const Tensor*> inputs) {
+    const auto s = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index());
+    if (s == c10::hip::getDefaultHIPStreamMasqueradingAsCUDA(dev.index())) return;
+    for (const Tensor* t : inputs)
+        if (t->defined() && t->numel() != 0 && t->is_cuda())
+            c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::recordStreamMasqueradingAsCUDA(t->storage().data_ptr(), s);
+}
 
 struct Alloc {
     Tensor* t;
@@ -172,6 +186,7 @@ LightFwd light_forward_core(const Tensor& background, const Tensor& means3D_, co
                  cov3D = f32c(cov3D_, dev), view = f32c(viewmatrix_, dev), proj = f32c(projmatrix_, dev),
                  campos = f32c(campos_, dev), gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
+    keep_until_read(dev, {&means3D, &bg, &colors, &opacity, &scales, &rotations, &cov3D, &view, &proj, &campos, &gt, &sh});
     const auto u8 = at::TensorOptions().dtype(at::kByte).device(dev);
     p_pre.stop();
     Probe p_out(HP_OUT_ALLOC);
@@ -412,6 +427,7 @@ FullFwd full_forward_core(const Tensor& background, const Tensor& means3D_, cons
                  cov3D = f32c(cov3D_, dev), view = f32c(viewmatrix_, dev), proj = f32c(projmatrix_, dev),
                  campos = f32c(campos_, dev), gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
+    keep_until_read(dev, {&means3D, &bg, &colors, &opacity, &scales, &rotations, &cov3D, &view, &proj, &campos, &gt, &sh});
     const auto u8 = at::TensorOptions().dtype(at::kByte).device(dev);
     FullFwd o;
     const size_t N = (size_t)H * (size_t)W, n1 = up256(4 * N), np = up256(4 * (size_t)P);

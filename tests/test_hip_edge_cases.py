@@ -107,6 +107,24 @@ def test_oversize_tiles_and_many_batches(oracle, P):
             assert_grad_close(g[k], gr[k], k, rel_to_max=1e-5, elem_rtol=2e-3, elem_frac=2e-3)
 
 
+def test_frame_too_wide_for_the_segment_tables(oracle):
+    """250 x 144 tiles = 9 072 four-tile segments: above what bin_segments' LDS tables hold (8 192), so this frame NEEDS the
+    global-counter binning (count_rank / scan_tiles / emit_instances / sort_tiles) rather than being sent there by an option.
+    Lists, images and gradients against the oracle like every other frame."""
+    s = make_scene(20000, 4000, 2300, 2)
+    out, d = hh.hip_forward(s, 1)
+    st, ref = hh.oracle_forward(oracle, s, 1)
+    assert d["num_rendered"] == st.num_rendered > s.P
+    assert np.array_equal(hh.hip_state("ranges", s, d), st.get("ranges"))
+    assert np.array_equal(hh.hip_state("point_list", s, d), st.get("point_list"))
+    assert_images_carry_the_references_bits(d, st, ref, s)
+    grads = tuple(g * (s.W * s.H) ** 0.5 for g in (s.gC, s.gD, s.gM, s.gV))
+    gr = hh.oracle_backward(oracle, st, s, 1, ref["opacity_map"], grads=grads)
+    g = hh.hip_backward(s, 1, out, grads=grads)
+    for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dview"):
+        assert_grad_close(g[k], gr[k], k, rel_to_max=1e-5, elem_rtol=2e-3, elem_frac=2e-3)
+
+
 def test_binning_overflow_is_retried(oracle):
     """A too-small learned capacity must not change the result (presized path re-runs with a larger buffer)."""
     from dgr_amd import light as L
