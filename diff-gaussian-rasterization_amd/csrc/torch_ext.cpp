@@ -91,7 +91,9 @@ inline void* stream_of(const c10::Device& dev) { return (void*)c10::hip::getCurr
 // flight, dgr_amd.multiview.ViewStreams) does it for its inputs -- a per-view viewmatrix or gt_depth made on the
 // caller's stream and dropped right after the call is the case that bites; the saved inputs are read by the backward
 // on the same stream, so the one record covers both.  On the default stream: one comparison.
+const bool g_record_inputs = [] { const char* e = getenv("DGR_RECORD_INPUT_STREAMS"); return !(e && e[0] == '0'); }();
 inline void keep_until_read(const c10::Device& dev, std::initializer_list<const Tensor*> inputs) {
+    if (!g_record_inputs) return;  // (DGR_RECORD_INPUT_STREAMS=0: the caller keeps its inputs alive until the streams are joined)
     const auto s = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index());
     if (s == c10::hip::getDefaultHIPStreamMasqueradingAsCUDA(dev.index())) return;
     for (const Tensor* t : inputs)
@@ -372,6 +374,8 @@ std::vector<Tensor> light_backward(const Tensor& background, const Tensor& means
                  gC = f32c(dL_dout_color, dev), gD = f32c(dL_dout_depth, dev), gM = f32c(dL_dout_median, dev),
                  gV = f32c(dL_dout_var, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
+    // (the forward recorded the saved inputs; the gradient images of a graph root are whatever the caller passed in)
+    keep_until_read(dev, {&gC, &gD, &gM, &gV, &alphas, &perspec});
     Probe p_al(HP_BWD_ALLOC);
     std::vector<Tensor> g(9);
     float* gp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -532,6 +536,7 @@ std::vector<Tensor> full_backward(const Tensor& background, const Tensor& means3
                  gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev), perspec = f32c(perspec_, dev), gC = f32c(dL_dout_color, dev),
                  gD = f32c(dL_dout_depth, dev), gU = f32c(dL_dout_unc, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
+    keep_until_read(dev, {&gC, &gD, &gU, &perspec});
     std::vector<Tensor> g(9);
     float* gp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (need_gaussian_grads) {

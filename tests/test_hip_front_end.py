@@ -250,3 +250,64 @@ def test_compiled_node_keeps_its_scratch_and_agrees_with_the_python_function():
         for a, b in zip(g, g_ref):
             assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), rep
     L.check_async_errors()
+
+
+def test_inputs_made_on_the_callers_stream_and_dropped_after_the_call_stay_valid(monkeypatch):
+    """Views in flight run on side streams; PyTorch hands a freed block out again on its allocation stream without
+    waiting for other streams' readers unless the reader was recorded on it.  The compiled forward (and the backward, for
+    the gradient images of a graph root) records its inputs when it is issued on a side stream (csrc/torch_ext.cpp:
+    keep_until_read): a per-view viewmatrix / gt_depth / gradient image made on the caller's stream and dropped right
+    after the call must not be handed out again while the view's kernels are still to run.  The side stream is kept
+    busy (a 10 ms spin) so that they certainly are; the next allocations of those sizes must then come from other
+    blocks (with DGR_RECORD_INPUT_STREAMS=0 they are the same blocks: that is the hazard), and the view's results are
+    those of a run that kept its inputs."""
+    from dgr_amd import light as L
+    from dgr_amd.multiview import ViewStreams, make_settings
+    if L._C is not L._CompiledC:
+        pytest.skip("ctypes binding selected: the documented rule (keep the inputs alive until join()) applies there")
+    s = make_scene(20000, 256, 192, 3)
+    dev = hh.dev()
+    rast = L.GaussianRasterizer(make_settings(s, 3, dev))
+    leaves = [T(a).requires_grad_() for a in (s.means, s.shs, s.opac, s.scales, s.rots)]
+    m2 = torch.zeros((s.P, 3), device=dev, requires_grad=True)
+
+    def one(view, gt, grads):
+        for p_ in leaves + [m2, view]:
+            p_.grad = None
+        o = rast(means3D=leaves[0], means2D=m2, opacities=leaves[2], shs=leaves[1], scales=leaves[3], rotations=leaves[4],
+                 viewmatrix=view, gt_depth=gt)
+        torch.autograd.backward([o[0], o[2], o[3], o[4]], grads)
+        return [x.detach() for x in (o[0], o[2], o[3], o[5], view.grad, leaves[0].grad, leaves[1].grad)]  # (the graph dies here)
+
+    def fresh():
+        return (T(s.view).requires_grad_(), T(s.gt), [T(s.gC), T(s.gD[None]), T(s.gM[None]), T(s.gV[None])])
+
+    ref = [x.clone() for x in one(*fresh())]      # (strict: this call also learns the binning capacity of the shape)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("DGR_SYNC_MODE", "lazy")   # no host wait inside the forward: the calls return with everything still queued
+    views = ViewStreams(2)
+    kept, handed_out_again = [], 0
+    for rep in range(4):
+        view, gt, grads = fresh()                     # on the caller's stream
+        torch.cuda.current_stream().synchronize()
+        with views.next():
+            torch.cuda._sleep(20_000_000)              # ~10 ms: everything issued below is still to run when the inputs go
+            kept.append(one(view, gt, grads))
+        shapes = [t.shape for t in [view, gt] + grads]
+        blocks = {t.data_ptr() for t in [view, gt] + grads}
+        del view, gt, grads
+        again = [torch.full(shape, float("nan"), device=dev) for shape in shapes]   # what the caller's stream allocates next
+        handed_out_again += len(blocks & {t.data_ptr() for t in again})
+        del again
+    views.join()
+    torch.cuda.synchronize()
+    L.check_async_errors()
+    assert handed_out_again == 0, f"{handed_out_again} input blocks were reused while a side stream still had to read them"
+    for rep, got in enumerate(kept):
+        for i, (a, b) in enumerate(zip(got, ref)):
+            a, b = a.cpu().numpy(), b.cpu().numpy()
+            assert np.isfinite(a).all(), (rep, i)
+            if i < 4:
+                assert np.array_equal(a, b), (rep, i)
+            else:
+                assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), (rep, i)
