@@ -48,8 +48,10 @@ size_t blend_pad_bytes(const void* kernel) {
             known.emplace_back(kernel, static_lds);
         }
     }
-    const size_t per = (size_t)(160 * 1024) / (size_t)n;  // LDS budget of one workgroup when exactly n fit a CU
-    return per > static_lds ? ((per - static_lds) & ~(size_t)255) : 0;
+    // the smallest LDS claim that keeps workgroup n + 1 off a CU: n claims then leave the rest of the 160 KB to whatever else
+    // fits beside them (160 / n each, as through round 6, left nothing -- and every front-end kernel stages through LDS)
+    const size_t per = (((size_t)(160 * 1024) / (size_t)(n + 1)) & ~(size_t)255) + 256;
+    return per > static_lds ? per - static_lds : 0;
 }
 }
 

@@ -311,3 +311,28 @@ def test_inputs_made_on_the_callers_stream_and_dropped_after_the_call_stay_valid
                 assert np.array_equal(a, b), (rep, i)
             else:
                 assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), (rep, i)
+
+
+@pytest.mark.parametrize("variant", ["light", "full"])
+@pytest.mark.parametrize("cap", [7, 5])
+def test_capped_blend_kernels_give_the_same_view(variant, cap):
+    """dgr_set_option("blend_wgs_per_cu", n): the blend kernels claim enough dynamic LDS that only n of their workgroups fit a
+    CU (room for the other streams' kernels and RCCL's; csrc/api.hip: blend_pad_bytes).  A scheduling choice: images and lists
+    bit-identical, gradients equal up to the order of the float atomics."""
+    s = make_scene(30000, 320, 240, 6)
+    fwd, bwd = (hh.hip_forward, hh.hip_backward) if variant == "light" else (hh.hip_full_forward, hh.hip_full_backward)
+    out0, d0 = fwd(s, 3)
+    g0 = bwd(s, 3, out0)
+    keep = _capi.get_option("blend_wgs_per_cu")
+    _capi.set_option("blend_wgs_per_cu", cap)
+    try:
+        assert _capi.get_option("blend_wgs_per_cu") == cap
+        out1, d1 = fwd(s, 3)
+        g1 = bwd(s, 3, out1)
+    finally:
+        _capi.set_option("blend_wgs_per_cu", keep)
+    for k, v in d0.items():
+        if isinstance(v, np.ndarray) and k not in ("geom", "binning", "img", "gau_uncertainty"):
+            assert np.array_equal(v, d1[k]), k
+    for k in g0:
+        assert np.abs(g1[k] - g0[k]).max() <= 2e-5 * max(np.abs(g0[k]).max(), 1e-30), k
