@@ -90,7 +90,9 @@ inline void* stream_of(const c10::Device& dev) { return (void*)c10::hip::getCurr
 // the block is handed out again while that stream's kernels still read it.  A forward issued on a side stream (views in
 // flight, dgr_amd.multiview.ViewStreams) does it for its inputs -- a per-view viewmatrix or gt_depth made on the
 // caller's stream and dropped right after the call is the case that bites; the saved inputs are read by the backward
-// on the same stream, so the one record covers both.  On the default stream: one comparison.
+// on the same stream, so the one record covers both.  The ORIGINAL arguments are recorded: where f32c converts one (a
+// transposed perspec_matrix is the usual case) the conversion reads it on this stream and its result is a temporary of
+// this stream.  On the default stream: one comparison.
 const bool g_record_inputs = [] { const char* e = getenv("DGR_RECORD_INPUT_STREAMS"); return !(e && e[0] == '0'); }();
 inline void keep_until_read(const c10::Device& dev, std::initializer_list<const Tensor*> inputs) {
     if (!g_record_inputs) return;  // (DGR_RECORD_INPUT_STREAMS=0: the caller keeps its inputs alive until the streams are joined)
@@ -188,7 +190,8 @@ LightFwd light_forward_core(const Tensor& background, const Tensor& means3D_, co
                  cov3D = f32c(cov3D_, dev), view = f32c(viewmatrix_, dev), proj = f32c(projmatrix_, dev),
                  campos = f32c(campos_, dev), gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
-    keep_until_read(dev, {&means3D, &bg, &colors, &opacity, &scales, &rotations, &cov3D, &view, &proj, &campos, &gt, &sh});
+    keep_until_read(dev, {&means3D_, &background, &colors_, &opacity_, &scales_, &rotations_, &cov3D_, &viewmatrix_, &projmatrix_,
+                          &campos_, &gt_depth_, &sh_});
     const auto u8 = at::TensorOptions().dtype(at::kByte).device(dev);
     p_pre.stop();
     Probe p_out(HP_OUT_ALLOC);
@@ -375,7 +378,7 @@ std::vector<Tensor> light_backward(const Tensor& background, const Tensor& means
                  gV = f32c(dL_dout_var, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
     // (the forward recorded the saved inputs; the gradient images of a graph root are whatever the caller passed in)
-    keep_until_read(dev, {&gC, &gD, &gM, &gV, &alphas, &perspec});
+    keep_until_read(dev, {&dL_dout_color, &dL_dout_depth, &dL_dout_median, &dL_dout_var, &alphas_, &perspec_});
     Probe p_al(HP_BWD_ALLOC);
     std::vector<Tensor> g(9);
     float* gp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -431,7 +434,8 @@ FullFwd full_forward_core(const Tensor& background, const Tensor& means3D_, cons
                  cov3D = f32c(cov3D_, dev), view = f32c(viewmatrix_, dev), proj = f32c(projmatrix_, dev),
                  campos = f32c(campos_, dev), gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
-    keep_until_read(dev, {&means3D, &bg, &colors, &opacity, &scales, &rotations, &cov3D, &view, &proj, &campos, &gt, &sh});
+    keep_until_read(dev, {&means3D_, &background, &colors_, &opacity_, &scales_, &rotations_, &cov3D_, &viewmatrix_, &projmatrix_,
+                          &campos_, &gt_depth_, &sh_});
     const auto u8 = at::TensorOptions().dtype(at::kByte).device(dev);
     FullFwd o;
     const size_t N = (size_t)H * (size_t)W, n1 = up256(4 * N), np = up256(4 * (size_t)P);
@@ -536,7 +540,7 @@ std::vector<Tensor> full_backward(const Tensor& background, const Tensor& means3
                  gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev), perspec = f32c(perspec_, dev), gC = f32c(dL_dout_color, dev),
                  gD = f32c(dL_dout_depth, dev), gU = f32c(dL_dout_unc, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
-    keep_until_read(dev, {&gC, &gD, &gU, &perspec});
+    keep_until_read(dev, {&dL_dout_color, &dL_dout_depth, &dL_dout_unc, &perspec_});
     std::vector<Tensor> g(9);
     float* gp[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (need_gaussian_grads) {

@@ -271,7 +271,7 @@ def test_inputs_made_on_the_callers_stream_and_dropped_after_the_call_stay_valid
     leaves = [T(a).requires_grad_() for a in (s.means, s.shs, s.opac, s.scales, s.rots)]
     m2 = torch.zeros((s.P, 3), device=dev, requires_grad=True)
 
-    def one(view, gt, grads):
+    def one(view, gt, grads, rast=rast):
         for p_ in leaves + [m2, view]:
             p_.grad = None
         o = rast(means3D=leaves[0], means2D=m2, opacities=leaves[2], shs=leaves[1], scales=leaves[3], rotations=leaves[4],
@@ -286,23 +286,25 @@ def test_inputs_made_on_the_callers_stream_and_dropped_after_the_call_stay_valid
     torch.cuda.synchronize()
     monkeypatch.setenv("DGR_SYNC_MODE", "lazy")   # no host wait inside the forward: the calls return with everything still queued
     views = ViewStreams(2)
-    kept, handed_out_again = [], 0
+    kept, handed_out_again = [], []
     for rep in range(4):
         view, gt, grads = fresh()                     # on the caller's stream
+        settings = make_settings(s, 3, dev)           # ... and the camera's tensors (bg, projmatrix, campos, perspec_matrix)
+        cam = [settings.bg, settings.projmatrix, settings.campos, settings.perspec_matrix]  # (settings.viewmatrix: markVisible only)
         torch.cuda.current_stream().synchronize()
         with views.next():
             torch.cuda._sleep(20_000_000)              # ~10 ms: everything issued below is still to run when the inputs go
-            kept.append(one(view, gt, grads))
-        shapes = [t.shape for t in [view, gt] + grads]
-        blocks = {t.data_ptr() for t in [view, gt] + grads}
-        del view, gt, grads
+            kept.append(one(view, gt, grads, L.GaussianRasterizer(settings)))
+        shapes = [t.shape for t in [view, gt] + grads + cam]
+        blocks = {t.data_ptr(): n for t, n in zip([view, gt] + grads + cam, "view gt gC gD gM gV bg proj campos perspec".split())}
+        del view, gt, grads, settings, cam
         again = [torch.full(shape, float("nan"), device=dev) for shape in shapes]   # what the caller's stream allocates next
-        handed_out_again += len(blocks & {t.data_ptr() for t in again})
+        handed_out_again += [blocks[t.data_ptr()] for t in again if t.data_ptr() in blocks]
         del again
     views.join()
     torch.cuda.synchronize()
     L.check_async_errors()
-    assert handed_out_again == 0, f"{handed_out_again} input blocks were reused while a side stream still had to read them"
+    assert not handed_out_again, f"input blocks reused while a side stream still had to read them: {handed_out_again}"
     for rep, got in enumerate(kept):
         for i, (a, b) in enumerate(zip(got, ref)):
             a, b = a.cpu().numpy(), b.cpu().numpy()

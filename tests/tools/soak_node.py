@@ -22,6 +22,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--drop-inputs", action="store_true",
+                    help="make every view's inputs on the caller's stream right before its call and drop them right after it, with the "
+                         "views still queued on their side streams: what the compiled binding's stream record (csrc/torch_ext.cpp: "
+                         "keep_until_read) makes safe")
     args = ap.parse_args()
     from dgr_amd import light as L, full as F
     from dgr_amd.multiview import ViewStreams, make_settings
@@ -51,10 +55,12 @@ def main():
             L._USE_NODE = mode == "node"
             views = ViewStreams(int(rng.integers(2, 5)), dev) if (mode == "node" and nviews > 1) else None
             outs, keep = [], []
-            # every view's inputs are made BEFORE any view is issued and kept alive until the device has drained: a tensor
-            # allocated on the caller's stream and freed while a side stream still reads it would be handed out again
-            # (PyTorch's rule for tensors used on another stream than the one they were allocated on)
-            for s in scenes:
+            # Default: every view's inputs are made BEFORE any view is issued and kept alive until the device has drained -- a
+            # tensor allocated on the caller's stream and freed while a side stream still reads it would be handed out again
+            # (PyTorch's rule for tensors used on another stream than the one they were allocated on).  --drop-inputs does the
+            # opposite in node mode: the compiled binding records the side stream on its inputs, so it must make no difference.
+
+            def make(s):
                 leaves = [T(a).requires_grad_(not tracking) for a in (s.means, s.shs, s.opac, s.scales, s.rots)]
                 view = T(s.view).requires_grad_(True)
                 m2 = torch.zeros((P, 3), device=dev, requires_grad=not tracking)
@@ -66,9 +72,9 @@ def main():
                     rast = F.GaussianRasterizer(st)
                 else:
                     rast = L.GaussianRasterizer(make_settings(s, deg, dev, map_off=tracking))
-                keep.append((leaves, view, m2, rast, [T(s.gC), T(s.gD[None]), T(s.gM[None]), T(s.gV[None])], T(s.gt)))
-            torch.cuda.synchronize()
-            for leaves, view, m2, rast, g, gt in keep:
+                return (leaves, view, m2, rast, [T(s.gC), T(s.gD[None]), T(s.gM[None]), T(s.gV[None])], T(s.gt))
+
+            def issue(leaves, view, m2, rast, g, gt):
                 def one():
                     o = rast(means3D=leaves[0], means2D=m2, opacities=leaves[2], shs=leaves[1], scales=leaves[3], rotations=leaves[4],
                              viewmatrix=view, gt_depth=gt)
@@ -76,13 +82,27 @@ def main():
                         torch.autograd.backward([o[0], o[2], o[3]], [g[0], g[1], g[3]])
                     else:
                         torch.autograd.backward([o[0], o[2], o[3], o[4]], g)
-                    return o
+                    return [x.detach() for x in o]
                 if views is not None:
                     with views.next():
                         o = one()
                 else:
                     o = one()
-                outs.append((o, [x.grad for x in leaves + [m2, view]]))
+                return (o, [x.grad for x in leaves + [m2, view]])
+
+            drop = args.drop_inputs and mode == "node"
+            if not drop:
+                keep = [make(s) for s in scenes]
+                torch.cuda.synchronize()
+                outs = [issue(*k) for k in keep]
+            else:
+                for s in scenes:
+                    k = make(s)                       # on the caller's stream
+                    torch.cuda.current_stream().synchronize()
+                    outs.append(issue(*k))
+                    del k                             # the view is still queued on its side stream
+                    trash = [torch.full((n,), float("nan"), device=dev) for n in (16, W * H, 3 * W * H, 3 * P, 48 * P)]  # noqa: F841
+                    del trash
             if views is not None:
                 views.join()
             torch.cuda.synchronize()
@@ -112,7 +132,7 @@ def main():
         draws += 1
     L._USE_NODE = True
     assert bad == 0, f"{bad} mismatches"
-    print(f"soak_node: {draws} draws ({args.seconds:.0f} s, seed {args.seed}) -- outputs identical, worst gradient difference {worst:.2e} of scale")
+    print(f"soak_node{' --drop-inputs' if args.drop_inputs else ''}: {draws} draws ({args.seconds:.0f} s, seed {args.seed}) -- outputs identical, worst gradient difference {worst:.2e} of scale")
 
 
 if __name__ == "__main__":
