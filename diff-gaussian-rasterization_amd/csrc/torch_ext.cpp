@@ -78,6 +78,14 @@ inline Tensor f32c(const Tensor& t, const c10::Device& dev) {
     if (t.numel() == 0 || (t.scalar_type() == at::kFloat && t.is_contiguous() && t.device() == dev)) return t;
     return t.to(dev, at::kFloat).contiguous();
 }
+// perspec_matrix: the kernels read entries 0 and 5 only (L/cr/backward.cu:725-739) -- the diagonal, which a transposed
+// 4x4 (how callers usually hold Proj^T: `projection.transpose(0, 1)`) keeps in place: no copy kernel per backward for it
+inline Tensor f32c_diag4(const Tensor& t, const c10::Device& dev) {
+    if (t.scalar_type() == at::kFloat && t.device() == dev && t.dim() == 2 && t.size(0) == 4 && t.size(1) == 4 && t.stride(0) == 1 &&
+        t.stride(1) == 4)
+        return t;
+    return f32c(t, dev);
+}
 // the reference's nullptr convention: an empty tensor stands for "None"
 template <typename T>
 inline T* ptr(const Tensor& t) {
@@ -373,7 +381,7 @@ std::vector<Tensor> light_backward(const Tensor& background, const Tensor& means
     const Tensor means3D = f32c(means3D_, dev), bg = f32c(background, dev), colors = f32c(colors_, dev),
                  scales = f32c(scales_, dev), rotations = f32c(rotations_, dev), cov3D = f32c(cov3D_, dev),
                  view = f32c(viewmatrix_, dev), proj = f32c(projmatrix_, dev), campos = f32c(campos_, dev),
-                 gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev), alphas = f32c(alphas_, dev), perspec = f32c(perspec_, dev),
+                 gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev), alphas = f32c(alphas_, dev), perspec = f32c_diag4(perspec_, dev),
                  gC = f32c(dL_dout_color, dev), gD = f32c(dL_dout_depth, dev), gM = f32c(dL_dout_median, dev),
                  gV = f32c(dL_dout_var, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
@@ -537,7 +545,7 @@ std::vector<Tensor> full_backward(const Tensor& background, const Tensor& means3
     const Tensor means3D = f32c(means3D_, dev), bg = f32c(background, dev), colors = f32c(colors_, dev),
                  scales = f32c(scales_, dev), rotations = f32c(rotations_, dev), cov3D = f32c(cov3D_, dev),
                  view = f32c(viewmatrix_, dev), proj = f32c(projmatrix_, dev), campos = f32c(campos_, dev),
-                 gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev), perspec = f32c(perspec_, dev), gC = f32c(dL_dout_color, dev),
+                 gt = f32c(gt_depth_, dev), sh = f32c(sh_, dev), perspec = f32c_diag4(perspec_, dev), gC = f32c(dL_dout_color, dev),
                  gD = f32c(dL_dout_depth, dev), gU = f32c(dL_dout_unc, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
     keep_until_read(dev, {&dL_dout_color, &dL_dout_depth, &dL_dout_unc, &perspec_});
@@ -841,7 +849,7 @@ std::vector<Tensor> light_backward_batch(const Tensor& background, const Tensor&
     const Tensor means3D = f32c(means3D_, dev), bg = f32c(background, dev), colors = f32c(colors_, dev),
                  scales = f32c(scales_, dev), rotations = f32c(rotations_, dev), cov3D = f32c(cov3D_, dev),
                  views = f32c(viewmatrices_, dev), projs = f32c(projmatrices_, dev), campos = f32c(campos_, dev),
-                 gts = f32c(gt_depths_, dev), sh = f32c(sh_, dev), alphas = f32c(alphas_, dev), perspec = f32c(perspec_, dev),
+                 gts = f32c(gt_depths_, dev), sh = f32c(sh_, dev), alphas = f32c(alphas_, dev), perspec = f32c_diag4(perspec_, dev),
                  gC = f32c(dL_dout_color, dev), gD = f32c(dL_dout_depth, dev), gM = f32c(dL_dout_median, dev),
                  gV = f32c(dL_dout_var, dev);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;

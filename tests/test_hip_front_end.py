@@ -338,3 +338,38 @@ def test_capped_blend_kernels_give_the_same_view(variant, cap):
             assert np.array_equal(v, d1[k]), k
     for k in g0:
         assert np.abs(g1[k] - g0[k]).max() <= 2e-5 * max(np.abs(g0[k]).max(), 1e-30), k
+
+
+@pytest.mark.parametrize("variant", ["light", "full"])
+def test_a_transposed_perspec_matrix_is_read_in_place(variant):
+    """perspec_matrix usually reaches the rasterizer as `projection.transpose(0, 1)`: a non-contiguous tensor.  The kernels
+    read its entries 0 and 5 only (L/cuda_rasterizer/backward.cu:725-739) -- the diagonal, which keeps its place -- so the
+    compiled binding passes such a tensor as it is instead of launching a copy per backward; same pose gradient, bit for bit."""
+    from dgr_amd import light as L, full as F
+    if L._C is not L._CompiledC:
+        pytest.skip("ctypes binding selected")
+    s = make_scene(8000, 160, 120, 2)
+    dev = hh.dev()
+    persp_c = T(s.persp)                                  # contiguous
+    persp_t = persp_c.t().contiguous().t()                # same values, column-major strides
+    assert not persp_t.is_contiguous() and torch.equal(persp_c, persp_t)
+    got = []
+    for persp in (persp_c, persp_t):
+        leaves = [T(a).requires_grad_() for a in (s.means, s.shs, s.opac, s.scales, s.rots, s.view)]
+        m2 = torch.zeros((s.P, 3), device=dev, requires_grad=True)
+        if variant == "light":
+            from dgr_amd.multiview import make_settings
+            rast = L.GaussianRasterizer(make_settings(s, 3, dev)._replace(perspec_matrix=persp))
+        else:
+            rast = F.GaussianRasterizer(F.GaussianRasterizationSettings(
+                image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=T(s.bg), scale_modifier=1.0,
+                viewmatrix=T(s.view), projmatrix=T(s.proj), sh_degree=3, campos=T(s.campos), prefiltered=False, perspec_matrix=persp))
+        o = rast(means3D=leaves[0], means2D=m2, opacities=leaves[2], shs=leaves[1], scales=leaves[3], rotations=leaves[4],
+                 viewmatrix=leaves[5], gt_depth=T(s.gt))
+        if variant == "light":
+            torch.autograd.backward([o[0], o[2], o[3], o[4]], [T(s.gC), T(s.gD[None]), T(s.gM[None]), T(s.gV[None])])
+        else:
+            torch.autograd.backward([o[0], o[2], o[3]], [T(s.gC), T(s.gD[None]), T(s.gV[None])])
+        got.append(leaves[5].grad.cpu().numpy())
+    assert np.abs(got[0]).max() > 0
+    assert np.allclose(got[0], got[1], rtol=2e-5, atol=1e-7 * np.abs(got[0]).max())  # (double atomics into 64 buckets: order only)
