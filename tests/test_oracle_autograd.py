@@ -64,6 +64,7 @@ def torch_light(s, deg, vis, point_list, ranges, n_contrib, grads):
     p_hom = mh @ (leaves["view_ndc"] @ persp)
     p_w = 1.0 / (p_hom[:, 3] + 1e-7)
     pix = torch.stack([((p_hom[:, 0] * p_w + 1.0) * W - 1.0) * 0.5, ((p_hom[:, 1] * p_w + 1.0) * H - 1.0) * 0.5], 1)
+    pix.retain_grad()   # (dL_dmeans2D in pixels, for tests/tools/arbitrate_fp64.py: returned as `_pix`, rows `_idx`)
     z_depth = (mh @ leaves["view_depth"])[:, 2]                                              # (pose path 2)
     t = (mh @ view_o)[:, :3]                                                                  # (no pose gradient)
     z_cam = t[:, 2]
@@ -140,7 +141,7 @@ def torch_light(s, deg, vis, point_list, ranges, n_contrib, grads):
     gC, gD, gM, gV = (f(g) for g in grads)
     loss = (gC * color).sum() + (gD * depth).sum() + (gM * median).sum() + (gV * var).sum()
     return loss, leaves, dict(color=color.detach().numpy(), depth=depth.detach().numpy(),
-                              opacity_map=alpha_img.detach().numpy())
+                              opacity_map=alpha_img.detach().numpy(), _pix=pix, _idx=idx.numpy())
 
 
 CASES = [(400, 64, 48, 3, 11), (300, 40, 40, 0, 12), (500, 70, 45, 2, 13), (300, 40, 40, 1, 15)]

@@ -7,7 +7,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-gaussian-rasterization_amd"), os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "diff-gaussian-rasterization_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "tools")]
 import numpy as np  # noqa: E402
 
 import hip_helpers as hh  # noqa: E402
@@ -18,25 +18,14 @@ O.use_cmath(False)
 FAST = os.environ.get("DGR_FAST_ALPHA") == "1"
 n_light = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_full = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 7)
 fails, ambiguous, flips, t0 = [], [], 0, time.time()
 
 
-def draw_scene(i):
-    W = int(rng.choice([7, 16, 31, 64, 100, 129, 250, 321, 400, 803]))
-    H = int(rng.choice([5, 16, 47, 64, 97, 200, 300, 611]))
-    P = int(rng.integers(1, 30000)) if rng.random() < 0.9 else int(rng.integers(30000, 200000))
-    s = make_scene(P, W, H, 1000 + i)
-    if rng.random() < 0.4:  # round 6: non-uniform scenes (dense segments, helper workgroups, long-list merges, the tile schedule)
-        from dgr_amd.synth import cluster_scene
-        s = cluster_scene(s, frac=float(rng.uniform(0.3, 0.95)), shrink=float(rng.uniform(0.02, 0.5)),
-                          shift=(float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.3, 0.3))), seed=2000 + i)
-    mode = rng.choice(["as drawn", "translucent", "opaque"])
-    if mode == "translucent":
-        s = s._replace(opac=(s.opac * 0.12).astype(np.float32))
-    elif mode == "opaque":
-        s = s._replace(opac=np.minimum(1.0, s.opac * 0.2 + 0.85).astype(np.float32))
-    return s, int(rng.integers(0, 4)), float(rng.choice([0.3, 1.0, 1.0, 2.5, 8.0])), mode
+from soak_draws import Draws  # noqa: E402
+
+_draws = Draws(int(sys.argv[3]) if len(sys.argv) > 3 else 7)
+rng = _draws.rng
+draw_scene = _draws.scene
 
 
 for i in range(n_light):
