@@ -41,4 +41,38 @@ for case in range(24):
                            if np.asarray(v).size % P == 0 and np.asarray(v).size >= P}
         print(f"case {case:2d} {variant:5s} P={P} {W}x{H} poisoned {field:6s} x{len(rows)}: R={d['num_rendered']}, image finite: "
               f"{bool(np.isfinite(d['color']).all())}, clean rows with a non-finite gradient: {nonfinite_clean}", flush=True)
+# hostile camera / per-image inputs
+base = make_scene(20000, 250, 97, 7)
+hostile = {
+    "view all NaN": base._replace(view=np.full_like(base.view, np.nan)),
+    "view zero": base._replace(view=np.zeros_like(base.view)),
+    "proj all NaN": base._replace(proj=np.full_like(base.proj, np.nan)),
+    "proj zero": base._replace(proj=np.zeros_like(base.proj)),
+    "proj 1e30": base._replace(proj=(base.proj * 1e30).astype(np.float32)),
+    "campos NaN": base._replace(campos=np.full_like(base.campos, np.nan)),
+    "gt_depth NaN": base._replace(gt=np.full_like(base.gt, np.nan)),
+    "bg NaN": base._replace(bg=np.full_like(base.bg, np.nan)),
+    "tanfov 0": base._replace(tanfovx=0.0, tanfovy=0.0),
+    "tanfov inf": base._replace(tanfovx=float("inf"), tanfovy=float("inf")),
+    "tanfov NaN": base._replace(tanfovx=float("nan"), tanfovy=float("nan")),
+    "all means equal": base._replace(means=np.tile(base.means[:1], (base.P, 1))),
+    "all scales 1e3": base._replace(scales=np.full_like(base.scales, 1e3)),
+    "gradient images NaN": base._replace(gC=np.full_like(base.gC, np.nan), gD=np.full_like(base.gD, np.nan)),
+}
+for name, s in hostile.items():
+    for variant in ("light", "full"):
+        for sm in (1.0, 1e10, 0.0):
+            try:
+                if variant == "light":
+                    out, d = hh.hip_forward(s, 3, scale_modifier=sm)
+                    g = hh.hip_backward(s, 3, out, scale_modifier=sm)
+                else:
+                    if sm != 1.0:
+                        continue
+                    out, d = hh.hip_full_forward(s, 3)
+                    g = hh.hip_full_backward(s, 3, out)
+                torch.cuda.synchronize()
+                print(f"hostile {name:22s} {variant:5s} sm={sm:g}: R={d['num_rendered']}", flush=True)
+            except RuntimeError as e:  # an error return is fine; a fault or a hang is not
+                print(f"hostile {name:22s} {variant:5s} sm={sm:g}: raised {str(e)[:100]}", flush=True)
 print("no fault, no hang")
