@@ -13,6 +13,8 @@ Matrix convention (cuda_rasterizer/auxiliary.h:58-77 reads 16 floats column-majo
 `campos` are recomputed from the same pose but enter as constants, exactly as in the reference (its backward adds their
 dependence inside the kernels: L/cuda_rasterizer/backward.cu:633-651, 683-751).
 """
+from collections.abc import Mapping as _Mapping
+
 import torch
 
 from . import full as _full
@@ -202,6 +204,7 @@ def _campos(vm):
     return torch.addcmul(r, vm[..., :3, 2], nt[..., 2:3]).contiguous()
 
 
+_VIEWS_CACHE = {}   # render_views: camera tensors of the last few keyframe batches (see there)
 _ZERO_POINTS = {}  # (device, P) -> a [P, 3] zero tensor for calls whose screen-space gradient nobody reads (tracking)
 
 
@@ -298,25 +301,45 @@ def render_views(cameras, pc, pipe, bg_color, scaling_modifier=1.0, override_col
     for c in cameras[1:]:
         if (int(c["HW"][0]), int(c["HW"][1])) != (H, W) or (float(c["fov"][0]), float(c["fov"][1])) != (tanfovx, tanfovy):
             raise ValueError("the cameras of a batch share fov and HW")
-    viewmatrices = torch.stack([c["viewmatrix"] for c in cameras])  # (differentiable: every pose keeps its gradient)
-    dev = viewmatrices.device
     cam0 = c0.get("viewpoint_camera")
     znear = float(_get(cam0, "znear", 0.01)) if cam0 is not None else 0.01
     zfar = float(_get(cam0, "zfar", 100.0)) if cam0 is not None else 100.0
-    with torch.no_grad():
-        perspec = _get(cam0, "projection_matrix") if cam0 is not None else None
-        if perspec is None:
-            perspec = projection_matrix(tanfovx, tanfovy, znear, zfar, device=dev).transpose(0, 1).contiguous()
-        perspec = perspec.to(dev, torch.float32)
-        vm = viewmatrices.detach()
-        # (the operations of render(), in a fixed order: the cameras -- hence the images -- are those of the one-view path
-        #  bit for bit)
-        projmatrices = _matmul_fixed_order(vm, perspec).contiguous()
-        campos = _campos(vm)
-        gts = [c.get("gt_depth") for c in cameras]
-        if any(g is None for g in gts):
-            raise ValueError("the light variant needs gt_depth for every camera")
-        gt_depths = torch.stack([g.reshape(H, W) for g in gts])
+    gts = [c.get("gt_depth") for c in cameras]
+    if any(g is None for g in gts):
+        raise ValueError("the light variant needs gt_depth for every camera")
+    vms = [c["viewmatrix"] for c in cameras]
+    perspec_src = _get(cam0, "projection_matrix") if cam0 is not None else None
+    # A mapping loop renders the same keyframes iteration after iteration: the camera tensors derived from the poses (a dozen
+    # small launches) are kept while the tensors they were made from are the same objects at the same version -- an optimiser
+    # step on a pose, or a new depth image, changes the key.
+    key = (H, W, tanfovx, tanfovy, znear, zfar, id(perspec_src), getattr(perspec_src, "_version", 0),
+           tuple((id(v), v._version, id(g), g._version) for v, g in zip(vms, gts)))
+    # (never while a hipGraph is being recorded: a replay must re-derive the cameras from whatever the poses hold then)
+    capturing = vms[0].is_cuda and torch.cuda.is_current_stream_capturing()
+    hit = None if capturing else _VIEWS_CACHE.get(key)
+    if hit is None:
+        dev = vms[0].device
+        with torch.no_grad():
+            perspec = perspec_src
+            if perspec is None:
+                perspec = _perspec_cached(tanfovx, tanfovy, znear, zfar, dev)
+            perspec = perspec.to(dev, torch.float32)
+            vm = torch.stack([v.detach() for v in vms])
+            # (the operations of render(), in a fixed order: the cameras -- hence the images -- are those of the one-view
+            #  path bit for bit)
+            projmatrices = _matmul_fixed_order(vm, perspec).contiguous()
+            campos = _campos(vm)
+            gt_depths = torch.stack([g.reshape(H, W) for g in gts])
+        # (the sources are held too: an id() is only unique among live objects)
+        hit = (perspec, vm, projmatrices, campos, gt_depths, list(vms), list(gts), perspec_src)
+        if not capturing:
+            if len(_VIEWS_CACHE) >= 4:
+                _VIEWS_CACHE.pop(next(iter(_VIEWS_CACHE)))
+            _VIEWS_CACHE[key] = hit
+    perspec, vm, projmatrices, campos, gt_depths = hit[:5]
+    dev = vm.device
+    # (differentiable where a pose is a leaf: every pose keeps its gradient)
+    viewmatrices = torch.stack(vms) if any(v.requires_grad for v in vms) else vm
     means3D = pc.get_xyz
     shs_or_colors = override_color if override_color is not None else pc.get_features
     opacity, scaling, rotation = pc.get_opacity, pc.get_scaling, pc.get_rotation
@@ -337,19 +360,38 @@ def render_views(cameras, pc, pipe, bg_color, scaling_modifier=1.0, override_col
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
 
+class _ViewOf(_Mapping):
+    """View k of `render_views`' dict: entry n is `out[n][k]`, sliced when it is first asked for (a loss reads two or three
+    of the ten; every slice is an autograd node and a launch-free but not cost-free call) -- except `viewspace_points`,
+    which stays the whole [V,P,3] tensor: one backward fills every view's slice."""
+    _NAMES = ("render", "depth", "depth_median", "opacity_map", "depth_var", "gau_uncertainty", "num_related_pixels",
+              "visibility_filter", "radii", "viewspace_points")
+
+    def __init__(self, out, k):
+        self._out, self._k, self._got = out, k, {}
+
+    def __getitem__(self, n):
+        v = self._got.get(n)
+        if v is None:
+            if n not in self._NAMES:
+                raise KeyError(n)
+            v = self._got[n] = self._out[n] if n == "viewspace_points" else self._out[n][self._k]
+        return v
+
+    def __iter__(self):
+        return iter(self._NAMES)
+
+    def __len__(self):
+        return len(self._NAMES)
+
+
 def render_batch_fused(cameras, pc, pipe, bg_color, loss_fn, **render_kwargs):
     """`render_batch` through ONE batched forward and ONE batched backward (`render_views`): `loss_fn(out_k, k)` sees the
     dict of view k (slices of the batched outputs), the losses are summed and back-propagated once.  Same gradients as
     `render_batch` -- the sum over the keyframes in the Gaussians' `.grad`, one pose gradient per `viewmatrix` -- without V - 1
     accumulation passes over the dense gradient rows and with the camera-independent per-Gaussian work done once."""
     out = render_views(cameras, pc, pipe, bg_color, **render_kwargs)
-    per_view = ("render", "depth", "depth_median", "opacity_map", "depth_var", "gau_uncertainty", "num_related_pixels",
-                "visibility_filter", "radii")
-    losses = []
-    for k in range(out["render"].size(0)):
-        ok = {n: out[n][k] for n in per_view}
-        ok["viewspace_points"] = out["viewspace_points"]  # ([V,P,3]: one backward fills every view's slice)
-        losses.append(loss_fn(ok, k))
+    losses = [loss_fn(_ViewOf(out, k), k) for k in range(out["render"].size(0))]
     torch.stack(losses).sum().backward()
     return [l_.detach() for l_ in losses], out
 

@@ -182,6 +182,48 @@ def test_render_batch_fused_equals_the_serial_loop():
 
 
 @pytest.mark.gpu
+def test_render_views_keeps_the_camera_tensors_of_unchanged_keyframes():
+    """slam.render_views derives projmatrices / campos / the depth stack from the keyframes' poses once and keeps them while
+    the pose and depth tensors are the same objects at the same version; an in-place pose update (an optimiser step) or a new
+    tensor must be seen.  Every call is compared with the one-view path, which keeps nothing."""
+    dev = torch.device("cuda:0")
+    W, H = 160, 120
+    scenes = [make_scene(5000, W, H, 3, view_index=k) for k in range(3)]
+    s = scenes[0]
+    bg, gt = torch.from_numpy(s.bg).to(dev), torch.from_numpy(s.gt).to(dev)
+    m = Model(s, dev)
+    cams = [dict(viewmatrix=torch.from_numpy(sc.view).to(dev), fov=(sc.tanfovx, sc.tanfovy), HW=(H, W), gt_depth=gt) for sc in scenes]
+
+    def check(what):
+        with torch.no_grad():
+            out = slam.render_views(cams, m, None, bg)
+            for k, c in enumerate(cams):
+                o = slam.render(None, m, None, bg, viewmatrix=c["viewmatrix"], fov=c["fov"], HW=c["HW"], gt_depth=c["gt_depth"])
+                assert torch.equal(o["render"], out["render"][k]) and torch.equal(o["depth"], out["depth"][k]), (what, k)
+        return out
+
+    slam._VIEWS_CACHE.clear()
+    check("first call")
+    assert len(slam._VIEWS_CACHE) == 1
+    kept = next(iter(slam._VIEWS_CACHE.values()))
+    check("second call")
+    assert len(slam._VIEWS_CACHE) == 1 and next(iter(slam._VIEWS_CACHE.values())) is kept   # served from the kept tensors
+    with torch.no_grad():                                   # an optimiser step on pose 1: same tensor, next version
+        cams[1]["viewmatrix"][3, 0] += 0.05
+    check("pose updated in place")
+    assert next(reversed(slam._VIEWS_CACHE.values())) is not kept
+    cams[2]["viewmatrix"] = torch.from_numpy(scenes[0].view).to(dev)      # another tensor
+    check("pose replaced")
+    cams[0]["gt_depth"] = gt * 1.5                                          # another depth image
+    out = check("depth replaced")
+    assert len(slam._VIEWS_CACHE) <= 4
+    # the per-view mapping of render_batch_fused slices on demand
+    v = slam._ViewOf(out, 1)
+    assert set(v) == set(out) and torch.equal(v["render"], out["render"][1]) and v["viewspace_points"] is out["viewspace_points"]
+    assert len(v._got) == 2 and v.get("nothing") is None and "radii" in v
+
+
+@pytest.mark.gpu
 def test_tracking_iteration_replayed_from_a_hipgraph(monkeypatch):
     """The whole tracking iteration -- pose -> camera matrices -> render -> loss -> backward -> Adam step -- recorded once
     (dgr_amd.multiview.CapturedStep) and replayed: the pose converges as in the eager loop (examples/tracking.py)."""
