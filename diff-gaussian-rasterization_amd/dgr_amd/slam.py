@@ -385,12 +385,20 @@ class _ViewOf(_Mapping):
         return len(self._NAMES)
 
 
-def render_batch_fused(cameras, pc, pipe, bg_color, loss_fn, **render_kwargs):
+def render_batch_fused(cameras, pc, pipe, bg_color, loss_fn, batch_loss_fn=None, **render_kwargs):
     """`render_batch` through ONE batched forward and ONE batched backward (`render_views`): `loss_fn(out_k, k)` sees the
     dict of view k (slices of the batched outputs), the losses are summed and back-propagated once.  Same gradients as
     `render_batch` -- the sum over the keyframes in the Gaussians' `.grad`, one pose gradient per `viewmatrix` -- without V - 1
-    accumulation passes over the dense gradient rows and with the camera-independent per-Gaussian work done once."""
+    accumulation passes over the dense gradient rows and with the camera-independent per-Gaussian work done once.
+    `batch_loss_fn(out)`, if given, replaces the V calls of `loss_fn`: it sees the batched dict and returns the SUM of the
+    views' losses as one scalar (then the returned list holds that one value)."""
     out = render_views(cameras, pc, pipe, bg_color, **render_kwargs)
+    if batch_loss_fn is not None:
+        # ONE loss over the stacked outputs ([V,3,H,W], [V,1,H,W], ...): no per-view slice in the graph -- each is a node whose
+        # backward zero-fills a tensor of the whole stack's size -- and one reduction instead of V
+        total = batch_loss_fn(out)
+        total.backward()
+        return [total.detach()], out
     losses = [loss_fn(_ViewOf(out, k), k) for k in range(out["render"].size(0))]
     torch.stack(losses).sum().backward()
     return [l_.detach() for l_ in losses], out

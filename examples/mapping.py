@@ -90,17 +90,25 @@ def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None, gr
         outs[k] = out
         return slam.l1_loss(out["render"], out["depth"], obs[k][0], obs[k][1], 1.0, 0.5)  # one fused reduction
 
+    obs_color, obs_depth = torch.stack([o[0] for o in obs]), torch.stack([o[1] for o in obs])
+
+    def batch_loss_fn(out):
+        # the keyframes' L1 losses summed, as ONE fused reduction over the stacked images: sum_k (mean_k |c - c_obs| + 0.5
+        # mean_k |d - d_obs|) = V x the means over the whole stack (the keyframes share a size)
+        V = float(out["render"].size(0))
+        return slam.l1_loss(out["render"], out["depth"], obs_color, obs_depth, V * 1.0, V * 0.5)
+
     def iteration_fused():
         # the keyframe batch through ONE batched forward and ONE batched backward (dgr_amd.batch): the Gaussians' gradients
         # arrive summed over the keyframes, the screen-space gradients per view
         opt.zero_grad(set_to_none=True)
-        losses, out = slam.render_batch_fused(cams, pc, None, bg, loss_fn, **kw)
+        losses, out = slam.render_batch_fused(cams, pc, None, bg, loss_fn, batch_loss_fn=batch_loss_fn, **kw)
         pts = out["viewspace_points"].grad
         for k in range(keyframes):
             add_densification_stats(pts[k], out["radii"][k], pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)
         torch.amax(out["radii"], dim=0, out=seen)
         opt.step(visible=seen)
-        return torch.stack(losses).mean()
+        return losses[0] / keyframes   # (the batch loss is the sum over the keyframes)
 
     def iteration():
         if fused:

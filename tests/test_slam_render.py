@@ -182,6 +182,43 @@ def test_render_batch_fused_equals_the_serial_loop():
 
 
 @pytest.mark.gpu
+def test_one_loss_over_the_stacked_views_equals_the_per_view_losses():
+    """render_batch_fused(batch_loss_fn=...): the keyframes' L1 losses as ONE reduction over the stacked outputs (what
+    examples/mapping.py --fused does) against V per-view losses summed: same total, same gradients."""
+    dev = torch.device("cuda:0")
+    W, H, V = 160, 120, 3
+    scenes = [make_scene(5000, W, H, 3, view_index=k) for k in range(V)]
+    s = scenes[0]
+    bg, gt = torch.from_numpy(s.bg).to(dev), torch.from_numpy(s.gt).to(dev)
+    obs_c, obs_d = torch.rand((V, 3, H, W), device=dev), 1.0 + 4.0 * torch.rand((V, 1, H, W), device=dev)
+    names = ("get_xyz", "get_opacity", "get_scaling", "get_rotation", "get_features")
+
+    def model():
+        m = Model(s, dev)
+        for name in names:
+            setattr(m, name, getattr(m, name).clone().requires_grad_())
+        return m
+
+    def cams():
+        return [dict(viewmatrix=torch.from_numpy(sc.view).to(dev).requires_grad_(), fov=(sc.tanfovx, sc.tanfovy), HW=(H, W),
+                     gt_depth=gt) for sc in scenes]
+
+    a, ca = model(), cams()
+    la, _ = slam.render_batch_fused(ca, a, None, bg, lambda o, k: slam.l1_loss(o["render"], o["depth"], obs_c[k], obs_d[k], 1.0, 0.5))
+    b, cb = model(), cams()
+    lb, out = slam.render_batch_fused(cb, b, None, bg, None,
+                                      batch_loss_fn=lambda o: slam.l1_loss(o["render"], o["depth"], obs_c, obs_d, V * 1.0, V * 0.5))
+    torch.cuda.synchronize()
+    assert len(lb) == 1 and abs(float(lb[0]) - float(torch.stack(la).sum())) <= 2e-6 * abs(float(lb[0]))
+    for name in names:
+        ga, gb = getattr(a, name).grad.cpu().numpy(), getattr(b, name).grad.cpu().numpy()
+        assert np.abs(ga - gb).max() <= 2e-5 * np.abs(ga).max(), name
+    for k in range(V):
+        ga, gb = ca[k]["viewmatrix"].grad.cpu().numpy(), cb[k]["viewmatrix"].grad.cpu().numpy()
+        assert np.abs(ga - gb).max() <= 2e-5 * np.abs(ga).max(), k
+
+
+@pytest.mark.gpu
 def test_render_views_keeps_the_camera_tensors_of_unchanged_keyframes():
     """slam.render_views derives projmatrices / campos / the depth stack from the keyframes' poses once and keeps them while
     the pose and depth tensors are the same objects at the same version; an in-place pose update (an optimiser step) or a new
