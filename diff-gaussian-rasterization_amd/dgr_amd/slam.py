@@ -205,6 +205,7 @@ def _campos(vm):
 
 
 _VIEWS_CACHE = {}   # render_views: camera tensors of the last few keyframe batches (see there)
+_VIEW_CACHE = {}    # render: the same for single fixed poses
 _ZERO_POINTS = {}  # (device, P) -> a [P, 3] zero tensor for calls whose screen-space gradient nobody reads (tracking)
 
 
@@ -234,14 +235,29 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         vm = viewmatrix.detach()
         projmatrix, perspec, campos = pose_tensors[1].detach(), pose_tensors[2], pose_tensors[3].detach()
     else:
-        with torch.no_grad():
-            perspec = _get(viewpoint_camera, "projection_matrix") if viewpoint_camera is not None else None
-            if perspec is None:
-                perspec = _perspec_cached(tanfovx, tanfovy, znear, zfar, dev)
-            perspec = perspec.to(dev, torch.float32)
-            vm = viewmatrix.detach()
-            projmatrix = _matmul_fixed_order(vm, perspec).contiguous()
-            campos = _campos(vm)
+        perspec_src = _get(viewpoint_camera, "projection_matrix") if viewpoint_camera is not None else None
+        # a fixed keyframe pose (mapping) is rendered again and again: its derived tensors are kept while `viewmatrix` is the
+        # same object at the same version (render_views does the same for a batch); a pose under optimisation is a new
+        # tensor every iteration and is not kept; never while a hipGraph is being recorded (a replay re-derives them)
+        keep = (not viewmatrix.requires_grad and viewmatrix.is_cuda and not torch.cuda.is_current_stream_capturing())
+        key = (id(viewmatrix), viewmatrix._version, id(perspec_src), getattr(perspec_src, "_version", 0), tanfovx, tanfovy,
+               znear, zfar) if keep else None
+        hit = _VIEW_CACHE.get(key) if keep else None
+        if hit is None:
+            with torch.no_grad():
+                perspec = perspec_src
+                if perspec is None:
+                    perspec = _perspec_cached(tanfovx, tanfovy, znear, zfar, dev)
+                perspec = perspec.to(dev, torch.float32)
+                vm = viewmatrix.detach()
+                projmatrix = _matmul_fixed_order(vm, perspec).contiguous()
+                campos = _campos(vm)
+            hit = (perspec, vm, projmatrix, campos, viewmatrix, perspec_src)  # (the sources too: ids are unique among live objects)
+            if keep:
+                if len(_VIEW_CACHE) >= 16:
+                    _VIEW_CACHE.pop(next(iter(_VIEW_CACHE)))
+                _VIEW_CACHE[key] = hit
+        perspec, vm, projmatrix, campos = hit[:4]
 
     means3D = pc.get_xyz
     # 3DGS keeps a zero tensor whose .grad receives the screen-space gradient (densification statistics).  A tracking

@@ -222,7 +222,7 @@ def test_one_loss_over_the_stacked_views_equals_the_per_view_losses():
 def test_render_views_keeps_the_camera_tensors_of_unchanged_keyframes():
     """slam.render_views derives projmatrices / campos / the depth stack from the keyframes' poses once and keeps them while
     the pose and depth tensors are the same objects at the same version; an in-place pose update (an optimiser step) or a new
-    tensor must be seen.  Every call is compared with the one-view path, which keeps nothing."""
+    tensor must be seen.  Every call is compared with the one-view path after ITS cache (same rule, single poses) was emptied."""
     dev = torch.device("cuda:0")
     W, H = 160, 120
     scenes = [make_scene(5000, W, H, 3, view_index=k) for k in range(3)]
@@ -234,9 +234,14 @@ def test_render_views_keeps_the_camera_tensors_of_unchanged_keyframes():
     def check(what):
         with torch.no_grad():
             out = slam.render_views(cams, m, None, bg)
-            for k, c in enumerate(cams):
-                o = slam.render(None, m, None, bg, viewmatrix=c["viewmatrix"], fov=c["fov"], HW=c["HW"], gt_depth=c["gt_depth"])
+            one = lambda c: slam.render(None, m, None, bg, viewmatrix=c["viewmatrix"], fov=c["fov"], HW=c["HW"],  # noqa: E731
+                                        gt_depth=c["gt_depth"])
+            kept_one = [one(c) for c in cams]      # render() keeps a fixed pose's tensors by the same rule: whatever it holds now
+            slam._VIEW_CACHE.clear()
+            fresh = [one(c) for c in cams]         # ... and these calls derive them afresh (and fill the cache for the next check)
+            for k, (o, ko) in enumerate(zip(fresh, kept_one)):
                 assert torch.equal(o["render"], out["render"][k]) and torch.equal(o["depth"], out["depth"][k]), (what, k)
+                assert torch.equal(o["render"], ko["render"]) and torch.equal(o["depth"], ko["depth"]), (what, k)
         return out
 
     slam._VIEWS_CACHE.clear()
