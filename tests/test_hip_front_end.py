@@ -258,7 +258,7 @@ def test_inputs_made_on_the_callers_stream_and_dropped_after_the_call_stay_valid
     the gradient images of a graph root) records its inputs when it is issued on a side stream (csrc/torch_ext.cpp:
     keep_until_read): a per-view viewmatrix / gt_depth / gradient image made on the caller's stream and dropped right
     after the call must not be handed out again while the view's kernels are still to run.  The side stream is kept
-    busy (a 10 ms spin) so that they certainly are; the next allocations of those sizes must then come from other
+    busy (a 30 ms spin) so that they certainly are; the next allocations of those sizes must then come from other
     blocks (with DGR_RECORD_INPUT_STREAMS=0 they are the same blocks: that is the hazard), and the view's results are
     those of a run that kept its inputs."""
     from dgr_amd import light as L
@@ -293,7 +293,7 @@ def test_inputs_made_on_the_callers_stream_and_dropped_after_the_call_stay_valid
         cam = [settings.bg, settings.projmatrix, settings.campos, settings.perspec_matrix]  # (settings.viewmatrix: markVisible only)
         torch.cuda.current_stream().synchronize()
         with views.next():
-            torch.cuda._sleep(20_000_000)              # ~10 ms: everything issued below is still to run when the inputs go
+            torch.cuda._sleep(60_000_000)              # ~30 ms: everything issued below is still to run when the inputs go
             kept.append(one(view, gt, grads, L.GaussianRasterizer(settings)))
         shapes = [t.shape for t in [view, gt] + grads + cam]
         blocks = {t.data_ptr(): n for t, n in zip([view, gt] + grads + cam, "view gt gC gD gM gV bg proj campos perspec".split())}
