@@ -544,9 +544,10 @@ def main():
             line["config"]["grad_max_abs_err"] = dict(
                 errs, max=max(errs.values()), scale={k: float(np.abs(ref_grads[k]).max()) for k in pairs},
                 note="end to end (HIP forward feeding HIP backward) vs the CPU oracle, BASELINE's loss scaling; north_star's "
-                     "tolerance is 1e-5 abs.  The default alpha path evaluates alpha with the oracle's bits (glibc's expf "
-                     "algorithm restated in the double pipe, csrc/exact_math.h): the alpha image IS the oracle's, so the light "
-                     "backward's T_final = 1 - alpha_image amplifies nothing (fast_alpha option: 5.8e-5 on dL_dview; DESIGN.md)"
+                     "tolerance is 1e-5 abs.  The default alpha path evaluates alpha with the oracle's bits (one fp32-only "
+                     "polynomial expf, <= 0.9 ulp, evaluated operation for operation by both: csrc/exact_math.h, "
+                     "oracle/dgr_oracle.cpp: expf_p32): the alpha image IS the oracle's, so the light backward's "
+                     "T_final = 1 - alpha_image amplifies nothing (alpha_mode 1, fast: 5.8e-5 on dL_dview; DESIGN.md s4.6)"
                      + ("" if args.variant == "light" else "; full variant: dL_dview follows the well-defined reading of ComputePG"))
     if dist is not None:
         dist.barrier()
@@ -665,6 +666,9 @@ def cpu_baseline(s, deg, runs, variant="light"):
     O.build()
     O.use_native(True)
     O.set_threads(cores)
+    # the restatement evaluates the expf of the library's alpha mode (0: the fp32 polynomial, both sides' default; 2: glibc's form)
+    from dgr_amd import _capi as _c
+    O.set_exp_mode(1 if _c.get_option("alpha_mode") == 2 else 0)
     grads = {}
     tf, tb = [], []
 

@@ -213,14 +213,20 @@ std::atomic<int> g_profile_every{1};
 
 // dgr_set_option("tight_cull", 1): alpha-aware tile rectangles (preprocess.hip); process-wide, default off
 std::atomic<int> g_tight_cull{0};
-// dgr_set_option("fast_alpha", v): how the blend kernels evaluate alpha and T / (1 - alpha) (csrc/render_common.h).
-//   0 (default) = the reference's expression with the host library's bits (exp_ref / div_ref, csrc/exact_math.h): alpha image,
-//       n_contrib and median depth bit-identical to the CPU restatement, gradients within 1e-5 of it;
-//   1 = log2(e)-scaled conic, one v_exp_f32, v_rcp_f32: every operation good to an ulp, but the light backward's
-//       T_final = 1 - alpha and its divisions by (1 - alpha) amplify the last-bit differences to 6e-5 abs at config 3.
+// dgr_set_option("alpha_mode", v): how the blend kernels evaluate alpha and T / (1 - alpha) (csrc/render_common.h).
+//   0 (default) = the reference's expression with the CPU restatement's bits (exp_p32 / div_ref, csrc/exact_math.h): alpha
+//       image, n_contrib and median depth bit-identical to the restatement, gradients within 1e-5 of it;
+//   1 (= "fast_alpha", 1) = log2(e)-scaled conic, one v_exp_f32, v_rcp_f32: every operation good to an ulp, but the light
+//       backward's T_final = 1 - alpha and its divisions by (1 - alpha) amplify the last-bit differences to 6e-5 abs at config 3;
+//   2 = as 0 with glibc's expf algorithm in the double pipe (exp_glibc; rounds 5-7's default, the oracle's exp mode 1), for A/B.
 // Set it before the forward whose backward should use it (forward and backward of a view must use the same mode).
-// Initial value from DGR_FAST_ALPHA (for A/B runs).
-std::atomic<int> g_alpha_mode{[] { const char* e = getenv("DGR_FAST_ALPHA"); return (e && e[0] == '1') ? 1 : 0; }()};
+// Initial value from DGR_ALPHA_MODE (or DGR_FAST_ALPHA=1), for A/B runs.
+std::atomic<int> g_alpha_mode{[] {
+    const char* m = getenv("DGR_ALPHA_MODE");
+    if (m && m[0] >= '0' && m[0] <= '2' && m[1] == 0) return m[0] - '0';
+    const char* e = getenv("DGR_FAST_ALPHA");
+    return (e && e[0] == '1') ? 1 : 0;
+}()};
 // dgr_set_option("lds_count", v): how the forward bins tile instances.
 //   1 (default) = the two-level segment binning (csrc/segment_binning.hip) whenever the frame's segment tables fit LDS;
 //   0 = returning global atomics on per-tile counters (csrc/binning.hip; inside preprocess_fwd when presized), which also
@@ -1042,7 +1048,7 @@ int dgr_debug_exact_math(void* stream, int n, const float* x, const float* a, co
         g_last_error = "dgr_debug_exact_math: bad argument";
         return DGR_ERR_BAD_ARGUMENT;
     }
-    HIP_TRY(dgr::launch_exact_math_test(n, x, a, b, out_exp, out_div, (hipStream_t)stream));
+    HIP_TRY(dgr::launch_exact_math_test(n, x, a, b, out_exp, out_div, g_alpha_mode.load(), (hipStream_t)stream));
     return DGR_OK;
 }
 
@@ -1250,8 +1256,13 @@ int dgr_set_option(const char* name, int value) {
     if (n == "blend_wgs_per_cu") { g_blend_wgs_per_cu.store((value >= 3 && value <= 7) ? value : 0); return DGR_OK; }
     if (n == "tight_cull") { g_tight_cull.store(value ? 1 : 0); return DGR_OK; }
     if (n == "tile_schedule") { g_tile_schedule.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
-    if (n == "fast_alpha") {
+    if (n == "fast_alpha") {  // (the option's name before alpha_mode 2 existed)
         g_alpha_mode.store(value ? 1 : 0);
+        return DGR_OK;
+    }
+    if (n == "alpha_mode") {
+        if (value < 0 || value > 2) { g_last_error = "alpha_mode: 0 (restatement's bits, fp32 expf), 1 (fast), 2 (glibc's expf form)"; return DGR_ERR_BAD_ARGUMENT; }
+        g_alpha_mode.store(value);
         return DGR_OK;
     }
     if (n == "lds_count") { g_lds_count.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
@@ -1266,7 +1277,8 @@ int dgr_get_option(const char* name) {
     if (n == "blend_wgs_per_cu") return g_blend_wgs_per_cu.load();
     if (n == "tight_cull") return g_tight_cull.load();
     if (n == "tile_schedule") return g_tile_schedule.load();
-    if (n == "fast_alpha") return g_alpha_mode.load();
+    if (n == "fast_alpha") return g_alpha_mode.load() == 1 ? 1 : 0;
+    if (n == "alpha_mode") return g_alpha_mode.load();
     if (n == "lds_count") return g_lds_count.load();
     if (n == "profile_every") return g_profile_every.load();
     if (n == "batch_streams") return g_batch_streams.load();

@@ -288,14 +288,14 @@ hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStrea
 // start first and every XCD gets its share of a cluster
 hipError_t launch_tile_schedule(ImageView img, int tiles, hipStream_t stream);
 
-// alpha_mode: render_common.h (0 = ALPHA_REF, the reference's bits; 1 = ALPHA_FAST)
+// alpha_mode: render_common.h (0 = ALPHA_REF, the restatement's bits; 1 = ALPHA_FAST; 2 = ALPHA_GLIBC)
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, hipStream_t stream);
 hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, int alpha_mode, hipStream_t stream);
 hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hipStream_t stream);
 hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream);
 hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12, int* comp4,
                                    hipStream_t stream);
-hipError_t launch_exact_math_test(int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div,
+hipError_t launch_exact_math_test(int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div, int alpha_mode,
                                   hipStream_t stream);
 
 }  // namespace dgr

@@ -30,31 +30,37 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 constexpr float ALPHA_MIN = 15.0f / 255.0f;  // forward.cu:365
 
-// How the blend kernels evaluate alpha = min(0.99, o exp(power)) and T / (1 - alpha)  (DESIGN.md s5, exact_math.h):
+// How the blend kernels evaluate alpha = min(0.99, o exp(power)) and T / (1 - alpha)  (DESIGN.md s4.6, exact_math.h):
 //   ALPHA_REF  (default): the reference's expression in the reference's association (forward.cu:354-364,
-//       backward.cu:561-570), expf with the host library's bits (exp_ref), correctly rounded division (div_ref).  The
-//       light backward amplifies a last-bit difference of one alpha by 1 / T_final and by alpha / (1 - alpha) per
-//       division, so agreement with the CPU restatement to 1e-5 needs the same BITS, not merely the same accuracy.
-//   ALPHA_FAST (dgr_set_option("fast_alpha", 1)): the conic pre-scaled by log2(e), power from two fused multiply-adds,
-//       one v_exp_f32, v_rcp_f32 -- every operation accurate to an ulp, gradients up to 6e-5 abs away at config 3.
-// Measured at config 3 (profiles/r5/alpha_modes_summary.txt; end-to-end max |dL_dview - oracle|, forward / backward blend
-// kernel): REF 1.8e-7, 128 / 240 us; FAST 5.8e-5, 98-103 / 193-204 us; the reference association with a hi/lo-corrected
-// v_exp_f32 1.4e-5, 107 / 219 us; with ocml's expf and the compiler's IEEE division (round 2's "exact" build) 6.6e-6,
-// 115 / 271 us.  Only the path that reproduces the host's bits brings the alpha image itself to the restatement's.
-enum { ALPHA_REF = 0, ALPHA_FAST = 1 };
+//       backward.cu:561-570), expf with the CPU restatement's bits (exp_p32: an fp32-only polynomial expf, <= 0.9 ulp, the
+//       same operation sequence in oracle/dgr_oracle.cpp), correctly rounded division (div_ref).  The light backward
+//       amplifies a last-bit difference of one alpha by 1 / T_final and by alpha / (1 - alpha) per division, so agreement
+//       with the CPU restatement to 1e-5 needs the same BITS, not merely the same accuracy.
+//   ALPHA_GLIBC (dgr_set_option("alpha_mode", 2)): as ALPHA_REF with glibc's expf algorithm in the double pipe (exp_glibc) --
+//       rounds 5-7's default, kept for A/B; matches the oracle's exp mode 1.
+//   ALPHA_FAST (dgr_set_option("alpha_mode", 1) = "fast_alpha"): the conic pre-scaled by log2(e), power from two fused
+//       multiply-adds, one v_exp_f32, v_rcp_f32 -- every operation accurate to an ulp, gradients up to 6e-5 abs away at
+//       config 3.
+// Measured at config 3 (profiles/r5/alpha_modes_summary.txt, profiles/r8/ab_alpha_modes.txt; end-to-end max |dL_dview - oracle|,
+// forward / backward blend kernel): GLIBC 1.8e-7, 128 / 240 us; FAST 5.8e-5, 98-103 / 193-204 us; the reference association
+// with a hi/lo-corrected v_exp_f32 1.4e-5, 107 / 219 us; with ocml's expf and the compiler's IEEE division (round 2's
+// "exact" build) 6.6e-6, 115 / 271 us.  Only a path that reproduces the restatement's bits brings the alpha image itself to
+// the restatement's.
+enum { ALPHA_REF = 0, ALPHA_FAST = 1, ALPHA_GLIBC = 2 };
 template <int AM>
 struct AlphaPath {
     static constexpr bool LOG2 = (AM == ALPHA_FAST);               // staged conic scaled by log2(e): p2 = log2(e) power
     static constexpr float PSCALE = LOG2 ? LOG2E : 1.0f;
     static constexpr float PUNSCALE = LOG2 ? LN2 : 1.0f;
-    static constexpr bool TABLE = (AM == ALPHA_REF);               // needs the workgroup's copy of EXP2F_TABLE
+    static constexpr bool TABLE = (AM == ALPHA_GLIBC);             // needs the workgroup's copy of EXP2F_TABLE
 };
-// o G for one pair: alpha before the 0.99 clamp.  p2 = pair_p2<AM>(); `tab` = LDS copy of EXP2F_TABLE (ALPHA_REF only)
+// o G for one pair: alpha before the 0.99 clamp.  p2 = pair_p2<AM>(); `tab` = LDS copy of EXP2F_TABLE (ALPHA_GLIBC only)
 // UNTESTED_ARG: the caller has not bounded p2 from below (the backward blend; the forward's log-domain pre-test has)
 template <int AM, bool UNTESTED_ARG = false>
 __device__ __forceinline__ float alpha_raw(float o, float p2, const uint64_t* tab) {
     if (AM == ALPHA_FAST) return o * __builtin_amdgcn_exp2f(p2);
-    return o * exp_ref<UNTESTED_ARG>(p2, tab);
+    if (AM == ALPHA_GLIBC) return o * exp_glibc<UNTESTED_ARG>(p2, tab);
+    return o * exp_p32<UNTESTED_ARG>(p2);
 }
 // T / om for the backward's transmittance; `inv` ~ 1 / om for the terms that are not amplified
 template <int AM>

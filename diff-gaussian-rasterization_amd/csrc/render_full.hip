@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     __shared__ Staged s;
     __shared__ uint32_t hit[DGR_TILE_PIX];  // byte w of word j: quadrant wave w blended staged instance j
     __shared__ int s_nvalid;
-    __shared__ uint64_t exptab[32];         // ALPHA_REF: exact_math.h
+    __shared__ uint64_t exptab[32];         // ALPHA_GLIBC: exact_math.h
     if (a.rep.host && blockIdx.x == 0 && threadIdx.x == 0) report_status(a.rep, a.status);
     const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
@@ -137,7 +137,7 @@ struct StagedBwdFull {
     StagedT<BWD_NB> f;
     float acc[NACC_FULL * BWD_LD];
     int max_last;
-    uint64_t exptab[32];  // ALPHA_REF: exact_math.h
+    uint64_t exptab[32];  // ALPHA_GLIBC: exact_math.h
 };
 
 template <int AM>
@@ -303,6 +303,7 @@ hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hi
     if (tiles <= 0) return hipSuccess;
     switch (alpha_mode) {
         case ALPHA_FAST: launch_blend(render_fwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+        case ALPHA_GLIBC: launch_blend(render_fwd_full_kernel<ALPHA_GLIBC>, dim3(tiles), dim3(256), stream, a); break;
         default: launch_blend(render_fwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
     }
     return hipGetLastError();
@@ -312,6 +313,7 @@ hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hi
     if (tiles <= 0) return hipSuccess;
     switch (alpha_mode) {
         case ALPHA_FAST: launch_blend(render_bwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+        case ALPHA_GLIBC: launch_blend(render_bwd_full_kernel<ALPHA_GLIBC>, dim3(tiles), dim3(256), stream, a); break;
         default: launch_blend(render_bwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
     }
     return hipGetLastError();

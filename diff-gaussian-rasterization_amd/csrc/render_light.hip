@@ -25,8 +25,9 @@
 //    measurable gain, and a factor of two lost on a frame whose Gaussians cluster -- DESIGN.md s4.8.)
 //
 // alpha: template parameter AM (render_common.h).  ALPHA_REF, the default, evaluates the reference's expression with the
-// host library's bits (exact_math.h): the alpha image, n_contrib and the median depth then equal the CPU restatement's bit
-// for bit, which is what the light backward's T_final = 1 - alpha needs.  ALPHA_FAST (an option) is
+// CPU restatement's bits (exact_math.h: an fp32 polynomial expf; ALPHA_GLIBC: glibc's algorithm in the double pipe): the
+// alpha image, n_contrib and the median depth then equal the restatement's bit for bit, which is what the light backward's
+// T_final = 1 - alpha needs.  ALPHA_FAST (an option) is
 // o * exp2(p2) on a conic pre-scaled by log2(e) -- one v_exp_f32.  Forward and backward of one mode use the identical
 // expression, so they agree on every decision.
 #include "render_common.h"
@@ -42,7 +43,7 @@ struct StagedFwd {
     float unc[DGR_TILE_PIX];   // per staged instance: sum of (d - gt)^2 alpha T over its median pixels (forward.cu:386)
     uint32_t cnt[DGR_TILE_PIX];
     uint32_t hit[DGR_TILE_PIX];  // byte w of word j != 0 <=> some pixel of quadrant wave w blended staged instance j
-    uint64_t exptab[32];         // ALPHA_REF: exact_math.h
+    uint64_t exptab[32];         // ALPHA_GLIBC: exact_math.h
 };
 
 // Per-slot results of the batch staged at list position `pos0`: the median statistics go to the Gaussian, the
@@ -179,7 +180,7 @@ struct StagedBwd {
     StagedT<BWD_NB> f;
     float acc[NACC_LIGHT * BWD_LD];
     int max_last;
-    uint64_t exptab[32];  // ALPHA_REF: exact_math.h
+    uint64_t exptab[32];  // ALPHA_GLIBC: exact_math.h
 };
 
 // 8 waves per SIMD (63 VGPRs, no scratch): measured 258 us at the compiler's own choice of 7, 247 us at 8
@@ -375,14 +376,16 @@ __global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, f
     comp4[lane] = wave_reduce4_comp(lane);
 }
 
-// self-test of exact_math.h: out_exp[i] = exp_ref(x[i]), out_div[i] = div_ref(a[i], b[i]) (dgr_debug_exact_math)
+// self-test of exact_math.h: out_exp[i] = exp_p32(x[i]) (GLIBC: exp_glibc), out_div[i] = div_ref(a[i], b[i]) (dgr_debug_exact_math)
+template <bool GLIBC>
 __global__ void __launch_bounds__(256) exact_math_test_kernel(int n, const float* x, const float* a, const float* b, float* out_exp,
                                                              float* out_div) {
     __shared__ uint64_t tab[32];
     exp_ref_table_fill(tab, threadIdx.x);
     __syncthreads();
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        out_exp[i] = exp_ref<true>(x[i], tab);  // (the clamped form: equal to the plain one down to -104, 0 below)
+        // (the clamped forms: equal to the plain ones down to -104, 0 below)
+        out_exp[i] = GLIBC ? exp_glibc<true>(x[i], tab) : exp_p32<true>(x[i]);
         float inv;
         out_div[i] = t_div<ALPHA_REF>(a[i], b[i], inv);
     }
@@ -404,6 +407,7 @@ hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, 
     if (tiles <= 0) return hipSuccess;
     switch (alpha_mode) {
         case ALPHA_FAST: launch_blend(render_fwd_light_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+        case ALPHA_GLIBC: launch_blend(render_fwd_light_kernel<ALPHA_GLIBC>, dim3(tiles), dim3(256), stream, a); break;
         default: launch_blend(render_fwd_light_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
     }
     return hipGetLastError();
@@ -413,14 +417,18 @@ hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, int alpha_mode, 
     if (tiles <= 0 || (a.track_off && a.map_off)) return hipSuccess;
     switch (alpha_mode) {
         case ALPHA_FAST: launch_bwd_light_mode<ALPHA_FAST>(a, tiles, stream); break;
+        case ALPHA_GLIBC: launch_bwd_light_mode<ALPHA_GLIBC>(a, tiles, stream); break;
         default: launch_bwd_light_mode<ALPHA_REF>(a, tiles, stream);
     }
     return hipGetLastError();
 }
 hipError_t launch_exact_math_test(int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div,
-                                  hipStream_t stream) {
+                                  int alpha_mode, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    launch(exact_math_test_kernel, dim3(min((n + 255) / 256, 4096)), dim3(256), stream, n, x, a, b, out_exp, out_div);
+    if (alpha_mode == ALPHA_GLIBC)
+        launch(exact_math_test_kernel<true>, dim3(min((n + 255) / 256, 4096)), dim3(256), stream, n, x, a, b, out_exp, out_div);
+    else
+        launch(exact_math_test_kernel<false>, dim3(min((n + 255) / 256, 4096)), dim3(256), stream, n, x, a, b, out_exp, out_div);
     return hipGetLastError();
 }
 hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12, int* comp4,

@@ -247,13 +247,18 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
                          float* dL_ddepth);
 
 /* Process-wide options (default 0 unless stated).
- *  "fast_alpha": how the blend kernels evaluate alpha = min(0.99, o exp(power)) and T / (1 - alpha).  0 (default) = the
- *     reference's expression in the reference's association (forward.cu:354-364, backward.cu:561-570) with expf and the
- *     division rounded exactly as on the host (csrc/exact_math.h): the alpha image, n_contrib and the median depth are
- *     bit-identical to the CPU restatement and the gradients agree with it to 1e-5 abs (BASELINE's loss scaling).
+ *  "alpha_mode": how the blend kernels evaluate alpha = min(0.99, o exp(power)) and T / (1 - alpha).  0 (default) = the
+ *     reference's expression in the reference's association (forward.cu:354-364, backward.cu:561-570) with an expf and a
+ *     division whose bits the CPU restatement reproduces on any host (csrc/exact_math.h: an fp32-only polynomial expf,
+ *     <= 0.9 ulp -- as faithful to nvcc's <= 2-ulp expf as any other; the correctly rounded quotient): the alpha image,
+ *     n_contrib and the median depth are bit-identical to the restatement and the gradients agree with it to 1e-5 abs
+ *     (BASELINE's loss scaling).
  *     1 = log2(e)-scaled conic, v_exp_f32, v_rcp_f32: each operation good to an ulp and the blend kernels faster, but
  *     the light backward's T_final = 1 - alpha image and its divisions by (1 - alpha) amplify last-bit differences: up to
- *     6e-5 abs on the pose gradient at BASELINE config 3.  Forward and backward of a view must run in the same mode.
+ *     6e-5 abs on the pose gradient at BASELINE config 3.
+ *     2 = as 0 with glibc's expf algorithm evaluated in the double pipe (rounds 5-7's default; slower), kept for A/B.
+ *     Forward and backward of a view must run in the same mode.
+ *  "fast_alpha": the older name of alpha_mode 0 / 1 (get: 1 iff alpha_mode == 1).
  *  "tight_cull": 1 = alpha-aware tile rectangles.  The reference gives a Gaussian every tile its
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle
  *     is cut down to the box where alpha can reach 15/255.  Images and gradients are unchanged, but num_rendered, the
@@ -367,9 +372,10 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
  * first 12 / 4 values), comp16 / comp12 / comp4 [lane] the index of the value that lane's total belongs to.  64 entries each. */
 int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12,
                           int* comp4);
-/* Self-test of csrc/exact_math.h, the arithmetic behind the default alpha path: out_exp[i] = exp_ref(x[i]) -- expf with the
- * host C library's bits, for -87 < x <= 0 -- and out_div[i] = div_ref(a[i], b[i]) -- correctly rounded a / b for normal
- * operands.  n device floats each.  tests/test_hip_exact_math.py compares both with the host bit for bit. */
+/* Self-test of csrc/exact_math.h, the arithmetic behind the default alpha path: out_exp[i] = the current alpha mode's expf of
+ * x[i] (mode 0: exp_p32, mode 2: exp_glibc; x <= 0, clamped at -104) and out_div[i] = div_ref(a[i], b[i]) -- correctly rounded
+ * a / b for normal operands.  n device floats each.  tests/test_hip_exact_math.py compares both with the CPU restatement's
+ * functions bit for bit. */
 int dgr_debug_exact_math(void* stream, int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div);
 
 /* ---- per-stage timing (bench.py's roofline object) ----

@@ -80,12 +80,52 @@ inline float expf_restated(float x) {
     return (float)(y * s);
 }
 
+// ---- expf, restated a second way: fp32 only (round 8; the default of the float build).  Any expf good to <= 2 ulp is as
+// faithful to the reference's `exp` (nvcc's expf on a float argument, L/cr/forward.cu:364, backward.cu:565) as glibc's; this one is
+// made of operations a GPU's single-precision pipe issues at full rate, and csrc/exact_math.h: exp_p32 evaluates exactly this
+// sequence (tests/test_hip_exact_math.py: bit for bit).  Every step is one IEEE single-precision operation -- std::fmaf is
+// correctly rounded whether or not the CPU has the instruction -- or an integer shift / add, so the bits are the same on
+// every machine:
+//   t = fma(x, log2 e, M), M = 1.5 * 2^23 + 64: the round-to-nearest-even integer k of x log2 e sits in t's low mantissa bits,
+//   biased by 64;  k = t - M;  r = x - k ln 2 in two fused steps (ln 2 = hi + lo);  p = 1 + r + r^2 / 2 + r^3 (C3 + r (C4 + r (C5
+//   + r C6))) by Horner's rule, the four free coefficients minimising the relative error on |r| <= 0.3467 (3.6e-9);
+//   2^(k + 64) p by adding (bits of t) << 23 to the bits of p (M's bits vanish in the shift);  times 2^-64 -- exact for normal
+//   results, one rounding for denormal ones.
+// Error against exp() in double over all 1 120 927 745 floats of [-104, -0]: <= 0.892 ulp (0.858 ulp where the result is denormal),
+// 99.52 % correctly rounded (dgro_expf_p32_scan, tests/test_oracle_expf.py).  Arguments below -104 (and NaN) are evaluated at
+// -104, where the result is 0 as at every smaller argument.  Supported: x <= 0 (the blend loops reject power > 0 before).
+inline float expf_p32(float x) {
+    x = std::fmax(x, -104.0f);  // (fmaxf: a NaN argument yields -104, as v_max_f32 does)
+    constexpr float LOG2E = 0x1.715476p+0f, M = 12582976.0f, NLN2HI = -0x1.62e430p-1f, NLN2LO = 0x1.05c610p-29f;
+    constexpr float C3 = 0x1.5554a4p-3f, C4 = 0x1.555688p-5f, C5 = 0x1.122faep-7f, C6 = 0x1.6b6e26p-10f;
+    const float t = std::fma(x, LOG2E, M);
+    const float k = t - M;
+    float r = std::fma(k, NLN2HI, x);
+    r = std::fma(k, NLN2LO, r);
+    float p = std::fma(C6, r, C5);
+    p = std::fma(p, r, C4);
+    p = std::fma(p, r, C3);
+    p = std::fma(p, r, 0.5f);
+    p = std::fma(p, r, 1.0f);
+    p = std::fma(p, r, 1.0f);
+    uint32_t tb, pb;
+    std::memcpy(&tb, &t, 4);
+    std::memcpy(&pb, &p, 4);
+    const uint32_t b = (tb << 23) + pb;
+    float y;
+    std::memcpy(&y, &b, 4);
+    return y * 0x1p-64f;
+}
+// which of the two restated expf the float build's blend loops call: 0 = expf_p32 (default; the HIP kernels' alpha mode 0),
+// 1 = expf_restated, glibc's algorithm (the kernels' alpha mode 2; rounds 5-7's default).  dgro_set_exp_mode.
+int g_exp_mode = 0;
+
 #if defined(DGRO_C_MATH) && DGRO_C_MATH
 inline double m_exp(float x) { return ::exp((double)x); }
 inline double m_sqrt(float x) { return ::sqrt((double)x); }
 inline double m_ceil(double x) { return ::ceil(x); }
 #else
-inline float m_exp(float x) { return expf_restated(x); }
+inline float m_exp(float x) { return g_exp_mode ? expf_restated(x) : expf_p32(x); }
 inline float m_sqrt(float x) { return std::sqrt(x); }
 inline float m_ceil(float x) { return std::ceil(x); }
 #endif
@@ -1311,14 +1351,62 @@ void pairStats(const State& st, double* out, double* out2, double* out3 = nullpt
 }
 
 extern "C" {
-// y[i] = the exponential exactly as renderForward / renderBackward call it (m_exp on a float), so that the GPU's exp_ref
-// (csrc/exact_math.h) can be compared with THIS library's binding bit for bit (tests/test_hip_exact_math.py)
+// y[i] = the exponential exactly as renderForward / renderBackward call it (m_exp on a float), so that the GPU's exp_p32 /
+// exp_glibc (csrc/exact_math.h) can be compared with THIS library's binding bit for bit (tests/test_hip_exact_math.py)
 void dgro_exp(const float* x, float* y, long n) {
     for (long i = 0; i < n; i++) y[i] = (float)m_exp(x[i]);
 }
-// ... and the restated expf itself, whichever binding this library was built with (tests/test_oracle_expf.py)
+// ... and the two restated expf themselves, whichever binding this library was built with (tests/test_oracle_expf.py)
 void dgro_expf_restated(const float* x, float* y, long n) {
     for (long i = 0; i < n; i++) y[i] = expf_restated(x[i]);
+}
+void dgro_expf_p32(const float* x, float* y, long n) {
+    for (long i = 0; i < n; i++) y[i] = expf_p32(x[i]);
+}
+// which one the float build's blend loops call (0 = expf_p32, the default; 1 = expf_restated); returns the previous mode
+int dgro_set_exp_mode(int mode) {
+    const int old = g_exp_mode;
+    g_exp_mode = mode ? 1 : 0;
+    return old;
+}
+// expf_p32 against exp() in double on EVERY float whose bit pattern lies in [lo_bits, hi_bits] (negative floats: 0x80000000 =
+// -0.0 ... 0xc2d00000 = -104.0).  out = {largest error in ulps where the result is normal, the same where it is denormal
+// (in units of 2^-149), arguments whose result is not the correctly rounded one, arguments scanned, argument bits of the
+// two maxima}.
+void dgro_expf_p32_scan(uint32_t lo_bits, uint32_t hi_bits, double* out) {
+    double worst_n = 0, worst_d = 0, at_n = 0, at_d = 0;
+    long bad = 0, total = 0;
+#pragma omp parallel
+    {
+        double ln = 0, ld = 0;
+        uint32_t an = 0, ad = 0;
+        long lb = 0, lt = 0;
+#pragma omp for schedule(static)
+        for (int64_t u = lo_bits; u <= (int64_t)hi_bits; u++) {
+            const uint32_t ub = (uint32_t)u;
+            float x;
+            std::memcpy(&x, &ub, 4);
+            const float y = expf_p32(x);
+            const double t = ::exp((double)x);
+            int e;
+            std::frexp(t, &e);
+            const double ulp = std::ldexp(1.0, std::max(e - 24, -149));
+            const double err = std::fabs((double)y - t) / ulp;
+            if (t >= 0x1p-126) {
+                if (err > ln) { ln = err; an = ub; }
+            } else if (err > ld) { ld = err; ad = ub; }
+            lb += (y != (float)t);
+            lt++;
+        }
+#pragma omp critical
+        {
+            if (ln > worst_n) { worst_n = ln; at_n = an; }
+            if (ld > worst_d) { worst_d = ld; at_d = ad; }
+            bad += lb;
+            total += lt;
+        }
+    }
+    out[0] = worst_n; out[1] = worst_d; out[2] = (double)bad; out[3] = (double)total; out[4] = at_n; out[5] = at_d;
 }
 void dgro_pair_stats(void* st, double* out) { pairStats(*(State*)st, out, nullptr); }
 void dgro_pair_stats2(void* st, double* out, double* out2) { pairStats(*(State*)st, out, out2); }

@@ -18,6 +18,7 @@ _LIBS = {}
 # use_cmath(True) / DGR_ORACLE_CMATH=1 selects the second one for subsequently created states.
 _CMATH = os.environ.get("DGR_ORACLE_CMATH") == "1"
 _NATIVE = False
+_EXP_MODE = 0
 
 
 def use_cmath(flag):
@@ -71,6 +72,7 @@ def lib(cmath=None):
         l.dgro_state_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_long]
         l.dgro_state_set_dims.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         l.dgro_state_num_rendered.argtypes = [C.c_void_p]
+        l.dgro_set_exp_mode(C.c_int(_EXP_MODE))
         _LIBS[cmath] = l
     return _LIBS[cmath]
 
@@ -83,9 +85,37 @@ def expf_restated(x):
     return y
 
 
+def expf_p32(x):
+    """dgr_oracle.cpp: expf_p32 -- the fp32-only expf (fused multiply-adds and an exponent-field add; machine-independent bits),
+    the default exponential of the float build since round 8."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().dgro_expf_p32(C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), C.c_long(x.size))
+    return y
+
+
+def set_exp_mode(mode):
+    """Which restated expf the float build's blend loops call: 0 = expf_p32 (default; the HIP kernels' alpha_mode 0),
+    1 = expf_restated = glibc's algorithm (alpha_mode 2).  Returns the previous mode."""
+    global _EXP_MODE
+    old, _EXP_MODE = _EXP_MODE, (1 if mode else 0)
+    for l in _LIBS.values():  # every build loaded so far (the C-math build ignores it); later loads pick it up in lib()
+        l.dgro_set_exp_mode(C.c_int(_EXP_MODE))
+    return old
+
+
+def expf_p32_scan(lo_bits=0x80000000, hi_bits=0xC2D00000):
+    """expf_p32 against exp() in double on every float with bits in [lo_bits, hi_bits]: dict(max_ulp_normal, max_ulp_denormal,
+    not_correctly_rounded, scanned, at_normal, at_denormal)."""
+    out = (C.c_double * 6)()
+    lib(False).dgro_expf_p32_scan(C.c_uint32(lo_bits), C.c_uint32(hi_bits), out)
+    return dict(max_ulp_normal=out[0], max_ulp_denormal=out[1], not_correctly_rounded=int(out[2]), scanned=int(out[3]),
+                at_normal=int(out[4]), at_denormal=int(out[5]))
+
+
 def exp_as_the_oracle_calls_it(x):
-    """exp of a float32 array through the very function the blend loops of dgr_oracle.cpp call (expf_restated in the default
-    build, the C double exp in the cmath build)."""
+    """exp of a float32 array through the very function the blend loops of dgr_oracle.cpp call (expf_p32 -- or expf_restated
+    after set_exp_mode(1) -- in the default build, the C double exp in the cmath build)."""
     x = np.ascontiguousarray(x, np.float32)
     y = np.empty_like(x)
     lib().dgro_exp(C.c_void_p(x.ctypes.data), C.c_void_p(y.ctypes.data), C.c_long(x.size))
