@@ -71,8 +71,12 @@ __device__ __forceinline__ float t_div(float T, float om, float& inv) {
 
 // NB = instances staged per batch (<= 256, one per thread).  The forward uses 256; the light backward 128, which
 // halves its LDS footprint (it is occupancy-bound: see DESIGN.md s4.2).
-template <int NB>
+// LIST_T = type of a list entry: unsigned short (the forward: its LDS footprint decides 8 workgroups per CU) or uint32_t (the
+// backward kernels: two entries arrive as one 8-byte read, ready to be used as addresses -- parting two 16-bit halves costs a
+// v_lshrrev_b32 at 4.2 cycles and a mask at 2.4 per two entries, in loops bound by vector issue).
+template <int NB, typename LIST_T = unsigned short>
 struct StagedT {
+    typedef LIST_T list_t;
     static constexpr int SLOTS = NB;
     static constexpr int SENTINEL = NB;       // record slot that can never contribute (opacity 0)
     static constexpr int LIST_LD = NB + 8;    // list row: NB entries + sentinel padding, 8-byte aligned rows
@@ -80,7 +84,7 @@ struct StagedT {
                                //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power (pair_p2)
     float4 rgbd[NB + 1];       // {r, g, b, depth}; [NB] = zeros (the sentinel's entry: the branch-free backward reads it)
     uint32_t id[NB];
-    unsigned short list[4][LIST_LD];  // per consumer wave: byte offsets (slot * 32) into rec, tile-list order
+    LIST_T list[4][LIST_LD];          // per consumer wave: byte offsets (slot * 32) into rec, tile-list order
     int cnt4[4][4];                   // [staging wave][consumer wave] entries contributed
 };
 using Staged = StagedT<DGR_TILE_PIX>;
@@ -91,8 +95,8 @@ using Staged = StagedT<DGR_TILE_PIX>;
 // fast rcp / sqrt used here), so every dropped (pixel, Gaussian) pair is one the per-pixel test rejects.
 // (An exact ellipse-vs-quadrant test was measured: it removes almost no list entries beyond the box -- the
 // iterations without a valid lane are finished pixels and sub-pixel splats -- and costs more VALU than it saves.)
-template <int AM, int NB>
-__device__ __forceinline__ unsigned stage_one(StagedT<NB>& s, int slot, uint32_t gid, const float4* __restrict__ rec,
+template <int AM, int NB, typename LT>
+__device__ __forceinline__ unsigned stage_one(StagedT<NB, LT>& s, int slot, uint32_t gid, const float4* __restrict__ rec,
                                               float tile_x0, float tile_y0) {
     const float4 q0 = rec[3 * (size_t)gid + 0];
     const float4 q1 = rec[3 * (size_t)gid + 1];
@@ -128,8 +132,8 @@ constexpr int TAG_SHIFT = DGR_TAG_SHIFT;
 constexpr uint32_t ID_MASK = DGR_ID_MASK;
 
 // backward staging: returns the entry's tag; untagged entries are not loaded
-template <int AM, int NB>
-__device__ __forceinline__ unsigned stage_tagged(StagedT<NB>& s, int slot, uint32_t entry, const float4* __restrict__ rec) {
+template <int AM, int NB, typename LT>
+__device__ __forceinline__ unsigned stage_tagged(StagedT<NB, LT>& s, int slot, uint32_t entry, const float4* __restrict__ rec) {
     constexpr float PSCALE = AlphaPath<AM>::PSCALE;
     const unsigned code = entry >> TAG_SHIFT;
     if (code == 0u) return 0u;
@@ -138,8 +142,9 @@ __device__ __forceinline__ unsigned stage_tagged(StagedT<NB>& s, int slot, uint3
     const float4 q1 = rec[3 * (size_t)gid + 1];
     const float4 q2 = rec[3 * (size_t)gid + 2];
     s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
-    // (.w: byte offset of the slot's rgbd entry -- the light backward addresses LDS with it directly)
-    s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, q0.w, __int_as_float(slot), __int_as_float(slot * 16));
+    // (.z: 4 * slot = the byte offset of the slot's accumulator column; .w: byte offset of its rgbd entry -- the backward
+    //  kernels address LDS with both directly, and compare .z with 4 * (slots at or before the pixel's last contributor))
+    s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, q0.w, __int_as_float(slot * 4), __int_as_float(slot * 16));
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
     return code;
@@ -151,8 +156,8 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
 
 // Builds the four per-consumer lists from the staging threads' quadrant codes.  Contains two barriers;
 // returns the (uniform) length of the calling wave's list, padded to a multiple of 4 with sentinels.
-template <int NB>
-__device__ __forceinline__ int build_lists(StagedT<NB>& s, unsigned code, int tid, int wave, int lane) {
+template <int NB, typename LT>
+__device__ __forceinline__ int build_lists(StagedT<NB, LT>& s, unsigned code, int tid, int wave, int lane) {
     unsigned long long bal[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -165,12 +170,12 @@ __device__ __forceinline__ int build_lists(StagedT<NB>& s, unsigned code, int ti
         if ((code >> w) & 1u) {
             int base = 0;
             for (int sw = 0; sw < wave; sw++) base += s.cnt4[sw][w];
-            s.list[w][base + lanes_below(bal[w])] = (unsigned short)(tid * 32);
+            s.list[w][base + lanes_below(bal[w])] = (LT)(tid * 32);
         }
     }
     const int n = __builtin_amdgcn_readfirstlane(s.cnt4[0][wave] + s.cnt4[1][wave] + s.cnt4[2][wave] + s.cnt4[3][wave]);
     __syncthreads();
-    if (lane < 4) s.list[wave][n + lane] = (unsigned short)(StagedT<NB>::SENTINEL * 32);  // own list, own wave: program order suffices
+    if (lane < 4) s.list[wave][n + lane] = (LT)(StagedT<NB, LT>::SENTINEL * 32);  // own list, own wave: program order suffices
     return n;
 }
 
@@ -198,11 +203,19 @@ __device__ __forceinline__ float pair_p2(const float4& q0, const float4& q1, f2 
     }
 }
 
-// two consecutive list entries: one 4-byte LDS read yields two record offsets
-template <int NB>
-__device__ __forceinline__ void load2(const StagedT<NB>& s, int wave, int k, float4 (&q0)[2], float4 (&q1)[2]) {
-    const unsigned pk = *reinterpret_cast<const unsigned*>(&s.list[wave][k]);
-    const unsigned off[2] = {pk & 0xffffu, pk >> 16};
+// two consecutive list entries: one LDS read (4 bytes, parted by a mask and a shift; 8 bytes with 32-bit entries)
+template <int NB, typename LT>
+__device__ __forceinline__ void load2(const StagedT<NB, LT>& s, int wave, int k, float4 (&q0)[2], float4 (&q1)[2]) {
+    unsigned off[2];
+    if (sizeof(LT) == 4) {
+        const uint2 pk = *reinterpret_cast<const uint2*>(&s.list[wave][k]);
+        off[0] = pk.x;
+        off[1] = pk.y;
+    } else {
+        const unsigned pk = *reinterpret_cast<const unsigned*>(&s.list[wave][k]);
+        off[0] = pk & 0xffffu;
+        off[1] = pk >> 16;
+    }
     const char* base = reinterpret_cast<const char*>(s.rec);
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -214,10 +227,10 @@ __device__ __forceinline__ void load2(const StagedT<NB>& s, int wave, int k, flo
 
 // sentinel record: p2 = 0 but lthr = +big, so it never passes `p2 >= lthr`; opacity 0, so its alpha is 0.
 // TAGGED (backward staging, stage_tagged): .w carries the byte offset of the sentinel's all-zero rgbd entry instead.
-template <bool TAGGED = false, int NB>
-__device__ __forceinline__ void write_sentinel(StagedT<NB>& s) {
+template <bool TAGGED = false, int NB, typename LT>
+__device__ __forceinline__ void write_sentinel(StagedT<NB, LT>& s) {
     s.rec[2 * NB] = make_float4(0.f, 0.f, 0.f, 0.f);
-    s.rec[2 * NB + 1] = make_float4(0.f, 0.f, __int_as_float(NB), TAGGED ? __int_as_float(NB * 16) : 3.0e38f);
+    s.rec[2 * NB + 1] = make_float4(0.f, 0.f, __int_as_float(TAGGED ? NB * 4 : NB), TAGGED ? __int_as_float(NB * 16) : 3.0e38f);
     s.rgbd[NB] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 

@@ -134,7 +134,7 @@ constexpr int NACC_FULL = 15;
 constexpr int BWD_NB = 128;          // list positions staged per batch (occupancy: see render_light.hip)
 constexpr int BWD_LD = BWD_NB + 1;
 struct StagedBwdFull {
-    StagedT<BWD_NB> f;
+    StagedT<BWD_NB, uint32_t> f;
     float acc[NACC_FULL * BWD_LD];
     int max_last;
     uint64_t exptab[32];  // ALPHA_GLIBC: exact_math.h
@@ -143,7 +143,7 @@ struct StagedBwdFull {
 template <int AM>
 __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullArgs a) {
     __shared__ StagedBwdFull sb;
-    StagedT<BWD_NB>& s = sb.f;
+    StagedT<BWD_NB, uint32_t>& s = sb.f;
     const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -195,6 +195,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     const int c16 = wave_reduce16d_comp(lane);
     const int my_comp = ((lane & 3) == 0 && c16 < NACC_FULL) ? c16 : -1;
+    float* const my_acc = sb.acc + (my_comp >= 0 ? my_comp : 0) * BWD_LD;  // this lane's accumulator row (column = slot)
 
     for (int hi = total; hi > 0; hi -= BWD_NB) {
         const int lo = max(0, hi - BWD_NB);
@@ -206,8 +207,9 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
         for (int k = 0; k < NACC_FULL; k++)
             if (tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
         const int n = build_lists(s, code, tid, wave, lane);
-        const int rel_last = last_contributor - lo;
-        const int rel_first = first_contributor - 1 - lo;  // slot of the front-most valid contributor, if in this batch
+        // (the staged record carries 4 * slot: render_common.h, stage_tagged)
+        const int rel_last4 = 4 * (last_contributor - lo);
+        const int rel_first4 = 4 * (first_contributor - 1 - lo);  // 4 * slot of the front-most valid contributor, if in this batch
 
         for (int k = ((n + 1) & ~1) - 2; k >= 0; k -= 2) {
             float4 q0[2], q1[2];
@@ -216,18 +218,18 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
             for (int u = 1; u >= 0; u--) {
                 f2 dxy;
                 const float p2 = pair_p2<AM>(q0[u], q1[u], pxy, dxy);
-                const int j = __float_as_int(q1[u].z);
+                const int j4 = __float_as_int(q1[u].z);
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
                 const float oG = alpha_raw<AM, true>(q1[u].y, p2, sb.exptab);  // o G: alpha before the 0.99 clamp
-                const float alpha = fminf(0.99f, oG);
-                const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha >= ALPHA_MIN);
+                // (0.99 is above the threshold, so o G itself decides; "not below" keeps a NaN o G valid as min(0.99f, NaN) does)
+                const bool valid = (j4 < rel_last4) & (p2 <= 0.0f) & !(oG < ALPHA_MIN);
                 // No branch (see render_light.hip): a lane the Gaussian does not reach runs the same instructions with
                 // alpha = 0 and o G = 0 -- 1 / (1 - 0) is exactly 1 and S = 0 X + 1 S keeps its bits, so its state is
                 // untouched and all of its contributions are 0; valid lanes execute the reference's operations unchanged.
                 // Per-lane scalars: w = alpha T, qq = o G dL/dalpha, qc = o G * (colour-only part of dL/dalpha), and the
                 // front-most-pair depth terms fw, fq.
-                const float am = valid ? alpha : 0.f;
                 const float oGm = valid ? oG : 0.f;
+                const float am = fminf(0.99f, oGm);  // (one select: render_light.hip)
                 const float4 cd = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rgbd) + __float_as_int(q1[u].w));
                 const float om = 1.f - am;
                 float inv;
@@ -247,7 +249,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
                 const float qq = oGm * dL_dalpha;
                 const float qc = oGm * (T * dcol);  // sum_ch dL_dpixel[ch] * dpixel_dalpha[ch] = T * dcol (backward.cu:693)
                 // the pair ComputePG matches last: its dd_dvK survive (backward.cu:1278-1289)
-                const bool front = valid & (j == rel_first);
+                const bool front = valid & (j4 == rel_first4);
                 const float fw = front ? dL_depth * w : 0.f;
                 const float fq = front ? oG * (dL_depth * (T * ddep)) : 0.f;  // dL_depth * ddepth_dalpha * o * G
                 const float dx = dxy.x, dy = dxy.y;
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
                 g[14] = fq * dy;
                 g[15] = 0.f;
                 const float tot = wave_reduce16d(g);  // (within-row stages first: wave_reduce.h)
-                if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * BWD_LD + j], tot);
+                if (my_comp >= 0) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(my_acc) + j4), tot);
             }
         }
         __syncthreads();

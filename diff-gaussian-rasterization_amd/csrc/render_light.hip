@@ -177,7 +177,7 @@ constexpr int NACC_LIGHT = 14;
 constexpr int BWD_NB = 128;                // list positions staged per batch (256: 5 workgroups per CU, 267 us; 128: 247 us)
 constexpr int BWD_LD = BWD_NB + 1;         // accumulator row length
 struct StagedBwd {
-    StagedT<BWD_NB> f;
+    StagedT<BWD_NB, uint32_t> f;
     float acc[NACC_LIGHT * BWD_LD];
     int max_last;
     uint64_t exptab[32];  // ALPHA_GLIBC: exact_math.h
@@ -187,7 +187,7 @@ struct StagedBwd {
 template <int AM, bool DO_MAP, bool DO_POSE>
 __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
     __shared__ StagedBwd sb;
-    StagedT<BWD_NB>& s = sb.f;
+    StagedT<BWD_NB, uint32_t>& s = sb.f;
     const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -255,6 +255,8 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
     }
 
+    float* const my_acc = sb.acc + (my_comp >= 0 ? my_comp : 0) * BWD_LD;  // this lane's accumulator row (column = slot)
+
     // back-to-front: batches cover list positions [lo, hi) with hi walking down from `total`
     for (int hi = total; hi > 0; hi -= BWD_NB) {
         const int lo = max(0, hi - BWD_NB);
@@ -266,7 +268,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         for (int k = 0; k < NACC_LIGHT; k++)
             if (BWD_NB == DGR_TILE_PIX || tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
         const int n = build_lists(s, code, tid, wave, lane);
-        const int rel_last = last_contributor - lo;  // slots below this are at or before the last contributor
+        const int rel_last4 = 4 * (last_contributor - lo);  // slots whose 4 * index is below this are at or before the last contributor
 
         // (the list is padded with sentinels to a multiple of 4, so a multiple of 2 is always readable)
         for (int k = ((n + 1) & ~1) - 2; k >= 0; k -= 2) {
@@ -277,17 +279,20 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                 f2 dxy;
                 const float p2 = pair_p2<AM>(q0[u], q1[u], pxy, dxy);
                 const float dx = dxy.x, dy = dxy.y;
-                const int j = __float_as_int(q1[u].z);
+                const int j4 = __float_as_int(q1[u].z);  // 4 * slot
                 // every listed entry was blended by some pixel of this wave (contribution tags): no wave-level tests
                 const float oG = alpha_raw<AM, true>(q1[u].y, p2, sb.exptab);  // o G: alpha before the 0.99 clamp, and dalpha/dG * G
-                const float alpha0 = fminf(0.99f, oG);
-                const bool valid = (j < rel_last) & (p2 <= 0.0f) & (alpha0 >= ALPHA_MIN);
+                // (the reference tests min(0.99, o G) >= 15/255; 0.99 is above the threshold, so o G itself decides)
+                // (written as "not below", so that a NaN o G -- a poisoned opacity -- stays a valid pair with alpha 0.99 as under
+                //  the reference's min(0.99f, NaN))
+                const bool valid = (j4 < rel_last4) & (p2 <= 0.0f) & !(oG < ALPHA_MIN);
                 // No branch: a lane the Gaussian does not reach runs the same instructions with alpha = 0 and o G = 0, which
                 // leave its state untouched -- 1/(1 - 0) is exactly 1, so T, and S = 0 X + 1 S, keep their bits -- and
                 // make every one of its contributions 0.  (The list's sentinel entries have opacity 0 and an all-zero
-                // rgbd entry.)  Valid lanes execute the operations of the reference's order unchanged.
-                const float alpha = valid ? alpha0 : 0.f;
+                // rgbd entry.)  Valid lanes execute the operations of the reference's order unchanged.  One select (on o G;
+                // the clamp of 0 is 0): a select and a compare issue at 4.2 cycles each, a multiply at 2.4.
                 const float oGm = valid ? oG : 0.f;
+                const float alpha = fminf(0.99f, oGm);
                 const float4 cd = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rgbd) + __float_as_int(q1[u].w));
                 const float om = 1.f - alpha;
                 float inv;
@@ -330,8 +335,8 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     float g4[4] = {qdx, qdy, wd, 0.f};
                     tot = wave_reduce4(g4);
                 }
-                // j is wave-uniform here (every lane read the same record)
-                if (my_comp >= 0) atomicAdd(&sb.acc[my_comp * BWD_LD + j], tot);
+                // j4 is wave-uniform here (every lane read the same record)
+                if (my_comp >= 0) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(my_acc) + j4), tot);
             }
         }
 

@@ -160,7 +160,10 @@ def test_overflow_writes_stay_inside_the_state_buffers(variant, P, W, H, seed, s
     gb, geom = guarded(lib.dgr_geometry_bytes(P)); bb, binning = guarded(lib.dgr_binning_bytes(cap, W, H))
     ib, img = guarded(lib.dgr_image_bytes(W, H))
     f = lambda *sh: torch.empty(sh, device=dev)  # noqa: E731
-    color, depth, median, var, alpha, unc = f(3, H, W), f(1, H, W), f(1, H, W), f(1, H, W), f(1, H, W), f(P, 1)
+    color, depth, median, var, alpha = f(3, H, W), f(1, H, W), f(1, H, W), f(1, H, W), f(1, H, W)
+    # (light: gau_uncertainty, one float per Gaussian; full: the uncertainty IMAGE, one per pixel -- a [P, 1] buffer here let
+    #  the full blend write H W floats into P of them whenever P < H W, over whatever the allocator had put behind it)
+    unc = f(P, 1) if variant == "light" else f(1, H, W)
     radii = torch.empty(P, dtype=torch.int32, device=dev); px = torch.empty((P, 1), dtype=torch.int32, device=dev)
     status = torch.zeros(4, dtype=torch.int32, device=dev)
     k = dict(bg=hh.T(s.bg), means=hh.T(s.means), opac=hh.T(s.opac), scales=hh.T(s.scales), rots=hh.T(s.rots), view=hh.T(s.view),
