@@ -135,10 +135,12 @@ def main():
                          "hold every wave slot of a CU otherwise, and kernels of other streams -- RCCL's with --gpus N, other views' "
                          "front ends -- only get in as blend workgroups drain (one GPU, three views in flight: 0.448 ms per view "
                          "without, 0.445 at 7, 0.454 at 6; profiles/r5/blend_cap_summary.txt)")
-    ap.add_argument("--scene", default="synth-v1", choices=["synth-v1", "clustered"],
+    ap.add_argument("--scene", default="synth-v1", choices=["synth-v1", "clustered", "heavy_tail"],
                     help="not the headline workload: clustered = dgr_amd.synth.cluster_scene of the same Gaussians (60 %% of them "
                          "pulled into one region of the frame: tile lists of 51 .. 1135 entries instead of 203 +- 20 %%), the "
-                         "case the blend kernels' heaviest-first tile schedule is for")
+                         "case the blend kernels' heaviest-first tile schedule is for; heavy_tail = dgr_amd.synth.heavy_tail_scene (1 %% "
+                         "of the Gaussians with an on-screen sigma of 20 .. 150 px: a few splats touching hundreds to thousands of "
+                         "tiles each among many touching three), the case the front end's per-Gaussian rectangle walks are for")
     ap.add_argument("--sync-mode", default="lazy", choices=["lazy", "strict"],
                     help="lazy: forward's status word is checked one step late (no host sync in the step); "
                          "strict: one blocking status read per forward, like the reference")
@@ -200,6 +202,9 @@ def main():
     if args.scene == "clustered":
         from dgr_amd.synth import cluster_scene
         s = cluster_scene(s)
+    elif args.scene == "heavy_tail":
+        from dgr_amd.synth import heavy_tail_scene
+        s = heavy_tail_scene(s)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     mapping = not args.tracking
     means3D = t(s.means).requires_grad_(mapping)
@@ -223,8 +228,8 @@ def main():
     params = [means3D, means2D, shs, opac, scales, rots]
     Vb = max(0, args.batch)
     if Vb:
-        if args.variant != "light" or args.tracking or args.graph:
-            raise SystemExit("--batch: light variant, mapping step, eager")
+        if args.variant != "light" or args.tracking:
+            raise SystemExit("--batch: light variant, mapping step")
         from dgr_amd import batch as Bm
         from dgr_amd.synth import camera
         # rank r renders views r*Vb .. r*Vb + Vb - 1 of the same Gaussians (view k: the camera at angle 0.05 (k + 1))
@@ -254,6 +259,9 @@ def main():
         torch.autograd.backward([color, depth, median, var], [gCb, gDb, gMb, gVb])
         if arena is not None:  # one fused RCCL all-reduce of the batch's summed per-Gaussian gradients
             arena.all_reduce(dist)
+        if args.graph:  # (a replayed graph rewrites these very tensors: what the error figure reads after a replay)
+            return radii[0], {"dL_dmeans3D": means3D.grad, "dL_dsh": shs.grad, "dL_dopacity": opac.grad, "dL_dscales": scales.grad,
+                              "dL_drotations": rots.grad, "dL_dview": views_b.grad}
         return radii[0]
 
     def step():
@@ -300,7 +308,8 @@ def main():
         # where it waits once per forward (strict: 0.478 with three views against 0.563 with seven), where the views are replayed
         # from graphs (config 2: 0.106 against 0.118), for the tracking step (0.355 against 0.378) and with a collective per view
         args.views_in_flight = 21 if (dist is None and args.sync_mode == "lazy" and not args.graph and not args.tracking) else 3
-    K = 1 if (Vb or args.group > 1) else max(1, args.views_in_flight)  # (a batch spreads its views over streams itself)
+    # (a batch spreads its views over streams itself: one batch at a time unless --views-in-flight asks for more)
+    K = (max(1, args.views_in_flight_requested) if Vb else 1) if (Vb or args.group > 1) else max(1, args.views_in_flight)
     views = ViewStreams(K, dev) if K > 1 else None  # dgr_amd.multiview: independent views on K HIP streams
 
     captured = []
@@ -309,23 +318,26 @@ def main():
         r = None
         if captured:
             for i in range(n):
-                captured[i % len(captured)].replay()
-            return radii
+                r = captured[i % len(captured)].replay()
+            return r[0] if isinstance(r, tuple) else radii
         for i in range(n):
             if views is None:
                 r = step()
             else:
                 with views.next():
                     r = step()
-        return r
+        return first(r)
+
+    def first(r):  # (a captured batch step returns (radii, gradients))
+        return r[0] if isinstance(r, tuple) else r
 
     for _ in range(args.warmup):
-        radii = step()
+        radii = first(step())
     # calibration pass (untimed): every stage bracketed, to find the dominant kernel
     _capi.set_option("profile_every", 1)
     _capi.profile_select("all")
     for _ in range(8):
-        radii = step()
+        radii = first(step())
     drain()
     torch.cuda.synchronize(dev)
     stage_ms, stage_n = {}, {}
@@ -356,7 +368,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         for _ in range(20):
-            radii = step()
+            radii = first(step())
         drain()
         barrier()
         serial_ms = (time.perf_counter() - t0) / 20 * 1e3
@@ -479,7 +491,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload} ({WORKLOAD_NAMES[args.workload]}): synth-v1 seed 0{' CLUSTERED (not a BASELINE scene: dgr_amd.synth.cluster_scene)' if args.scene == 'clustered' else ''}, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
+            "config": {"workload": f"{args.workload} ({WORKLOAD_NAMES[args.workload]}): synth-v1 seed 0{' CLUSTERED (not a BASELINE scene: dgr_amd.synth.cluster_scene)' if args.scene == 'clustered' else ' HEAVY-TAILED (not a BASELINE scene: dgr_amd.synth.heavy_tail_scene)' if args.scene == 'heavy_tail' else ''}, P={P}, {W}x{H}, SH degree {deg}, {args.variant} variant, "
                                    f"fwd+bwd incl. viewmatrix gradient, "
                                    + (f"one view per step, {K} independent views in flight per GPU" if not Vb else
                                       f"NOT the headline step: {Vb} camera views of the same Gaussians per step through the batched entry "
@@ -531,13 +543,25 @@ def main():
                 line["config"]["ms_per_step_hipgraph_replay"] = graph_replay_line(args)
             # (a bounded sample: 5 views at configs 1-3, 2 at the 2 M / 5 M Gaussian views, whose oracle pass takes 3-8 s)
             runs = args.cpu_runs if P <= 500_000 else min(args.cpu_runs, 2)
-            line["cpu_baseline"], ref_grads = cpu_baseline(s, deg, runs, args.variant)
+            if Vb:
+                # a batch: the oracle renders each of its views once (that is also the timed sample) and the Gaussians'
+                # gradients are summed over them in double, as the batched backward sums them in registers
+                line["cpu_baseline"], ref_grads = cpu_baseline_batch(s, cams, deg)
+            else:
+                line["cpu_baseline"], ref_grads = cpu_baseline(s, deg, runs, args.variant)
             # second half of BASELINE's metric: gradient max-abs-err against the CPU restatement of the reference, same
             # inputs and loss scaling (pixel-gradient images N(0,1)/(H W)); one extra untimed view on the default stream
-            step()
+            if captured:  # (after an eager step .grad no longer aliases the captured buffers: read what the graph returned)
+                step_result = captured[-1].replay()
+            else:
+                step_result = step()
             torch.cuda.synchronize(dev)
             pairs = {"dL_dmeans3D": means3D, "dL_dsh": shs, "dL_dopacity": opac, "dL_dscales": scales,
-                     "dL_drotations": rots, "dL_dview": view}
+                     "dL_drotations": rots, "dL_dview": views_b if Vb else view}
+            if captured and isinstance(step_result, tuple) and len(step_result) == 2 and isinstance(step_result[1], dict):
+                class _G:  # the gradient tensors recorded in the graph
+                    def __init__(self, g): self.grad = g
+                pairs = {k: _G(step_result[1][k]) for k in pairs if k in step_result[1]}
             pairs = {k: v for k, v in pairs.items() if v.grad is not None}  # (--tracking: the pose gradient only)
             errs = {k: float(np.abs(v.grad.detach().cpu().numpy().reshape(-1).astype(np.float64)
                                     - np.asarray(ref_grads[k], np.float64).reshape(-1)).max()) for k, v in pairs.items()}
@@ -706,6 +730,48 @@ def cpu_baseline(s, deg, runs, variant="light"):
             "sample": f"{len(tot)} complete fwd+bwd views ({variant} variant) of the same workload after 1 warm-up: median {med:.3f} s (min "
                       f"{min(tot):.3f} s; forward median {float(np.median(tf)):.3f} s, backward {float(np.median(tb)):.3f} s), "
                       f"oracle built -O3 -march=native, {cores} OpenMP threads = physical cores of {sockets} x {model}"}, grads
+
+
+def cpu_baseline_batch(s, cams, deg):
+    """The oracle on every view of a batch (cams: dgr_amd.synth.camera tuples): each view's forward + backward timed once after
+    one warm-up view; returns the baseline object and the reference gradients of the BATCH -- the Gaussians' gradients summed
+    over the views in double, the pose gradients stacked per view."""
+    from oracle import oracle as O
+    from dgr_amd import _capi as _c
+    model, sockets, cores, threads = host_cpu()
+    O.build()
+    O.use_native(True)
+    O.set_threads(cores)
+    O.set_exp_mode(1 if _c.get_option("alpha_mode") == 2 else 0)
+    tot, sums, dviews = [], {}, []
+
+    def one(cam, record):
+        sv = s._replace(view=cam[4], proj=cam[5], persp=cam[6], campos=cam[7])
+        t0 = time.perf_counter()
+        st, out = O.light_forward(sv.bg, sv.means, None, sv.opac, sv.scales, sv.rots, 1.0, None, sv.view, sv.gt, sv.proj,
+                                  sv.tanfovx, sv.tanfovy, sv.H, sv.W, sv.shs, deg, sv.campos)
+        g = O.light_backward(st, sv.bg, sv.means, None, sv.scales, sv.rots, 1.0, None, sv.view, sv.proj, sv.tanfovx, sv.tanfovy,
+                             sv.gC, sv.gD, sv.gM, sv.gV, sv.gt, sv.shs, deg, sv.campos, out["opacity_map"], sv.persp)
+        dt = time.perf_counter() - t0
+        if record:
+            tot.append(dt)
+            for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales", "dL_drotations"):
+                sums[k] = np.asarray(g[k], np.float64) + sums.get(k, 0.0)
+            dviews.append(np.asarray(g["dL_dview"], np.float64).reshape(4, 4))
+
+    try:
+        one(cams[0], False)
+        for cam in cams:
+            one(cam, True)
+    finally:
+        O.use_native(False)
+    sums["dL_dview"] = np.stack(dviews)
+    med = float(np.median(tot))
+    return {"value": 1.0 / med / 1e6, "unit": "Mviews/s", "cores": cores, "kind": "port",
+            "host": {"cpu": model, "sockets": sockets, "physical_cores": cores, "hardware_threads": threads, "omp_threads": cores},
+            "sample": f"the {len(tot)} views of one batch, each a complete fwd+bwd (light variant) after 1 warm-up view: median {med:.3f} s per "
+                      f"view (min {min(tot):.3f} s), oracle built -O3 -march=native, {cores} OpenMP threads = physical cores of "
+                      f"{sockets} x {model}"}, sums
 
 
 if __name__ == "__main__":

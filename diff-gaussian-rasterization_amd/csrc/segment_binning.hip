@@ -48,6 +48,8 @@ constexpr int SEG_MAX = SEG_TILES_MAX;      // tiles per segment: 16, 8 or 4 (ch
 constexpr int K2_PPT = 12;                   // pairs a bin_tiles thread holds in registers: 6144 per segment (= K2_CAP; 16 spill)
 constexpr int K2_CAP = 6144;        // keys of one segment held in LDS (48 KB: three workgroups per CU)
 constexpr int REG_SORT_MAX = 1024;  // a wave sorts a tile list in registers up to here (16 chunks of 64)
+constexpr int BIG_PAIRS = 24;       // bin_segments: rectangles of more (row, segment) pairs are walked by a whole wave
+constexpr int BIGQ = 512;           // ... from a queue of this many entries per 4096 Gaussians (8 KB of LDS)
 
 // exclusive (inclusive) scan of a[0..n) in place by the whole workgroup; returns the total.  NT threads, all call it.
 template <int NT>
@@ -95,6 +97,8 @@ __global__ void __launch_bounds__(K1_THREADS) bin_segments_kernel(int P, int per
     extern __shared__ unsigned long long lds64[];
     __shared__ uint32_t wsum[K1_THREADS / 64];
     __shared__ uint32_t s_base;
+    __shared__ uint32_t s_qn;        // the queue of big rectangles (below)
+    __shared__ uint4 s_q[BIGQ];      // {x0 | y0 << 16, x1 | y1 << 16, depth bits, Gaussian id}
     const int SEG = 1 << seg_shift;
     const int sgx = (grid_x + SEG - 1) >> seg_shift;
     const int nseg = grid_y * sgx;
@@ -130,6 +134,32 @@ __global__ void __launch_bounds__(K1_THREADS) bin_segments_kernel(int P, int per
         for (int b = tid; b < (g0 >> 8); b += K1_THREADS) part += geom.block_tiles[b] & 0x7fffffffu;
     }
     __syncthreads();
+    // A Gaussian whose rectangle covers many (row, segment) pairs -- the heavy tail of a real map: a splat of 150 px sigma touches
+    // 56 rows x 4-8 segments, a full-frame one 68 x 8 at 1080p -- is not walked by the lane that holds it (one lane looping
+    // over 500 pairs, an LDS atomic each, beside 63 idle lanes: 149 us for this kernel on dgr_amd.synth.heavy_tail_scene at
+    // config 3's size against 16 us on synth-v1) but queued, and the queue is walked by the whole workgroup, a wave per entry,
+    // a lane per pair -- the wave-per-rectangle form of the reference's one-thread loop (L/cuda_rasterizer/rasterizer_impl.cu:
+    // 94-107).  The queue is rebuilt in each pass (which lane's entry overflows a full queue may differ between the passes: each
+    // pass only needs every pair handled once); an entry that finds the queue full is walked by its own lane as before.
+    auto pairs_of = [&](ushort4 r) -> int {
+        if (r.z <= r.x || r.w <= r.y) return 0;
+        return ((int)r.w - (int)r.y) * ((((int)r.z - 1) >> seg_shift) - ((int)r.x >> seg_shift) + 1);
+    };
+    auto enqueue = [&](ushort4 r, float depth, int idx) -> bool {
+        const uint32_t q = atomicAdd(&s_qn, 1u);
+        if (q >= (uint32_t)BIGQ) return false;
+        s_q[q] = make_uint4((uint32_t)r.x | ((uint32_t)r.y << 16), (uint32_t)r.z | ((uint32_t)r.w << 16), __float_as_uint(depth), (uint32_t)idx);
+        return true;
+    };
+    // every lane of the calling wave: (row, segment) pair number p of entry e -> its segment index and column span
+    auto queued_pair = [&](const uint4& e, int p, float inv_nsx, int nsx, int sx0, int& seg, int& xa, int& xb) {
+        const int rx = (int)(e.x & 0xffffu), ry = (int)(e.x >> 16), rz = (int)(e.y & 0xffffu);
+        int row = (int)(((float)p + 0.5f) * inv_nsx);  // p / nsx for p < 2^22 (p + 1/2 is at least 1/(2 nsx) away from a multiple of nsx)
+        const int sx = sx0 + p - row * nsx;
+        seg = (ry + row) * sgx + sx;
+        xa = max(rx, sx * SEG);
+        xb = min(rz, sx * SEG + SEG);
+    };
     // ---- pass A: pairs and instances per segment
     auto count = [&](ushort4 r) {
         if (r.z <= r.x || r.w <= r.y) return;
@@ -141,8 +171,25 @@ __global__ void __launch_bounds__(K1_THREADS) bin_segments_kernel(int P, int per
     };
     for (int first = g0; first < g1; first += NH * K1_THREADS) {
         if (!hold) load_group(first, false);
+        if (tid == 0) s_qn = 0u;
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NH; k++) count(hr[k]);
+        for (int k = 0; k < NH; k++)
+            if (pairs_of(hr[k]) <= BIG_PAIRS || !enqueue(hr[k], 0.f, 0)) count(hr[k]);
+        __syncthreads();
+        const int nq = min((int)s_qn, BIGQ);
+        for (int q = tid >> 6; q < nq; q += K1_THREADS / 64) {
+            const uint4 e = s_q[q];
+            const int sx0 = (int)(e.x & 0xffffu) >> seg_shift, nsx = ((((int)(e.y & 0xffffu)) - 1) >> seg_shift) - sx0 + 1;
+            const int np = ((int)(e.y >> 16) - (int)(e.x >> 16)) * nsx;
+            const float inv_nsx = 1.0f / (float)nsx;
+            for (int p = lane; p < np; p += 64) {
+                int seg, xa, xb;
+                queued_pair(e, p, inv_nsx, nsx, sx0, seg, xa, xb);
+                atomicAdd(&both[seg], 1ull | ((unsigned long long)(xb - xa) << 32));
+            }
+        }
+        __syncthreads();  // (the queue is rewritten by the next group)
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
@@ -182,8 +229,33 @@ __global__ void __launch_bounds__(K1_THREADS) bin_segments_kernel(int P, int per
     };
     for (int first = g0; first < g1; first += NH * K1_THREADS) {
         if (!hold) load_group(first, true);
+        if (tid == 0) s_qn = 0u;
+        __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NH; k++) place(hr[k], hd[k], first + tid + k * K1_THREADS);
+        for (int k = 0; k < NH; k++) {
+            const int idx = first + tid + k * K1_THREADS;
+            if (pairs_of(hr[k]) <= BIG_PAIRS || !enqueue(hr[k], hd[k], idx)) place(hr[k], hd[k], idx);
+        }
+        __syncthreads();
+        const int nq = min((int)s_qn, BIGQ);
+        for (int q = tid >> 6; q < nq; q += K1_THREADS / 64) {
+            const uint4 e = s_q[q];
+            const int sx0 = (int)(e.x & 0xffffu) >> seg_shift, nsx = ((((int)(e.y & 0xffffu)) - 1) >> seg_shift) - sx0 + 1;
+            const int np = ((int)(e.y >> 16) - (int)(e.x >> 16)) * nsx;
+            const float inv_nsx = 1.0f / (float)nsx;
+            const uint64_t key = ((uint64_t)e.z << 32) | e.w;
+            for (int p = lane; p < np; p += 64) {
+                int seg, xa, xb;
+                queued_pair(e, p, inv_nsx, nsx, sx0, seg, xa, xb);
+                const uint32_t slot = base + atomicAdd(&cnt[seg], 1u);
+                const int x0 = xa & (SEG - 1), x1 = xb - (xa - x0);  // columns inside the segment: 0 <= x0 < x1 <= 16
+                if (slot < (uint32_t)capacity) {
+                    pair_keys[slot] = key;
+                    pair_cov[slot] = (uint8_t)(x0 | ((x1 - 1) << 4));
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 

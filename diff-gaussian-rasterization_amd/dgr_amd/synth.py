@@ -99,5 +99,24 @@ def cluster_scene(s: Scene, frac=0.6, shrink=0.35, shift=(0.5, 0.3), seed=1) -> 
     return s._replace(means=m.astype(np.float32))
 
 
+def heavy_tail_scene(s: Scene, frac=0.01, sigma_px=(20.0, 150.0), seed=2) -> Scene:
+    """A heavy-tailed variant of a synth-v1 scene (not a BASELINE configuration): `frac` of the Gaussians get an isotropic
+    extent whose standard deviation ON SCREEN is log-uniform in `sigma_px` pixels (3-sigma rectangles of 8 .. 56 tiles a side,
+    up to the whole frame at small sizes); everything else is synth-v1 (sigma 0.7 .. 4 px).  What a SLAM map looks like to the
+    front end: a few splats that touch hundreds or thousands of tiles each among many that touch three -- the case the
+    reference's duplicateWithKeys walks with ONE thread per Gaussian (L/cuda_rasterizer/rasterizer_impl.cu:70-111).  At config
+    3's size 1 % of the Gaussians then own ~70 % of the tile instances.  Used by tests/test_hip_heavy_tail.py and
+    `bench.py --scene heavy_tail`."""
+    rng = np.random.default_rng(seed)
+    pick = rng.random(s.P) < frac
+    n = int(pick.sum())
+    z = (np.concatenate([s.means, np.ones((s.P, 1), np.float32)], 1).astype(np.float64) @ s.view.astype(np.float64))[:, 2]
+    sig = np.exp(rng.uniform(np.log(sigma_px[0]), np.log(sigma_px[1]), n))
+    sc = s.scales.copy()
+    # (isotropic up to +-10 %: the extent on screen must not depend on the rotation drawn for the Gaussian)
+    sc[pick] = (sig[:, None] * rng.uniform(0.9, 1.1, (n, 3)) * (2 * s.tanfovx / s.W) * np.maximum(z[pick], 0.2)[:, None]).astype(np.float32)
+    return s._replace(scales=sc)
+
+
 def sha16(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]

@@ -9,8 +9,9 @@ The blend kernels are bound by VALU issue, and on gfx950 a wave64 vector instruc
   pk    4.65 v_pk_*_f32 (two operations)
   f64   5.2  double-pipe arithmetic (v_cvt f64<->f32 6.3)
   trans 8.2  v_rcp / v_exp / v_log / v_sqrt / v_rsq _f32, v_permlane{16,32}_swap
-Usage: python profiles/asm_ledger.py file.s <substring of the kernel's mangled name> [entries per loop iteration = 2]
-Prints the instructions of the innermost loop that holds the wave reduction (v_permlane32_swap), by class, per list entry."""
+Usage: python profiles/asm_ledger.py file.s <substring of the kernel's mangled name> [entries per loop iteration = 2] [marker]
+Prints the instructions of the innermost loop that holds `marker` (default: the wave reduction's v_permlane32_swap; the forward
+blend: ds_write_b8, its contribution-tag store), by class, per list entry."""
 import collections
 import re
 import sys
@@ -58,8 +59,9 @@ def main():
         return l
     labels = [(i, with_comment(i)) for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)]
     # the innermost loop header whose body has the permlane32 swap
-    swaps = [i for i, l in enumerate(body) if "v_permlane32_swap" in l]
-    assert swaps, "no wave reduction in this kernel"
+    marker = sys.argv[4] if len(sys.argv) > 4 else "v_permlane32_swap"
+    swaps = [i for i, l in enumerate(body) if marker in l]
+    assert swaps, "no " + marker + " in this kernel"
     hdr = max((i, l) for i, l in labels if "Inner Loop Header" in l and i < swaps[0])
     name = hdr[1].split(":")[0][1:]  # LBBx_y
     # loop region: every block whose comment says it belongs to this header (the latch block may precede the header)
