@@ -132,6 +132,8 @@ struct StatusSlot {
     bool mapped = false;         // this use of the slot: armed (written by the kernels) rather than posted (copied)
     uint32_t tag = 0;
     int W = 0, H = 0, P = 0;     // the forward that took the arm (key of the schedule hint below)
+    hipStream_t stream = nullptr;  // ... and the stream its kernels were enqueued on (dgr_status_poll watches it while it waits)
+    bool enqueued = false;         // the forward's blend kernel -- which delivers the word -- has been enqueued
 };
 std::mutex g_status_mu;
 std::vector<StatusSlot> g_status_slots;
@@ -176,19 +178,20 @@ struct ArmedReport {
     long id = -1;
     dgr::StatusReport rep{nullptr, 0u, nullptr};
     bool handed_over = false;
-    ArmedReport(int W, int H, int P) {
+    ArmedReport(int W, int H, int P, hipStream_t st = nullptr) {
         id = g_armed_slot;
         g_armed_slot = -1;
         if (id < 0) return;
         std::lock_guard<std::mutex> lk(g_status_mu);
         StatusSlot& sl = g_status_slots[(size_t)id];
-        sl.W = W; sl.H = H; sl.P = P;
+        sl.W = W; sl.H = H; sl.P = P; sl.stream = st; sl.enqueued = false;
         rep.host = sl.pinned_dev; rep.tag = sl.tag; rep.ws = sl.ws;
     }
     ~ArmedReport() {
-        if (id < 0 || handed_over) return;
+        if (id < 0) return;
         std::lock_guard<std::mutex> lk(g_status_mu);
         StatusSlot& sl = g_status_slots[(size_t)id];
+        if (handed_over) { sl.enqueued = true; return; }
         volatile int* w = sl.pinned;
         w[0] = w[1] = w[2] = w[3] = 0; w[5] = 0x7fffffff;
         w[4] = (int)sl.tag;
@@ -595,7 +598,7 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
                 cov3D_precomp, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
                 out_color, out_depth, out_median_depth, out_alpha, gt_depth, out_depth_var, gau_uncertainty,
                 gau_related_pixels, radii};
-    ArmedReport armed(width, height, P);  // (dgr_status_arm: completed from the host on every path that enqueues no binning kernel)
+    ArmedReport armed(width, height, P, st);  // (dgr_status_arm: completed from the host on every path that enqueues no binning kernel)
     int rc = check_common(c);
     if (rc) return rc;
     if (P == 0) {
@@ -734,7 +737,7 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
     FwdCommon c{P, D, M, width, height, background, means3D, shs, colors_precomp, opacities, scales, rotations,
                 cov3D_precomp, scale_modifier, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered,
                 out_color, out_depth, nullptr, out_uncertainty, gt_depth, nullptr, nullptr, nullptr, radii};
-    ArmedReport armed(width, height, P);  // (dgr_status_arm: completed from the host on every path that enqueues no binning kernel)
+    ArmedReport armed(width, height, P, st);  // (dgr_status_arm: completed from the host on every path that enqueues no binning kernel)
     int rc = check_common(c);
     if (rc) return rc;
     if (P == 0) {
@@ -1134,7 +1137,7 @@ static long status_slot_acquire() {
         if (!g_status_slots[i].busy && g_status_slots[i].device == dev) return (long)i;
     StatusSlot sl;
     HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
-    HIP_TRY(hipHostMalloc((void**)&sl.pinned, 8 * sizeof(int), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void**)&sl.pinned, 8 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
     HIP_TRY(hipHostGetDevicePointer((void**)&sl.pinned_dev, sl.pinned, 0));
     HIP_TRY(hipMalloc((void**)&sl.ws, 16 * sizeof(uint32_t)));
     HIP_TRY(hipMemset(sl.ws, 0, 16 * sizeof(uint32_t)));  // (once per slot; the kernels keep the words zero between forwards)
@@ -1178,8 +1181,9 @@ long dgr_status_arm(void) {
 int dgr_status_poll(long ticket, int wait, int* host_status4) {
     hipEvent_t ev;
     int* pinned;
-    bool mapped;
+    bool mapped, enqueued;
     uint32_t tag;
+    hipStream_t stream;
     {
         std::lock_guard<std::mutex> lk(g_status_mu);
         if (ticket < 0 || (size_t)ticket >= g_status_slots.size() || !g_status_slots[(size_t)ticket].busy || !host_status4) {
@@ -1191,16 +1195,49 @@ int dgr_status_poll(long ticket, int wait, int* host_status4) {
         pinned = g_status_slots[(size_t)ticket].pinned;
         mapped = g_status_slots[(size_t)ticket].mapped;
         tag = g_status_slots[(size_t)ticket].tag;
+        stream = g_status_slots[(size_t)ticket].stream;
+        enqueued = g_status_slots[(size_t)ticket].enqueued;
     }
-    if (mapped) {  // written by the forward's binning kernel, the tag last: nothing to wait for on a stream
-        const volatile int* w = pinned;
-        if (w[4] != (int)tag) {
+    if (mapped) {  // written by the forward blend's first workgroup, the tag last: nothing to wait for on a stream
+        const auto tag_here = [&] { return __atomic_load_n(pinned + 4, __ATOMIC_ACQUIRE) == (int)tag; };
+        if (!tag_here()) {
             if (!wait) return 0;
+            // Poll for a while, then stop burning the core (as wait_event_spinning).  The tag comes from ONE workgroup of ONE kernel:
+            // if an earlier kernel of that forward faults, the device hangs or the stream was being captured when the forward was
+            // issued, it never arrives -- so every millisecond the stream itself is asked: an error ends the wait with that error, a
+            // stream that has finished all its work without the tag having been written ends it too, and so does a hard limit
+            // (DGR_STATUS_TIMEOUT_MS, default 30 000).
+            static const long limit_ms = [] { const char* e = getenv("DGR_STATUS_TIMEOUT_MS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 30000L; }();
             const auto t0 = std::chrono::steady_clock::now();
-            while (w[4] != (int)tag)  // (as wait_event_spinning: poll for a while, then stop burning the core)
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            auto next_query = t0 + std::chrono::milliseconds(1);
+            auto release = [&](const char* why) {
+                std::lock_guard<std::mutex> lk(g_status_mu);
+                g_status_slots[(size_t)ticket].busy = false;
+                g_last_error = why;
+                return DGR_ERR_HIP;
+            };
+            while (!tag_here()) {
+                const auto now = std::chrono::steady_clock::now();
+                if (now - t0 > std::chrono::microseconds(400)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                if (now < next_query) continue;
+                next_query = now + std::chrono::milliseconds(1);
+                if (enqueued) {
+                    const hipError_t e = hipStreamQuery(stream);
+                    if (e == hipSuccess) {  // everything enqueued on the stream has completed: the tag is there, or it never will be
+                        if (tag_here()) break;
+                        return release("dgr_status_poll: the forward's stream is idle and its status word never arrived (was the forward "
+                                       "issued while the stream was being captured?)");
+                    }
+                    if (e != hipErrorNotReady) {
+                        (void)release("");
+                        return hip_fail(e, "dgr_status_poll: hipStreamQuery on the forward's stream");
+                    }
+                }
+                if (now - t0 > std::chrono::milliseconds(limit_ms))
+                    return release("dgr_status_poll: timed out waiting for the forward's status word (DGR_STATUS_TIMEOUT_MS)");
+            }
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
+        const volatile int* w = pinned;
         int word[8];
         for (int i = 0; i < 8; i++) word[i] = w[i];
         for (int i = 0; i < 4; i++) host_status4[i] = word[i];

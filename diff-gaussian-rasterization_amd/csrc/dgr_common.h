@@ -138,8 +138,9 @@ __device__ __forceinline__ void report_status(const StatusReport& r, const int* 
     __hip_atomic_store(r.host + 2, flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(r.host + 3, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(r.host + 5, (int)longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the word is on its way before the tag that announces it
-    __hip_atomic_store(r.host + 4, (int)r.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the tag announces the word: a system-scope RELEASE store (the host side reads the tag with an acquire load); the slot is
+    // allocated hipHostMallocMapped | hipHostMallocCoherent, so nothing here rests on the default coherence of host memory
+    __hip_atomic_store(r.host + 4, (int)r.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 struct BinningView {

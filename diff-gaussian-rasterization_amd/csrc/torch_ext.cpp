@@ -14,6 +14,7 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPCachingAllocatorMasqueradingAsCUDA.h>
 
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <stdexcept>
@@ -133,12 +134,54 @@ char* cb_img(size_t n, void* u) { return resize_cb(n, &static_cast<Alloc3*>(u)->
 // allocations, the caching allocator's lock.  view_of builds the TensorImpl of a contiguous window into `base`'s storage
 // directly (what as_strided does underneath, without the dispatch); byte offsets are multiples of 256.
 inline size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
-inline Tensor view_of(const Tensor& base, size_t byte_off, c10::IntArrayRef sizes, at::ScalarType dt) {
+// The raw construction below was validated on PyTorch 2.10 (TensorImpl::VIEW constructor, set_sizes_contiguous, set_storage_offset,
+// wrap_tensor_impl; the autograd engine's saved-tensor version check on such outputs: tests/test_hip_binding_guard.py).  Built
+// against another PyTorch it is NOT used unless DGR_RAW_VIEWS=1 asks for it; DGR_RAW_VIEWS=0 switches it off anywhere; and the
+// first view made in a process is checked against the dispatcher's own view of the same window (pointer, sizes, strides, dtype,
+// aliasing, a fresh version counter) -- a mismatch falls back for good, with one warning.  The fall-back is at::from_blob over the
+// window, its deleter holding `base`: a tensor of its own (own storage object, own version counter, not a view in autograd's
+// books), like the raw one.  NOT narrow / view / as_strided: a custom Function that returns several views of one base may not have
+// them edited in place at all, and views of one base share a version counter -- editing `color` would then invalidate the saved
+// `opacity_map`; neither happens with the reference's separately allocated outputs.
+inline Tensor dispatcher_view(const Tensor& base, size_t byte_off, c10::IntArrayRef sizes, at::ScalarType dt) {
+    Tensor keep = base;
+    return at::from_blob(static_cast<char*>(base.data_ptr()) + byte_off, sizes, [keep](void*) mutable { keep = Tensor(); },
+                         at::TensorOptions().dtype(dt).device(base.device()));
+}
+inline Tensor raw_view(const Tensor& base, size_t byte_off, c10::IntArrayRef sizes, at::ScalarType dt) {
     auto impl = c10::make_intrusive<c10::TensorImpl>(c10::TensorImpl::VIEW, c10::Storage(base.storage()), base.key_set(),
                                                      c10::scalarTypeToTypeMeta(dt));
     impl->set_sizes_contiguous(sizes);
     impl->set_storage_offset((int64_t)(byte_off / c10::elementSize(dt)));
     return Tensor::wrap_tensor_impl(std::move(impl));
+}
+std::atomic<int> g_raw_views{-1};  // -1: not decided yet, 0: dispatcher views, 1: raw views
+inline bool decide_raw_views(const Tensor& base, size_t byte_off, c10::IntArrayRef sizes, at::ScalarType dt) {
+    const char* e = getenv("DGR_RAW_VIEWS");
+    if (e && e[0] == '0') return false;
+#if !(defined(TORCH_VERSION_MAJOR) && TORCH_VERSION_MAJOR == 2 && TORCH_VERSION_MINOR == 10)
+    if (!(e && e[0] == '1')) return false;  // a PyTorch this was not validated on
+#endif
+    bool ok = false;
+    try {
+        const Tensor a = raw_view(base, byte_off, sizes, dt), b = dispatcher_view(base, byte_off, sizes, dt);
+        ok = a.data_ptr() == b.data_ptr() && a.sizes() == b.sizes() && a.strides() == b.strides() && a.scalar_type() == b.scalar_type() &&
+             a.device() == b.device() && a.is_alias_of(base) && a._version() == 0 && a.is_contiguous() && !a.requires_grad() &&
+             !a.is_view() && a.numel() == b.numel() && a.key_set() == b.key_set();
+    } catch (...) {
+        ok = false;
+    }
+    if (!ok) TORCH_WARN_ONCE("dgr_hip: the raw tensor views of csrc/torch_ext.cpp do not behave as on the PyTorch they were validated on; "
+                             "using at::from_blob windows instead");
+    return ok;
+}
+inline Tensor view_of(const Tensor& base, size_t byte_off, c10::IntArrayRef sizes, at::ScalarType dt) {
+    int mode = g_raw_views.load(std::memory_order_relaxed);
+    if (mode < 0) {
+        mode = decide_raw_views(base, byte_off, sizes, dt) ? 1 : 0;
+        g_raw_views.store(mode, std::memory_order_relaxed);
+    }
+    return mode ? raw_view(base, byte_off, sizes, dt) : dispatcher_view(base, byte_off, sizes, dt);
 }
 inline Tensor bytes_on(const c10::Device& dev, size_t n) {
     return at::empty({(long long)std::max<size_t>(n, 1)}, at::TensorOptions().dtype(at::kByte).device(dev));
@@ -162,7 +205,11 @@ struct StateArena {
 // longest-list report that lets the next forward of the shape skip the tile schedule.  While a hipGraph is recorded nothing
 // can be read back: strict mode cannot be captured (as before).
 template <typename Run>
-inline void strict_status(Run& run, long cap, int* s) {
+inline void strict_status(Run& run, long cap, int* s, void* st) {
+    // (a status word cannot be read back while the stream records a hipGraph: the wait below would never end)
+    if (dgr_stream_is_capturing(st))
+        throw std::runtime_error("strict status mode (one host wait per forward) cannot run while its stream is being captured into a "
+                                 "hipGraph: use the lazy mode (DGR_SYNC_MODE=lazy), after a few eager forwards of the same shape");
     const long ticket = dgr_status_arm();
     check(ticket);
     try {
@@ -273,7 +320,7 @@ LightFwd light_forward_core(const Tensor& background, const Tensor& means3D_, co
     long cap = capacity;
     for (;;) {
         int s[4] = {0, 0, 0, 0};
-        strict_status(run, cap, s);  // the one host wait of this forward: until num_rendered is known
+        strict_status(run, cap, s, st);  // the one host wait of this forward: until num_rendered is known
         if (s[2]) throw std::runtime_error("Point is filtered although prefiltered is set. This shouldn't happen!");
         o.rendered = s[0];
         if (o.rendered <= cap) break;
@@ -504,7 +551,7 @@ FullFwd full_forward_core(const Tensor& background, const Tensor& means3D_, cons
     long cap = capacity;
     for (;;) {
         int s[4] = {0, 0, 0, 0};
-        strict_status(run, cap, s);
+        strict_status(run, cap, s, st);
         if (s[2]) throw std::runtime_error("Point is filtered although prefiltered is set. This shouldn't happen!");
         o.rendered = s[0];
         if (o.rendered <= cap) break;
@@ -925,4 +972,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("drop_post_backward_wait", &drop_post_backward_wait);
     m.def("mark_visible", &mark_visible);
     m.def("status_poll", &status_poll);
+    // which kind of views the outputs are: 1 = raw TensorImpl windows, 0 = dispatcher views, -1 = not decided yet (no view made)
+    m.def("raw_views", [] { return g_raw_views.load(); });
+    m.def("set_raw_views", [](long v) { g_raw_views.store(v < 0 ? -1 : v ? 1 : 0); });
 }

@@ -147,12 +147,14 @@ def _set_post_backward_wait(stream, event):
 
 
 def _drop_post_backward_wait(stream):
-    if not _post_backward_waits:
-        return
-    with _post_backward_lock:
-        _post_backward_waits.pop(int(stream.cuda_stream), None)
+    # (the C++ table is dropped whether or not the Python table still has the entry: the Python Function's backward may have
+    #  consumed it -- debug = True, DGR_AUTOGRAD=python -- and the raw event handle the extension holds must not outlive the Event)
+    key = int(stream.cuda_stream)
+    if _post_backward_waits:
+        with _post_backward_lock:
+            _post_backward_waits.pop(key, None)
     if _CompiledC.ext is not None:
-        _CompiledC.ext.drop_post_backward_wait(int(stream.cuda_stream))
+        _CompiledC.ext.drop_post_backward_wait(key)
 
 
 def _consume_post_backward_wait():
@@ -162,6 +164,8 @@ def _consume_post_backward_wait():
     with _post_backward_lock:
         w = _post_backward_waits.pop(key, None)
     if w is not None:
+        if _CompiledC.ext is not None:  # the extension's copy of the entry goes with it (it holds the event's raw handle)
+            _CompiledC.ext.drop_post_backward_wait(key)
         w[0].wait_event(w[1])
 
 

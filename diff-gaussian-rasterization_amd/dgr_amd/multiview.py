@@ -99,9 +99,13 @@ class ViewStreams:
             self.owner, self.stream = owner, stream
             self.prev_stream = None   # the stream of the view issued before this one (before_backward orders after its end)
             self.outer = None         # the caller's stream, restored on exit
+            self.outer_device = None  # ... and the caller's current device (set_stream switches to the stream's device)
 
         def __enter__(self):
+            if self.outer is not None:
+                raise RuntimeError("ViewStreams: a view's block is already open on this stream (the per-stream context is not re-entrant)")
             self.owner._current = self
+            self.outer_device = torch.cuda.current_device()
             self.outer = torch.cuda.current_stream(self.owner.device)
             torch.cuda.set_stream(self.stream)
             return self.stream
@@ -111,6 +115,9 @@ class ViewStreams:
             self.owner._current = None
             light._drop_post_backward_wait(self.stream)  # (a backward that never reached the rasterizer leaves nothing behind)
             torch.cuda.set_stream(self.outer)
+            if self.outer_device != torch.cuda.current_device():  # ViewStreams(device=another GPU): give the caller its device back
+                torch.cuda.set_device(self.outer_device)
+            self.outer = None
             return False
 
     def __init__(self, n=3, device=None, count_with_atomics=None):

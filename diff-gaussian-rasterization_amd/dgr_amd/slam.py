@@ -123,17 +123,52 @@ class _PoseToCamera(torch.autograd.Function):
         return grads[:4], grads[4:], None
 
 
-_PERSPEC = {}  # (tanfovx, tanfovy, znear, zfar, device) -> Proj^T: a constant of the sensor, built once
+# ---- tensors kept between calls (the caches below) are made by kernels of whichever stream was current at their first use.  A
+# later call on ANOTHER stream (dgr_amd.multiview.ViewStreams: a stream per view) must not read them before those kernels have
+# finished: every cache entry carries a stamp -- the creating stream and an event recorded behind the kernels that wrote the
+# tensors -- and a consumer on a different stream waits for that event once (per stream).  While a hipGraph is being recorded
+# nothing is cached.  The keys are (id, _version) of the source tensors: an in-place `viewmatrix.data = ...` swap changes
+# neither and is NOT supported for cached poses -- assign a new tensor, or update it in place with copy_().
+class _Stamp:
+    __slots__ = ("stream", "event", "seen")
+
+    def __init__(self, device):
+        st = torch.cuda.current_stream(device)
+        self.stream = int(st.cuda_stream)
+        self.event = torch.cuda.Event()
+        self.event.record(st)
+        self.seen = {self.stream}
+
+    def order(self, device):
+        st = torch.cuda.current_stream(device)
+        h = int(st.cuda_stream)
+        if h not in self.seen:
+            st.wait_event(self.event)
+            if len(self.seen) < 64:
+                self.seen.add(h)
+
+
+def _stamp(device):
+    dev = torch.device(device)
+    return _Stamp(dev) if dev.type == "cuda" else None
+
+
+_PERSPEC = {}  # (tanfovx, tanfovy, znear, zfar, device) -> (Proj^T, stamp): a constant of the sensor, built once
 
 
 def _perspec_cached(tanfovx, tanfovy, znear, zfar, device):
     key = (float(tanfovx), float(tanfovy), float(znear), float(zfar), device)
-    m = _PERSPEC.get(key)
-    if m is None:
+    hit = _PERSPEC.get(key)
+    if hit is None:
         if len(_PERSPEC) > 32:
             _PERSPEC.clear()
-        m = _PERSPEC[key] = projection_matrix(tanfovx, tanfovy, znear, zfar, device=device).transpose(0, 1).contiguous()
-    return m
+        m = projection_matrix(tanfovx, tanfovy, znear, zfar, device=device).transpose(0, 1).contiguous()
+        if m.is_cuda and torch.cuda.is_current_stream_capturing():
+            return m
+        hit = _PERSPEC[key] = (m, _stamp(m.device))
+    if hit[1] is not None:
+        hit[1].order(hit[0].device)
+    return hit[0]
 
 
 def pose_to_camera(q, t, tanfovx, tanfovy, znear=0.01, zfar=100.0):
@@ -252,11 +287,14 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
                 vm = viewmatrix.detach()
                 projmatrix = _matmul_fixed_order(vm, perspec).contiguous()
                 campos = _campos(vm)
-            hit = (perspec, vm, projmatrix, campos, viewmatrix, perspec_src)  # (the sources too: ids are unique among live objects)
+            # (the sources too: ids are unique among live objects; the stamp: see _Stamp)
+            hit = (perspec, vm, projmatrix, campos, viewmatrix, perspec_src, _stamp(dev) if keep else None)
             if keep:
                 if len(_VIEW_CACHE) >= 16:
                     _VIEW_CACHE.pop(next(iter(_VIEW_CACHE)))
                 _VIEW_CACHE[key] = hit
+        elif hit[6] is not None:
+            hit[6].order(dev)
         perspec, vm, projmatrix, campos = hit[:4]
 
     means3D = pc.get_xyz
@@ -271,11 +309,17 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         screenspace_points = torch.zeros_like(means3D, requires_grad=True)
     else:  # never read, never written: one shared zero tensor per size instead of a fill per call
         key = (means3D.device, means3D.shape[0])
-        screenspace_points = _ZERO_POINTS.get(key)
-        if screenspace_points is None:
+        zp = _ZERO_POINTS.get(key)
+        if zp is None:
             if len(_ZERO_POINTS) > 16:
                 _ZERO_POINTS.clear()
-            screenspace_points = _ZERO_POINTS[key] = torch.zeros_like(means3D)
+            z = torch.zeros_like(means3D)
+            zp = (z, _stamp(z.device))
+            if not (z.is_cuda and torch.cuda.is_current_stream_capturing()):
+                _ZERO_POINTS[key] = zp
+        elif zp[1] is not None:
+            zp[1].order(zp[0].device)
+        screenspace_points = zp[0]
     debug = bool(getattr(pipe, "debug", False)) if pipe is not None else False
     common = dict(image_height=H, image_width=W, tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color,
                   scale_modifier=scaling_modifier, viewmatrix=vm, projmatrix=projmatrix,
@@ -347,11 +391,13 @@ def render_views(cameras, pc, pipe, bg_color, scaling_modifier=1.0, override_col
             campos = _campos(vm)
             gt_depths = torch.stack([g.reshape(H, W) for g in gts])
         # (the sources are held too: an id() is only unique among live objects)
-        hit = (perspec, vm, projmatrices, campos, gt_depths, list(vms), list(gts), perspec_src)
+        hit = (perspec, vm, projmatrices, campos, gt_depths, list(vms), list(gts), perspec_src, None if capturing else _stamp(dev))
         if not capturing:
             if len(_VIEWS_CACHE) >= 4:
                 _VIEWS_CACHE.pop(next(iter(_VIEWS_CACHE)))
             _VIEWS_CACHE[key] = hit
+    elif hit[8] is not None:
+        hit[8].order(hit[1].device)
     perspec, vm, projmatrices, campos, gt_depths = hit[:5]
     dev = vm.device
     # (differentiable where a pose is a leaf: every pose keeps its gradient)
