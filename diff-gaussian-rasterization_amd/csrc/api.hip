@@ -230,6 +230,11 @@ std::atomic<int> g_alpha_mode{[] {
     const char* e = getenv("DGR_FAST_ALPHA");
     return (e && e[0] == '1') ? 1 : 0;
 }()};
+// dgr_set_option("deterministic_grads", 1): the light backward (one-view entry point, alpha_mode 0) forms its gradients without
+// order-dependent float atomics (csrc/render_light.hip: DET): bit-identical run after run, at the price of an instance-major row
+// buffer (64 bytes per tile instance: zero-filled, written and read once) and a smaller batch in the blend backward.  The backward
+// then needs dgr_light_backward_scratch_bytes_r(P, W, H, R) bytes of scratch, R = the value passed as `R` (>= num_rendered).
+std::atomic<int> g_det_grads{[] { const char* e = getenv("DGR_DETERMINISTIC_GRADS"); return (e && e[0] == '1') ? 1 : 0; }()};
 // dgr_set_option("lds_count", v): how the forward bins tile instances.
 //   1 (default) = the two-level segment binning (csrc/segment_binning.hip) whenever the frame's segment tables fit LDS;
 //   0 = returning global atomics on per-tile counters (csrc/binning.hip; inside preprocess_fwd when presized), which also
@@ -578,6 +583,30 @@ size_t dgr_binning_bytes(int cap, int width, int height) {
     return dgr::carve_binning(nullptr, (size_t)(cap > 0 ? cap : 0)).bytes + dgr::carve_segment_tables(nullptr, width, height).bytes;
 }
 size_t dgr_light_backward_scratch_bytes(int P, int, int) { return dgr::carve_backward_scratch(nullptr, P).bytes; }
+namespace {
+// deterministic gradients: behind the standard scratch, {per-block instance sums u32[blocks] | per-block pose partials
+// double[blocks][12] | instance-major rows float[R][16]}
+struct DetScratch {
+    uint32_t* blk;
+    double* pose;
+    float* rows;
+    size_t bytes;
+};
+DetScratch carve_det_scratch(char* base, int P, int R) {
+    const size_t nb = ((size_t)(P > 0 ? P : 0) + 255) / 256;
+    DetScratch d;
+    size_t o = dgr::carve_backward_scratch(nullptr, P).bytes;
+    d.blk = (uint32_t*)(base + o);  o = dgr::align_up(o + 4 * nb, 256);
+    d.pose = (double*)(base + o);   o = dgr::align_up(o + 8 * 12 * nb, 256);
+    d.rows = (float*)(base + o);    o = dgr::align_up(o + sizeof(float) * DGR_ACC_STRIDE * (size_t)(R > 0 ? R : 0), 256);
+    d.bytes = o;
+    return d;
+}
+}  // namespace
+size_t dgr_light_backward_scratch_bytes_r(int P, int W, int H, int R) {
+    if (!g_det_grads.load()) return dgr_light_backward_scratch_bytes(P, W, H);
+    return carve_det_scratch(nullptr, P, R).bytes;
+}
 
 int dgr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float*, uint8_t* present) {
     HIP_TRY(dgr::launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream));
@@ -677,7 +706,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
                        float* dL_dscale, float* dL_drot, int debug, float* dgndcs_dviewmatrix,
                        const float* perspec_matrix, float* dL_dview, float* dg_camd_dviewmatrix,
                        const float* gt_depth, int track_off, int map_off, char* scratch, size_t scratch_bytes) {
-    (void)R; (void)dgndcs_dviewmatrix; (void)dg_camd_dviewmatrix; (void)colors_precomp;
+    (void)dgndcs_dviewmatrix; (void)dg_camd_dviewmatrix; (void)colors_precomp;
     hipStream_t st = (hipStream_t)stream;
     const bool scratch_clean = g_scratch_clean_armed;
     g_scratch_clean_armed = false;
@@ -686,8 +715,11 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
         HIP_TRY(hipMemsetAsync(dL_dview, 0, 16 * 4, st));
         return DGR_OK;
     }
-    if (scratch_bytes < dgr_light_backward_scratch_bytes(P, width, height) || !scratch) {
-        g_last_error = "backward scratch too small";
+    const bool det = g_det_grads.load() != 0 && !(track_off && map_off);
+    if (det && g_alpha_mode.load() != 0) { g_last_error = "deterministic_grads needs alpha_mode 0"; return DGR_ERR_BAD_ARGUMENT; }
+    if (det && R <= 0) { g_last_error = "deterministic_grads: the backward needs R >= num_rendered (it sizes the instance-major row buffer)"; return DGR_ERR_BAD_ARGUMENT; }
+    if (scratch_bytes < dgr_light_backward_scratch_bytes_r(P, width, height, R) || !scratch) {
+        g_last_error = det ? "backward scratch too small (deterministic_grads: dgr_light_backward_scratch_bytes_r)" : "backward scratch too small";
         return DGR_ERR_BAD_ARGUMENT;
     }
     // (the 3D covariance is not kept by the forward: the backward re-forms it from scale and rotation -- the SAME tensors the
@@ -706,9 +738,20 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     r.gt_depth = gt_depth; r.alphas = alphas; r.n_contrib = img.n_contrib; r.dL_dpix = dL_dpix;
     r.dL_dpix_depth = dL_dpix_depth; r.dL_dpix_median = dL_dpix_median_depth; r.dL_dpix_var = dL_dpix_depth_var;
     r.means3D = means3D; r.view = viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
+    DetScratch ds{nullptr, nullptr, nullptr, 0};
+    if (det) {
+        // (the Gaussians' first-instance offsets go into the geometry state's goff array, which only the global-counter binning
+        //  of the FORWARD uses: free by now)
+        ds = carve_det_scratch(scratch, P, R);
+        { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(ds.rows, sizeof(float) * DGR_ACC_STRIDE * (size_t)R, st)); }
+        HIP_TRY(dgr::launch_det_offsets(P, geom.rect, ds.blk, geom.goff, st));
+        r.det_rows = ds.rows; r.det_rect = geom.rect; r.det_goff = geom.goff; r.det_R = (uint32_t)R;
+    }
     { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_light(r, g_alpha_mode.load(), st)); }
+    if (det) HIP_TRY(dgr::launch_det_gather(P, geom.rect, geom.goff, ds.rows, (uint32_t)R, sc.acc, st));
 
     dgr::PreprocessBwdArgs b{};
+    b.det_pose = det ? ds.pose : nullptr;
     b.P = P; b.D = D; b.M = M; b.W = width; b.H = height; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs;
     b.scales = scales;
     b.rotations = rotations; b.scale_modifier = scale_modifier; b.cov3D_precomp = cov3D_precomp; b.view = viewmatrix;
@@ -822,6 +865,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     (void)R; (void)colors_precomp; (void)dpixel_dgc; (void)gau_id_list; (void)pix_id_list; (void)dgc_dCam_position;
     (void)dpixel_dndcs; (void)dgndcs_dviewmatrix; (void)dpixel_dinvcovs; (void)dgc_invcovs_dT; (void)ddepth_dndcs;
     (void)ddepth_dinvcovs;
+    if (g_det_grads.load()) { g_last_error = "deterministic_grads: the light variant's one-view backward only"; return DGR_ERR_BAD_ARGUMENT; }
     hipStream_t st = (hipStream_t)stream;
     const bool scratch_clean = g_scratch_clean_armed;
     g_scratch_clean_armed = false;
@@ -959,6 +1003,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
                              int track_off, int map_off) {
     (void)colors_precomp;
     hipStream_t st = (hipStream_t)stream;
+    if (g_det_grads.load()) { g_last_error = "deterministic_grads: the light variant's one-view backward only"; return DGR_ERR_BAD_ARGUMENT; }
     if (n_views < 1 || n_views > DGR_MAX_BATCH_VIEWS || !views) { g_last_error = "1 .. DGR_MAX_BATCH_VIEWS views per batch"; return DGR_ERR_BAD_ARGUMENT; }
     if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
     for (int v = 0; v < n_views; v++)
@@ -1303,6 +1348,7 @@ int dgr_set_option(const char* name, int value) {
         return DGR_OK;
     }
     if (n == "lds_count") { g_lds_count.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
+    if (n == "deterministic_grads") { g_det_grads.store(value ? 1 : 0); return DGR_OK; }
     if (n == "profile_every") { g_profile_every.store(value > 0 ? value : 1); return DGR_OK; }
     if (n == "batch_order") { g_batch_order.store(value ? 1 : 0); return DGR_OK; }
     if (n == "batch_streams") { g_batch_streams.store(value < 1 ? 1 : value > DGR_BATCH_MAX_STREAMS ? DGR_BATCH_MAX_STREAMS : value); return DGR_OK; }
@@ -1317,6 +1363,7 @@ int dgr_get_option(const char* name) {
     if (n == "fast_alpha") return g_alpha_mode.load() == 1 ? 1 : 0;
     if (n == "alpha_mode") return g_alpha_mode.load();
     if (n == "lds_count") return g_lds_count.load();
+    if (n == "deterministic_grads") return g_det_grads.load();
     if (n == "profile_every") return g_profile_every.load();
     if (n == "batch_streams") return g_batch_streams.load();
     if (n == "batch_order") return g_batch_order.load();

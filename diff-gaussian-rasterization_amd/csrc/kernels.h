@@ -120,6 +120,7 @@ struct PreprocessBwdArgs {
                         //    dgc_dCampos / colour-only ndc sums / front-most depth sums); 0: light
     GeometryView geom;
     float* acc;         // [P,16] sums written by the blend backward
+    double* det_pose;   // deterministic gradients: [blocks, 12] per-block pose partials (NULL: the 64 bucket rows, double atomics)
     int clear_scratch;  // 1: leave the scratch as it was found -- all zero: every accumulator row read is cleared by its reader and
                         //    the block that finishes the pose sum clears the buckets and the ticket (dgr_backward_scratch_clean_arm)
     float* dL_dmean2D;  // [P,3]
@@ -196,6 +197,12 @@ struct RenderBwdLightArgs {
     const float* view;
     float* acc;  // [P,16]
     int track_off, map_off;
+    // deterministic gradients (render_light.hip: DET): the instance-major row buffer [R,16] (NULL: off), the Gaussians' tile
+    // rectangles and first-instance offsets
+    float* det_rows;
+    const ushort4* det_rect;
+    const uint32_t* det_goff;
+    uint32_t det_R;  // rows of det_rows (>= the frame's instances; a row index beyond it is dropped, not written)
 };
 
 struct RenderFwdFullArgs {
@@ -293,6 +300,8 @@ hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, 
 hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, int alpha_mode, hipStream_t stream);
 hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hipStream_t stream);
 hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream);
+hipError_t launch_det_offsets(int P, const ushort4* rect, uint32_t* blk, uint32_t* goff, hipStream_t stream);
+hipError_t launch_det_gather(int P, const ushort4* rect, const uint32_t* goff, const float* rows, uint32_t R, float* acc, hipStream_t stream);
 hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12, int* comp4,
                                    hipStream_t stream);
 hipError_t launch_exact_math_test(int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div, int alpha_mode,

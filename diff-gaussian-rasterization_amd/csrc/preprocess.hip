@@ -923,6 +923,58 @@ __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], doubl
     pose_finish_if_last((uint32_t)__builtin_amdgcn_readfirstlane((int)t), pose_part, dL_dview, ticket, clear);
 }
 
+// Deterministic form (dgr_set_option("deterministic_grads", 1)): double atomics on the 64 bucket rows arrive in any order, and a
+// double sum depends on its order in the last bit.  Here every block STORES its partial to its own row of `det_pose` and the block
+// that draws the last ticket adds the rows in a fixed order: lane l of wave 0 the rows l, l + 64, ... ascending, then lanes 0..11
+// the 64 lane sums ascending.
+__device__ __forceinline__ void pose_block_reduce_det(const float (&pose)[12], double* det_pose, uint32_t* ticket, float* dL_dview,
+                                                      double (*red)[12], bool clear) {
+    __shared__ double lane_sum[64][12];
+    pose_rows_to_lds(pose, red);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    if (threadIdx.x < 12) {
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) part += red[r][threadIdx.x];
+        __hip_atomic_store(det_pose + (size_t)blockIdx.x * 12 + threadIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores are acknowledged before the ticket is taken
+    uint32_t t = 0u;
+    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)t) != gridDim.x - 1) return;
+    {   // (a row's twelve loads in flight together, two rows per trip: one memory round trip per 128 rows, not per value)
+        double acc[12];
+#pragma unroll
+        for (int c = 0; c < 12; c++) acc[c] = 0.0;
+        for (uint32_t b = threadIdx.x; b < gridDim.x; b += 128) {
+            double v[2][12];
+            const bool two = b + 64 < gridDim.x;
+#pragma unroll
+            for (int c = 0; c < 12; c++) {
+                v[0][c] = __hip_atomic_load(det_pose + (size_t)b * 12 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[1][c] = two ? __hip_atomic_load(det_pose + (size_t)(b + 64) * 12 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 12; c++) acc[c] = (acc[c] + v[0][c]) + v[1][c];  // rows l, l + 64, l + 128, ... ascending
+        }
+#pragma unroll
+        for (int c = 0; c < 12; c++) lane_sum[threadIdx.x][c] = acc[c];
+    }
+    // (one wave: LDS writes and reads of a wave are in program order)
+    if (threadIdx.x < 16) {
+        float out = 0.0f;
+        if (threadIdx.x < 12) {
+            double tot = 0.0;
+            for (int l = 0; l < 64; l++) tot += lane_sum[l][threadIdx.x];
+            out = (float)tot;
+        }
+        if (clear && threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < 12) dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
+        if (threadIdx.x < 4) dL_dview[threadIdx.x * 4 + 3] = 0.0f;
+    }
+}
+
 // Fused per-Gaussian backward.  Order of the dL_dmean3D accumulation follows the reference's kernel
 // order: blend-kernel median term, computeCov2DCUDA, preprocessCUDA (2D mean, depth, SH).
 // (forcing more than 4 waves/SIMD spills: 5 -> 128 us, 6 -> 163 us against 87 us)
@@ -1074,7 +1126,10 @@ __global__ void __launch_bounds__(256, DGR_PPB_WAVES) preprocess_bwd_kernel(Prep
         return;
     }
     __shared__ double red[16][12];
-    pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red, a.clear_scratch != 0);
+    if (a.det_pose)
+        pose_block_reduce_det(pose, a.det_pose, a.ticket, a.dL_dview, red, a.clear_scratch != 0);
+    else
+        pose_block_reduce(pose, a.pose_part, a.ticket, a.dL_dview, red, a.clear_scratch != 0);
 }
 
 // ------------------------------------------------------------------------------------------------

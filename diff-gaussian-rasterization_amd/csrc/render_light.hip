@@ -174,19 +174,36 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
 // Tracking mode (map_off) needs only the three sums the pose gradient is built from: a 4-value butterfly.
 constexpr int NACC_LIGHT = 14;
 
-constexpr int BWD_NB = 128;                // list positions staged per batch (256: 5 workgroups per CU, 267 us; 128: 247 us)
-constexpr int BWD_LD = BWD_NB + 1;         // accumulator row length
+// list positions staged per batch (256: 5 workgroups per CU, 267 us; 128: 247 us).  The deterministic kernel (DET, below) keeps one
+// accumulator plane per quadrant wave -- four times the accumulators -- and stages 64 positions per batch to stay at 8 workgroups
+// per CU.
+template <bool DET>
 struct StagedBwd {
-    StagedT<BWD_NB, uint32_t> f;
-    float acc[NACC_LIGHT * BWD_LD];
+    static constexpr int NB = DET ? 64 : 128;
+    static constexpr int LD = NB + 1;          // accumulator row length
+    static constexpr int PLANE = NACC_LIGHT * LD;
+    StagedT<NB, uint32_t> f;
+    float acc[(DET ? 4 : 1) * PLANE];
+    uint32_t inst[DET ? NB : 1];               // DET: the staged entries' rows in the instance-major gradient buffer (~0u: none)
     int max_last;
     uint64_t exptab[32];  // ALPHA_GLIBC: exact_math.h
 };
 
 // 8 waves per SIMD (63 VGPRs, no scratch): measured 258 us at the compiler's own choice of 7, 247 us at 8
-template <int AM, bool DO_MAP, bool DO_POSE>
+//
+// DET (dgr_set_option("deterministic_grads", 1)): gradients that are the same bits run after run.  Two sums of the default kernel
+// depend on the order in which hardware atomics arrive: the four quadrant waves' totals of a (tile, Gaussian) pair meet in LDS
+// float atomics, and the tiles' totals of a Gaussian meet in global float atomics (as in the reference, backward.cu:593-596,
+// 666-680).  Here (a) every wave stores its total into its OWN accumulator plane -- a wave visits a list entry once per batch, so
+// a plain store suffices -- and the planes are added in wave order; (b) the finished row of a (tile, Gaussian) pair is STORED to
+// the pair's own 64-byte row of an instance-major buffer (row = the Gaussian's first instance, det_offsets_kernel, + the tile's
+// position in its rectangle; the buffer is zero-filled first: pairs nobody blended stay zero), and det_gather_kernel adds a
+// Gaussian's rows -- contiguous -- in ascending order into the accumulator row preprocess_bwd reads.
+template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false>
 __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
-    __shared__ StagedBwd sb;
+    typedef StagedBwd<DET> SB;
+    constexpr int BWD_NB = SB::NB, BWD_LD = SB::LD;
+    __shared__ SB sb;
     StagedT<BWD_NB, uint32_t>& s = sb.f;
     const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
@@ -255,7 +272,8 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
     }
 
-    float* const my_acc = sb.acc + (my_comp >= 0 ? my_comp : 0) * BWD_LD;  // this lane's accumulator row (column = slot)
+    // this lane's accumulator row (column = slot); DET: in its wave's own plane
+    float* const my_acc = sb.acc + (DET ? wave * SB::PLANE : 0) + (my_comp >= 0 ? my_comp : 0) * BWD_LD;
 
     // back-to-front: batches cover list positions [lo, hi) with hi walking down from `total`
     for (int hi = total; hi > 0; hi -= BWD_NB) {
@@ -264,9 +282,11 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
         if (tid < cnt) code = stage_tagged<AM>(s, tid, a.point_list[range.x + lo + tid], a.rec);
+        if (!DET) {  // (DET: a plane's column is written by its wave iff the entry's tag names the wave -- nothing to clear)
 #pragma unroll
-        for (int k = 0; k < NACC_LIGHT; k++)
-            if (BWD_NB == DGR_TILE_PIX || tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
+            for (int k = 0; k < NACC_LIGHT; k++)
+                if (BWD_NB == DGR_TILE_PIX || tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
+        }
         const int n = build_lists(s, code, tid, wave, lane);
         const int rel_last4 = 4 * (last_contributor - lo);  // slots whose 4 * index is below this are at or before the last contributor
 
@@ -336,11 +356,38 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     tot = wave_reduce4(g4);
                 }
                 // j4 is wave-uniform here (every lane read the same record)
-                if (my_comp >= 0) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(my_acc) + j4), tot);
+                if (my_comp >= 0) {
+                    float* const cell = reinterpret_cast<float*>(reinterpret_cast<char*>(my_acc) + j4);
+                    if (DET) *cell = tot; else atomicAdd(cell, tot);
+                }
             }
         }
 
         __syncthreads();
+        if (DET && tid < BWD_NB) {
+            // the four planes in wave order into plane 0 (a wave whose tag bit is clear never wrote its column; the sentinel
+            // entries of a padded list write column NB, which nobody reads), and the pair's row in the instance-major buffer
+            uint32_t row = ~0u;
+            if (code != 0u) {
+#pragma unroll
+                for (int k = 0; k < NACC_LIGHT; k++) {
+                    // (components this variant's lanes deliver -- my_comp above; the others are nobody's and read as zero)
+                    const bool delivered = DO_MAP ? (k <= 9 || k == 10 || (DO_POSE && k == 13)) : (k == 4 || k == 5 || k == 13);
+                    float v = 0.f;
+                    if (delivered) {
+#pragma unroll
+                        for (int w = 0; w < 4; w++)
+                            if ((code >> w) & 1u) v += sb.acc[w * SB::PLANE + k * BWD_LD + tid];
+                    }
+                    sb.acc[k * BWD_LD + tid] = v;
+                }
+                const uint32_t gid = s.id[tid];
+                const ushort4 rc = a.det_rect[gid];
+                row = a.det_goff[gid] + (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
+            }
+            sb.inst[tid] = row;
+        }
+        if (DET) __syncthreads();
         // moments -> gradients, one thread per staged Gaussian (backward.cu:627-631, 669-678):
         //   dL/dmean2D = -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2;  dL/dconic = -Sxx/2, -Sxy/2, -Syy/2;  dL/dopacity = S0/o
         if (code != 0u) {
@@ -358,8 +405,68 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
             }
         }
         __syncthreads();
-        flush_acc<NACC_LIGHT, BWD_LD>(sb.acc, s.id, cnt, a.acc, tid);
+        if (DET) {  // 16 consecutive lanes store one pair's 64-byte row (components 14, 15 stay zero)
+            const int comp = tid & 15;
+            for (int r = tid >> 4; r < cnt; r += 16) {
+                const uint32_t row = sb.inst[r];
+                if (row < a.det_R && comp < NACC_LIGHT) a.det_rows[(size_t)row * DGR_ACC_STRIDE + comp] = sb.acc[comp * BWD_LD + r];
+            }
+        } else {
+            flush_acc<NACC_LIGHT, BWD_LD>(sb.acc, s.id, cnt, a.acc, tid);
+        }
     }
+}
+
+// ---- deterministic gradients: the kernels around the DET blend backward
+// n = tiles of a Gaussian's rectangle; goff = exclusive prefix of n over the Gaussians (the reference's point_offsets,
+// L/cuda_rasterizer/rasterizer_impl.cu:283, which the segment binning never needs): per-block sums, then per-block bases.
+__device__ __forceinline__ uint32_t rect_tiles(ushort4 r) { return (r.z > r.x && r.w > r.y) ? (uint32_t)(r.z - r.x) * (uint32_t)(r.w - r.y) : 0u; }
+__global__ void __launch_bounds__(256) det_block_sums_kernel(int P, const ushort4* __restrict__ rect, uint32_t* __restrict__ blk) {
+    __shared__ uint32_t red[4];
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    uint32_t v = g < P ? rect_tiles(rect[g]) : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(256) det_offsets_kernel(int P, const ushort4* __restrict__ rect, const uint32_t* __restrict__ blk,
+                                                          uint32_t* __restrict__ goff) {
+    __shared__ uint32_t red[4], wsum[4];
+    uint32_t before = 0;  // instances of the blocks in front of this one (integer sums: any order)
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += blk[b];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = before;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t n = g < P ? rect_tiles(rect[g]) : 0u;
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((threadIdx.x & 63) >= off) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = red[0] + red[1] + red[2] + red[3];
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) base += wsum[w];
+    if (g < P) goff[g] = base + incl - n;
+}
+// a Gaussian's rows, contiguous from goff, added in ascending order: 16 lanes per Gaussian, a lane per component
+__global__ void __launch_bounds__(256) det_gather_kernel(int P, const ushort4* __restrict__ rect, const uint32_t* __restrict__ goff,
+                                                         const float* __restrict__ rows, uint32_t R, float* __restrict__ acc) {
+    const int g = blockIdx.x * 16 + (threadIdx.x >> 4), comp = threadIdx.x & 15;
+    if (g >= P) return;
+    uint32_t n = rect_tiles(rect[g]);
+    if (n == 0u) return;
+    const uint32_t first = goff[g];
+    if (first >= R) return;
+    n = min(n, R - first);
+    const float* r = rows + (size_t)first * DGR_ACC_STRIDE + comp;
+    float v = 0.f;
+    for (uint32_t i = 0; i < n; i++) v += r[(size_t)i * DGR_ACC_STRIDE];
+    acc[(size_t)g * DGR_ACC_STRIDE + comp] = v;
 }
 
 // self-test of the butterflies: in[c * 64 + lane] -> the three networks' results and value maps per lane (dgr_debug_wave_reduce)
@@ -398,6 +505,15 @@ __global__ void __launch_bounds__(256) exact_math_test_kernel(int n, const float
 
 template <int AM>
 void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t stream) {
+    if (AM == ALPHA_REF && a.det_rows) {
+        if (!a.map_off && !a.track_off)
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, true, true>), dim3(tiles), dim3(256), stream, a);
+        else if (!a.map_off)
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, false, true>), dim3(tiles), dim3(256), stream, a);
+        else
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, false, true, true>), dim3(tiles), dim3(256), stream, a);
+        return;
+    }
     if (!a.map_off && !a.track_off)
         launch_blend((render_bwd_light_kernel<AM, true, true>), dim3(tiles), dim3(256), stream, a);
     else if (!a.map_off)
@@ -425,6 +541,18 @@ hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, int alpha_mode, 
         case ALPHA_GLIBC: launch_bwd_light_mode<ALPHA_GLIBC>(a, tiles, stream); break;
         default: launch_bwd_light_mode<ALPHA_REF>(a, tiles, stream);
     }
+    return hipGetLastError();
+}
+hipError_t launch_det_offsets(int P, const ushort4* rect, uint32_t* blk, uint32_t* goff, hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    const int nb = (P + 255) / 256;
+    launch(det_block_sums_kernel, dim3(nb), dim3(256), stream, P, rect, blk);
+    launch(det_offsets_kernel, dim3(nb), dim3(256), stream, P, rect, (const uint32_t*)blk, goff);
+    return hipGetLastError();
+}
+hipError_t launch_det_gather(int P, const ushort4* rect, const uint32_t* goff, const float* rows, uint32_t R, float* acc, hipStream_t stream) {
+    if (P <= 0) return hipSuccess;
+    launch(det_gather_kernel, dim3((P + 15) / 16), dim3(256), stream, P, rect, goff, rows, R, acc);
     return hipGetLastError();
 }
 hipError_t launch_exact_math_test(int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div,

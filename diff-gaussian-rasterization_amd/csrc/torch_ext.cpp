@@ -445,7 +445,8 @@ std::vector<Tensor> light_backward(const Tensor& background, const Tensor& means
     }
     // scratch (accumulator rows, cleared by the backward's first launch) and, behind it, the [1,4,4] pose gradient -- what
     // L/__init__.py:160-161 sums over dim 0
-    const size_t nscr = up256(dgr_light_backward_scratch_bytes(P, (int)W, (int)H));
+    // (with the option "deterministic_grads" the scratch also holds 64 bytes per tile instance: R = num_rendered, or a lazy forward's capacity)
+    const size_t nscr = up256(dgr_light_backward_scratch_bytes_r(P, (int)W, (int)H, (int)R));
     void* st = stream_of(dev);
     bool resident = false;
     const Tensor scratch = backward_scratch(dev, st, nscr, &resident);

@@ -72,6 +72,7 @@ _SIGS = {
     "dgr_image_bytes": (_sz, [_i, _i]),
     "dgr_binning_bytes": (_sz, [_i, _i, _i]),
     "dgr_light_backward_scratch_bytes": (_sz, [_i, _i, _i]),
+    "dgr_light_backward_scratch_bytes_r": (_sz, [_i, _i, _i, _i]),
     "dgr_mark_visible": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "dgr_light_forward": (_i, [_vp, ALLOC_FN, ALLOC_FN, ALLOC_FN, _vp, _i, _i, _i, _vp, _i, _i,
                                _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i,

@@ -355,7 +355,8 @@ class _C:
         # [1,4,4]: the reference binding returns the per-pixel [H*W,4,4] buffer and its __init__.py sums dim 0
         # (L/rasterize_points.cu:186,235, L/__init__.py:160-161); one already-reduced "pixel" keeps that code working
         dL_dview = torch.empty((1, 4, 4), **f32)
-        scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes(P, W, H), 1),), dtype=torch.uint8, device=dev)
+        # (option "deterministic_grads": + 64 bytes per tile instance; R = num_rendered, or the capacity of a lazy forward)
+        scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes_r(P, W, H, int(R)), 1),), dtype=torch.uint8, device=dev)
         p = _capi.ptr
         q = lambda t: None if t is None else p(t)  # noqa: E731
         _check(lib.dgr_light_backward(

@@ -52,6 +52,10 @@ size_t dgr_image_bytes(int width, int height);
 size_t dgr_binning_bytes(int num_rendered_capacity, int width, int height);
 /* scratch the backward needs (per-Gaussian accumulator rows + reduction partials) */
 size_t dgr_light_backward_scratch_bytes(int P, int width, int height);
+/* ... with the option "deterministic_grads" on: the scratch also holds the instance-major row buffer, 64 bytes per tile
+ * instance -- R = the value the backward will be given as `R`, at least the forward's num_rendered (a lazy caller passes its
+ * binning capacity).  Equals dgr_light_backward_scratch_bytes(P, W, H) while the option is off. */
+size_t dgr_light_backward_scratch_bytes_r(int P, int W, int H, int R);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (L/cr/rasterizer.h:33-38,
  * L/cr/rasterizer_impl.cu:54-66,141-153).  present[i] = (view * p_i).z > 0.2.  `present` is P bytes (bool). */
@@ -259,6 +263,13 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
  *     2 = as 0 with glibc's expf algorithm evaluated in the double pipe (rounds 5-7's default; slower), kept for A/B.
  *     Forward and backward of a view must run in the same mode.
  *  "fast_alpha": the older name of alpha_mode 0 / 1 (get: 1 iff alpha_mode == 1).
+ *  "deterministic_grads": 1 = the light backward (one-view entry point, alpha_mode 0) forms its gradients without order-dependent
+ *     float atomics: every quadrant wave of a tile keeps its own accumulators (added in wave order), every (tile, Gaussian) pair
+ *     stores its finished row into an instance-major buffer (zero-filled first) and a Gaussian's rows are added in ascending tile
+ *     order; the pose gradient's block partials are stored per block and added in block order.  Two runs give the same bits; the
+ *     reference's own result, float atomics in arrival order (L/cuda_rasterizer/backward.cu:593-596, 666-680), lies within its
+ *     run-to-run spread of it.  Costs about a quarter of the backward at config 3 (profiles/r8/deterministic.txt).  Needs
+ *     dgr_light_backward_scratch_bytes_r() of scratch.  The full variant and the batched entry points refuse the option.
  *  "tight_cull": 1 = alpha-aware tile rectangles.  The reference gives a Gaussian every tile its
  *     3-sigma_max circle touches (cuda_rasterizer/forward.cu:229-237, auxiliary.h:46-56); with this option the rectangle
  *     is cut down to the box where alpha can reach 15/255.  Images and gradients are unchanged, but num_rendered, the
