@@ -1,0 +1,38 @@
+#!/bin/bash
+# Round 8 (driver round 5) evidence at HEAD: the GPU suite, smoke, rocprofv3 stats + PMC, every bench line quoted in DESIGN.md.
+cd "$(dirname "$0")/../.."
+O=gpurun_out/r8_evidence; mkdir -p $O
+timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" | grep -v "UserWarning\|return Variable\|assert abs\|Docs:\|Consider using" | tail -12 > $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2 > $O/smoke.log
+bash profiles/final_round.sh r8 > $O/final_round.log 2>&1
+cp gpurun_out/prof_r8/r8_* $O/ 2>/dev/null
+B="python bench.py"
+for i in 1 2 3; do $B --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_config3_light_driver_cmd_$i.json; done
+$B 2>/dev/null | tail -1 > $O/bench_config3_light.json
+$B --views-in-flight 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_one_stream.json
+$B --sync-mode strict --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_strict.json
+$B --tracking --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_tracking.json
+$B --tracking --views-in-flight 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_tracking_one_stream.json
+$B --tight-cull --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_tight_cull.json
+$B --scene clustered --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_clustered.json
+$B --scene heavy_tail --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_heavy_tail.json
+DGR_ALPHA_MODE=1 $B --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_fast_alpha.json
+DGR_ALPHA_MODE=2 $B --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_glibc_alpha.json
+$B --workload config2 --variant full 2>/dev/null | tail -1 > $O/bench_config2_full.json
+$B --workload config2 --variant full --views-in-flight 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config2_full_one_stream.json
+$B --workload config2 --variant full --graph --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config2_full_graph.json
+$B --workload config4 --cpu-runs 1 2>/dev/null | tail -1 > $O/bench_config4_light_view.json
+$B --workload config5 --steps 50 --warmup 5 --cpu-runs 1 2>/dev/null | tail -1 > $O/bench_config5_light_view.json
+python examples/tracking.py --fused 2>&1 | grep -v amdgpu.ids | tail -4 > $O/tracking_example_eager.txt
+python examples/tracking.py --fused --graph 2>&1 | grep -v amdgpu.ids | tail -4 > $O/tracking_example_graph.txt
+python examples/mapping.py 2>&1 | grep -v amdgpu.ids | tail -6 > $O/mapping_example.txt
+for f in $O/bench_*.json; do python - "$f" <<'PY'
+import json,sys
+try:
+    d=json.load(open(sys.argv[1])); c=d["config"]; r=d["roofline"]
+    print(sys.argv[1].split('/')[-1][6:-5], "ms/step", round(d["ms_per_step"],4), "one", c.get("ms_per_view_one_stream") and round(c["ms_per_view_one_stream"],4), "K", c["views_in_flight"], "frac", round(r["frac"],4), r["kernel"], {k:round(v*1e3,1) for k,v in c["stage_ms"].items()}, "graph", c.get("ms_per_step_hipgraph_replay"), "err", (c.get("grad_max_abs_err") or {}).get("max"), "cpu", (d.get("cpu_baseline") or {}).get("value"))
+except Exception as e:
+    print(sys.argv[1], "ERR", e)
+PY
+done > $O/summary.txt
+cat $O/pytest.log $O/smoke.log $O/summary.txt $O/tracking_example_*.txt $O/mapping_example.txt
