@@ -25,6 +25,17 @@ __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 constexpr int DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E;
+// f + f[lane ^ 1] + f[lane ^ 2] + f[lane ^ 3] in every lane of a quad: two DPP adds.  Written as asm because the compiler fuses
+// only the first `f += dpp_mov(f)` into a v_add_f32_dpp and sinks the second add into the caller's branch behind a v_mov_b32_dpp
+// (4.2 + 2.4 cycles of issue instead of 4.2).  The s_nop: a DPP read needs its source written >= 2 wait states earlier.
+__device__ __forceinline__ float quad_sum(float f) {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "+v"(f));
+    return f;
+}
 
 // Twelve sums, within-row stages first.  A DPP add issues at 1.4x a plain VALU instruction, a permlane
 // swap at 2.7x (profiles/microbench/valu_rates.hip), and a merge stage needs one DPP add per input register whatever the
@@ -58,10 +69,7 @@ __device__ __forceinline__ float wave_reduce12d(float (&x)[12]) {
     float u1 = z2 + z3;  // every row: values 8..11 (rows 0, 1: rows 0+1 ; rows 2, 3: rows 2+3)
     // stage 4 (halves): afterwards u0 + u1 holds values 0..3 in row 0, 4..7 in row 1, 8..11 in rows 2 and 3
     asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) : "+v"(u0), "+v"(u1));
-    float f = u0 + u1;
-    f += dpp_mov<DPP_QUAD_XOR1>(f);
-    f += dpp_mov<DPP_QUAD_XOR2>(f);
-    return f;
+    return quad_sum(u0 + u1);
 }
 
 // Sixteen values, within-row stages first: 16 -> 8 -> 4 registers with 24 DPP adds, two swaps + one swap across rows.
@@ -85,10 +93,7 @@ __device__ __forceinline__ float wave_reduce16d(float (&x)[16]) {
     float u0 = z0 + z1;  // rows 0, 2: values 0..3 ; rows 1, 3: values 4..7
     float u1 = z2 + z3;  // rows 0, 2: values 8..11 ; rows 1, 3: values 12..15
     asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) : "+v"(u0), "+v"(u1));
-    float f = u0 + u1;   // row r: values 4 r .. 4 r + 3
-    f += dpp_mov<DPP_QUAD_XOR1>(f);
-    f += dpp_mov<DPP_QUAD_XOR2>(f);
-    return f;
+    return quad_sum(u0 + u1);   // row r: values 4 r .. 4 r + 3
 }
 
 // x[0..3] per lane -> total of value {0,2,1,3}[lane >> 4] in every lane of that 16-lane row (10 instructions).

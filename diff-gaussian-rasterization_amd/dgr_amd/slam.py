@@ -140,10 +140,10 @@ class _Stamp:
         self.seen = {self.stream}
 
     def order(self, device):
-        st = torch.cuda.current_stream(device)
-        h = int(st.cuda_stream)
+        # (the raw handle first: building a Stream object per call costs more than the tensors the cache saves)
+        h = torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
         if h not in self.seen:
-            st.wait_event(self.event)
+            torch.cuda.current_stream(device).wait_event(self.event)
             if len(self.seen) < 64:
                 self.seen.add(h)
 
