@@ -203,7 +203,11 @@ int dgr_status_poll(long ticket, int wait, int* host_status4);
  * (full variant; completed by the forward blend, later than the rest) is NOT reported this way: read the device word when it
  * is needed.  A forward that enqueues no binning kernel (P == 0, an argument error) completes the word itself, all zero.  The
  * armed forward also reports its longest tile list, which feeds the "tile_schedule" policy below.  Not while `stream` records
- * a hipGraph (nothing can be read back then: do not arm). */
+ * a hipGraph (nothing can be read back then: do not arm).
+ * A blocking poll (wait != 0) of an armed ticket cannot spin for ever: every millisecond it asks the forward's stream -- a HIP
+ * error there ends the wait with DGR_ERR_HIP, and so does a stream that has finished all its work without the word having
+ * arrived (a forward issued into a capturing stream, a faulted kernel) -- and it gives up after DGR_STATUS_TIMEOUT_MS
+ * (environment, default 30 000).  The ticket is released on every such return. */
 long dgr_status_arm(void);
 int dgr_stream_is_capturing(void* stream);
 int dgr_early_status_arm(void);
