@@ -20,11 +20,21 @@ pytestmark = pytest.mark.gpu
 T, E = hh.T, hh.E
 
 
-def presized_forward(s, deg, cap, arm=False, P=None):
-    """dgr_light_forward_presized through ctypes with every buffer allocated here; returns (ticket, dict of tensors)."""
+def presized_forward(s, deg, cap, arm=False, P=None, reuse=None):
+    """dgr_light_forward_presized through ctypes with every buffer allocated here (or those of an earlier call: `reuse`); returns
+    (ticket, dict of tensors)."""
     lib = _capi.load()
     P = s.P if P is None else P
     dev = hh.dev()
+    if reuse is not None:
+        b, inp, p = reuse, reuse["inputs"], _capi.ptr
+        ticket = lib.dgr_status_arm() if arm else -1
+        b["rc"] = lib.dgr_light_forward_presized(
+            _capi.stream_handle(), p(b["geom"]), p(b["binning"]), cap, p(b["img"]), p(b["status"]), P, deg, 16, p(inp[0]), s.W, s.H,
+            p(inp[1]), p(inp[2]), None, p(inp[3]), p(inp[4]), 1.0, p(inp[5]), None, p(inp[6]), p(inp[7]), p(inp[8]), s.tanfovx,
+            s.tanfovy, 0, p(b["color"]), p(b["depth"]), p(b["median"]), p(b["alpha"]), p(inp[9]), p(b["var"]), p(b["unc"]),
+            p(b["px"]), p(b["radii"]))
+        return ticket, b
     u8 = dict(dtype=torch.uint8, device=dev)
     f32 = dict(dtype=torch.float32, device=dev)
     i32 = dict(dtype=torch.int32, device=dev)
@@ -96,6 +106,57 @@ def test_armed_slot_is_completed_by_the_library_when_no_kernel_runs():
     assert lib.dgr_status_poll(t2, 0, (C.c_int * 4)()) < 0   # armed, not yet taken by a forward: not pollable
     t3, b3 = presized_forward(s, 3, 4000, arm=False)          # (this forward takes t2's arm)
     assert poll(t2)[0] == 1
+
+
+def test_a_blocking_poll_ends_when_the_word_can_never_arrive():
+    """The armed word comes from one workgroup of one kernel.  A forward issued into a stream that is recording a hipGraph enqueues
+    nothing that runs: the wait used to spin for ever.  It now asks the stream -- idle, no word -- and returns DGR_ERR_HIP; the
+    ticket is released; the next armed forward works."""
+    import time
+    lib = _capi.load()
+    s = make_scene(3000, 96, 64, 1)
+    _, b0 = presized_forward(s, 3, 40000)  # (kernels loaded; the buffers and inputs of the captured call)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            ticket, b = presized_forward(s, 3, 40000, arm=True, reuse=b0)
+    assert b["rc"] >= 0 and ticket >= 0
+    t0 = time.time()
+    rc, _ = poll(ticket, wait=1)
+    assert rc == _capi.DGR_ERR_HIP and time.time() - t0 < 5.0, (rc, time.time() - t0)
+    assert "never arrived" in _capi.last_error()
+    assert lib.dgr_status_poll(ticket, 0, (C.c_int * 4)()) < 0  # released
+    t2, b2 = presized_forward(s, 3, 40000, arm=True)
+    rc, word = poll(t2)
+    assert rc == 1 and word[0] > 0
+
+
+def test_strict_mode_refuses_a_capturing_stream(monkeypatch):
+    """One host wait per forward cannot be recorded into a hipGraph: the compiled binding says so instead of arming a status slot
+    whose word would never come."""
+    from dgr_amd import light
+    from dgr_amd.multiview import make_settings
+    if light._C is not light._CompiledC:
+        pytest.skip("compiled binding not in use")
+    monkeypatch.setenv("DGR_SYNC_MODE", "strict")
+    s = make_scene(3000, 96, 64, 1)
+    dev = hh.dev()
+    rast = light.GaussianRasterizer(make_settings(s, 3, dev))
+    args = dict(means3D=T(s.means), means2D=torch.zeros((s.P, 3), device=dev), opacities=T(s.opac), shs=T(s.shs), scales=T(s.scales),
+                rotations=T(s.rots), viewmatrix=T(s.view), gt_depth=T(s.gt))
+    rast(**args)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="captured"):
+            with torch.cuda.graph(g, stream=side):
+                rast(**args)
+    torch.cuda.synchronize()
+    rast(**args)  # and the rasterizer is usable afterwards
 
 
 def forward_under(option, s, deg):
