@@ -77,6 +77,45 @@ def test_one_tile_frame_at_the_tight_bar(deterministic, oracle):
     check_backward(oracle, s, 3, rel_to_max=4e-6, view_rel_to_max=4e-6, what="deterministic one-tile frame")
 
 
+def test_heavy_tailed_scene(deterministic, oracle):
+    """Splats of hundreds to thousands of tiles: their rows in the instance-major buffer are summed by one 16-lane group each."""
+    from dgr_amd.synth import heavy_tail_scene
+    s = heavy_tail_scene(make_scene(100000, 1920, 1080, 0))
+    a, b = backward_twice(s, 3)
+    for k in list(GRAD_NAMES) + ["dL_dview"]:
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    check_backward(oracle, s, 3, what="deterministic heavy tail")
+
+
+@pytest.mark.parametrize("sync_mode", ["strict", "lazy"])
+def test_through_the_autograd_surface(deterministic, monkeypatch, sync_mode):
+    """GaussianRasterizer -> loss.backward(), twice: the same bits in every leaf's .grad.  In lazy mode the backward is handed the
+    binning CAPACITY as R (the host never learnt num_rendered): the row buffer is sized by it."""
+    from dgr_amd import light
+    from dgr_amd.multiview import make_settings
+    monkeypatch.setenv("DGR_SYNC_MODE", sync_mode)
+    dev = hh.dev()
+    s = make_scene(20000, 320, 200, 3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    rast = light.GaussianRasterizer(make_settings(s, 3, dev))
+    gC, gD, gM = (t(g) * (s.W * s.H) ** 0.5 for g in (s.gC, s.gD[None], s.gM[None]))
+    res = []
+    for _ in range(3):
+        L = dict(means3D=t(s.means), shs=t(s.shs), opac=t(s.opac), scales=t(s.scales), rots=t(s.rots), view=t(s.view))
+        for v in L.values():
+            v.requires_grad_(True)
+        m2 = torch.zeros((s.P, 3), device=dev, requires_grad=True)
+        color, radii, depth, median, var, alpha, unc, px = rast(means3D=L["means3D"], means2D=m2, opacities=L["opac"], shs=L["shs"],
+                                                                scales=L["scales"], rotations=L["rots"], viewmatrix=L["view"], gt_depth=t(s.gt))
+        torch.autograd.backward([color, depth, median], [gC, gD, gM])
+        torch.cuda.synchronize()
+        res.append({k: v.grad.cpu().numpy() for k, v in L.items()} | {"means2D": m2.grad.cpu().numpy()})
+    light.check_async_errors()
+    for k in res[0]:
+        assert np.abs(res[0][k]).max() > 0, k
+        assert np.array_equal(res[1][k].view(np.uint32), res[2][k].view(np.uint32)), k  # (run 0 sized the lazy capacity)
+
+
 def test_the_other_entry_points_refuse_the_option(deterministic):
     from dgr_amd import full as F  # noqa: F401
     s = make_scene(2000, 64, 48, 1)
