@@ -141,6 +141,10 @@ def main():
                          "case the blend kernels' heaviest-first tile schedule is for; heavy_tail = dgr_amd.synth.heavy_tail_scene (1 %% "
                          "of the Gaussians with an on-screen sigma of 20 .. 150 px: a few splats touching hundreds to thousands of "
                          "tiles each among many touching three), the case the front end's per-Gaussian rectangle walks are for")
+    ap.add_argument("--lean-loss", action="store_true",
+                    help="not the headline workload: the loss uses colour and depth only (no gradient image for the median depth and "
+                         "the depth variance, as in CG-SLAM's losses): the compiled node hands the C ABI NULL for both and the blend "
+                         "backward runs its leaner kernel (light variant)")
     ap.add_argument("--sync-mode", default="lazy", choices=["lazy", "strict"],
                     help="lazy: forward's status word is checked one step late (no host sync in the step); "
                          "strict: one blocking status read per forward, like the reference")
@@ -278,7 +282,10 @@ def main():
             torch.autograd.backward([color, depth, unc], [gC, gD, gV])
         else:
             color, radii, depth, median, var, alpha, unc, px = outs
-            torch.autograd.backward([color, depth, median, var], [gC, gD, gM, gV])
+            if args.lean_loss:
+                torch.autograd.backward([color, depth], [gC, gD])
+            else:
+                torch.autograd.backward([color, depth, median, var], [gC, gD, gM, gV])
         if grouped is not None:  # sum over the group's local views, then one fused RCCL all-reduce
             grouped.add_view()
         elif arena is not None:  # one fused RCCL all-reduce of the per-Gaussian gradients after every view
@@ -500,7 +507,8 @@ def main():
                                    + ("" if dist is None else f"; {world} GPUs, rank r renders view r of the same Gaussians (weak scaling, the "
                                       f"per-GPU view is the N=1 workload), exchange pattern of BASELINE config "
                                       f"{'4: one fused all-reduce of the Gaussian gradients after every view' if G == 1 else '5: one fused all-reduce per ' + str(G) + ' local views'}")
-                                   + (" -- TRACKING step: pose gradient only (map_off), not the headline mapping step" if args.tracking else ""), "visible": V,
+                                   + (" -- TRACKING step: pose gradient only (map_off), not the headline mapping step" if args.tracking else "")
+                                   + (" -- LEAN LOSS: colour and depth only (no median / variance gradient images), not the headline" if args.lean_loss else ""), "visible": V,
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
                        "autograd_engine_thread": torch.autograd.is_multithreading_enabled(),
                        "tile_schedule": {0: "never", 1: "always", 2: "by the frame (skipped on even frames)"}.get(_capi.get_option("tile_schedule")),

@@ -199,7 +199,13 @@ struct StagedBwd {
 // the pair's own 64-byte row of an instance-major buffer (row = the Gaussian's first instance, det_offsets_kernel, + the tile's
 // position in its rectangle; the buffer is zero-filled first: pairs nobody blended stay zero), and det_gather_kernel adds a
 // Gaussian's rows -- contiguous -- in ascending order into the accumulator row preprocess_bwd reads.
-template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false>
+//
+// LEAN: the caller passed no gradient image for the median depth and none for the depth variance (NULL pointers: the loss did
+// not use those outputs -- the usual case in CG-SLAM, whose depth_var output is identically zero, forward.cu:317,410).  The
+// kernel then drops what only they feed: the variance term of X and of the depth gradient, and the once-per-pixel median test --
+// five full-rate and three 4.2-cycle instructions per list entry.  Bit-identical to the full kernel fed all-zero images
+// (0 * e^2 adds an exact zero).
+template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false, bool LEAN = false>
 __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
     typedef StagedBwd<DET> SB;
     constexpr int BWD_NB = SB::NB, BWD_LD = SB::LD;
@@ -246,9 +252,11 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         dpix1 = __builtin_nontemporal_load(a.dL_dpix + N + pix_id);
         dpix2 = __builtin_nontemporal_load(a.dL_dpix + 2 * N + pix_id);
         dpix_depth = __builtin_nontemporal_load(a.dL_dpix_depth + pix_id);
-        dpix_median = __builtin_nontemporal_load(a.dL_dpix_median + pix_id);
-        dpix_var = __builtin_nontemporal_load(a.dL_dpix_var + pix_id);
-        gt_px = __builtin_nontemporal_load(a.gt_depth + pix_id);
+        if (!LEAN) {  // (either image may be missing on its own: it then reads as zero)
+            if (a.dL_dpix_median) dpix_median = __builtin_nontemporal_load(a.dL_dpix_median + pix_id);
+            if (a.dL_dpix_var) dpix_var = __builtin_nontemporal_load(a.dL_dpix_var + pix_id);
+            gt_px = __builtin_nontemporal_load(a.gt_depth + pix_id);
+        }
     }
     // per-pixel constants of the loop: -T_final <bg, dL/dpixel> (the background term of dL/dalpha is this times
     // 1/(1 - alpha)) and 2 dL/dvar
@@ -319,7 +327,8 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                 T = t_div<AM>(T, om, inv);  // backward.cu:570
                 const float w = alpha * T;  // dchannel_dcolor = dpixel_depth_ddepth
                 const float e = cd.w - gt_px;
-                const float X = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2 + cd.w * dpix_depth + (e * e) * dpix_var;
+                const float X = LEAN ? cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2 + cd.w * dpix_depth
+                                     : cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2 + cd.w * dpix_depth + (e * e) * dpix_var;
                 const float dL_dalpha = (X - S) * T + bg_term * inv;
                 S = alpha * X + om * S;  // what the NEXT valid pair (towards the front) subtracts: same operations, same order
                 const float qq = oGm * dL_dalpha;  // o G dL/dalpha  (dL_dG * G)
@@ -334,14 +343,17 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     // the Gaussian alone, so only the pixel sum of dL/dmedian is formed here, as one more value of the
                     // butterfly (its twelfth slot is free); preprocess_bwd applies the factors.  `mid_thr` turns to +inf
                     // once the pixel has fired.
-                    const bool fire = valid & (T > mid_thr);
-                    const float gmed = fire ? dpix_median : 0.f;
-                    mid_thr = fire ? __builtin_inff() : mid_thr;
+                    float gmed = 0.f;
+                    if (!LEAN) {
+                        const bool fire = valid & (T > mid_thr);
+                        gmed = fire ? dpix_median : 0.f;
+                        mid_thr = fire ? __builtin_inff() : mid_thr;
+                    }
                     float g[12];
                     g[0] = w * dpix0;
                     g[1] = w * dpix1;
                     g[2] = w * dpix2;
-                    g[3] = wd + (dvar2 * w) * e;
+                    g[3] = LEAN ? wd : wd + (dvar2 * w) * e;
                     g[4] = qdx;        // sum q dx
                     g[5] = qdy;        // sum q dy
                     g[6] = qdx * dx;   // sum q dx^2
@@ -505,6 +517,15 @@ __global__ void __launch_bounds__(256) exact_math_test_kernel(int n, const float
 
 template <int AM>
 void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t stream) {
+    if (AM == ALPHA_REF && !a.det_rows && !a.dL_dpix_median && !a.dL_dpix_var) {
+        if (!a.map_off && !a.track_off)
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, true, false, true>), dim3(tiles), dim3(256), stream, a);
+        else if (!a.map_off)
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, false, false, true>), dim3(tiles), dim3(256), stream, a);
+        else
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, false, true, false, true>), dim3(tiles), dim3(256), stream, a);
+        return;
+    }
     if (AM == ALPHA_REF && a.det_rows) {
         if (!a.map_off && !a.track_off)
             launch_blend((render_bwd_light_kernel<ALPHA_REF, true, true, true>), dim3(tiles), dim3(256), stream, a);

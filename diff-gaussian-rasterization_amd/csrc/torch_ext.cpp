@@ -718,8 +718,10 @@ struct LightNode : public torch::autograd::Function<LightNode> {
         // an output that did not take part in the loss arrives undefined: zeros, as the reference's autograd would have passed
         const Tensor gC = grad[0].defined() ? grad[0] : zeros_like_image(3, H, W, dev);
         const Tensor gD = grad[2].defined() ? grad[2] : zeros_like_image(1, H, W, dev);
-        const Tensor gM = grad[3].defined() ? grad[3] : zeros_like_image(1, H, W, dev);
-        const Tensor gV = grad[4].defined() ? grad[4] : zeros_like_image(1, H, W, dev);
+        // (no gradient image for the median depth / the depth variance: NULL at the C ABI, which then runs the lean blend backward
+        //  -- no zero images are made, filled and read)
+        const Tensor gM = grad[3].defined() ? grad[3] : Tensor();
+        const Tensor gV = grad[4].defined() ? grad[4] : Tensor();
         bool need = false;  // (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp): tracking needs none
         for (int i = 0; i < 8; i++) need = need || ctx->needs_input_grad(i);
         std::vector<Tensor> g = light_backward(sv[13], means3D, sv[6], sv[0], sv[2], sv[3], d["scale_modifier"].toDouble(), sv[4],

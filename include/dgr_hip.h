@@ -104,7 +104,11 @@ int dgr_light_forward_presized(void* stream, char* geometry_buffer, char* binnin
  *  - gradient outputs need not be zero-initialised: rows of invisible Gaussians are written as 0;
  *  - every per-Gaussian gradient output may be NULL and is then not written.  A tracking step (only `viewmatrix` requires
  *    a gradient) passes them all as NULL together with map_off = 1: the backward then forms the pose gradient alone and
- *    moves no dense per-Gaussian rows (248 bytes per Gaussian at SH degree 3).
+ *    moves no dense per-Gaussian rows (248 bytes per Gaussian at SH degree 3);
+ *  - `dL_dpix_median_depth` and `dL_dpix_depth_var` may each be NULL (the loss did not use that output: an all-zero image).
+ *    With both NULL the blend backward runs a leaner kernel -- no variance term, no median test: 8 % fewer issue cycles per
+ *    list entry, bit-identical to all-zero images -- which is what the compiled autograd node passes when autograd hands it
+ *    no gradient for those outputs (CG-SLAM's losses use neither: depth_var is identically zero, L/cr/forward.cu:317,410).
  * `R` is the value forward returned; `radii` may be NULL (internal copy is used).
  * The forward does not keep the 3D covariance: unless `cov3D_precomp` is given, `scales`, `rotations` and `scale_modifier`
  * must be the forward's (the backward re-forms the covariance from them, same expression, same bits) and may not be NULL

@@ -201,3 +201,36 @@ def oracle_module():
     from oracle import oracle as O
     O.use_cmath(False)
     return O
+
+
+@pytest.mark.parametrize("case", [(10000, 256, 256, 3, 0), (100000, 640, 480, 3, 0)])
+@pytest.mark.parametrize("mode", [dict(), dict(map_off=True), dict(track_off=True)])
+def test_missing_median_and_variance_gradient_images_read_as_zero(case, mode):
+    """`dL_dpix_median_depth` / `dL_dpix_depth_var` = NULL (the loss did not use those outputs): both missing runs the LEAN blend
+    backward (csrc/render_light.hip), one missing reads as zero in the full kernel; all three must equal the backward fed
+    all-zero images -- the same operations minus exact zeros -- up to the arrival order of the float atomics."""
+    import torch
+    from dgr_amd import light as L
+    P, W, H, deg, seed = case
+    s = make_scene(P, W, H, seed)
+    out, d = hh.hip_forward(s, deg)
+    (R, color, depth, median, var, alpha, radii, geom, binning, img, _, _) = out
+    T, E = hh.T, hh.E
+    k = (W * H) ** 0.5
+    zero = np.zeros((1, H, W), np.float32)
+
+    def run(gM, gV):
+        g = L._C.rasterize_gaussians_backward(
+            T(s.bg), T(s.means), radii, E(), T(s.scales), T(s.rots), 1.0, E(), T(s.view), T(s.proj), s.tanfovx, s.tanfovy,
+            T(s.gC * k), T(s.gD[None] * k), gM, gV, T(s.gt), T(s.shs), deg, T(s.campos), geom, R, binning, img, alpha, False,
+            T(s.persp), mode.get("track_off", False), mode.get("map_off", False))
+        torch.cuda.synchronize()
+        return [x.cpu().numpy().astype(np.float64) for x in g]
+
+    ref = run(T(zero), T(zero))
+    for name, gM, gV in (("lean", E(), E()), ("no median image", E(), T(zero)), ("no variance image", T(zero), E())):
+        got = run(gM, gV)
+        for i, (a, b) in enumerate(zip(got, ref)):
+            scale = max(np.abs(b).max(), 1e-30)
+            assert np.abs(a - b).max() <= 2e-5 * scale, (name, i, float(np.abs(a - b).max() / scale))
+    assert any(np.abs(x).max() > 0 for x in ref)

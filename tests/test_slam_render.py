@@ -327,9 +327,11 @@ def test_fused_mapping_loop_follows_the_per_view_loop(monkeypatch):
     (a0, a1), pa, _ = mapping_loop(dev, 8000, 192, 144, keyframes, iters, views_in_flight=1)
     (b0, b1), pb, _ = mapping_loop(dev, 8000, 192, 144, keyframes, iters, fused=True)
     assert abs(a0 - b0) <= 1e-5 * a0 and abs(a1 - b1) <= 2e-3 * a1, ((a0, a1), (b0, b1))
-    assert torch.equal(pa.denom, pb.denom) and torch.equal(pa.max_radii2D, pb.max_radii2D)
-    # (40 Adam steps amplify the rounding noise of the blend backward's float atomics: two runs of the SAME loop differ
-    #  by this much too)
+    # (40 Adam steps amplify the rounding noise of the blend backward's float atomics -- two runs of the SAME loop differ by as
+    #  much: a Gaussian's integer radius ceil(3 sigma) may then land one pixel apart, and with it whether a keyframe saw it)
+    dr = (pa.max_radii2D - pb.max_radii2D).abs()
+    assert float(dr.max()) <= 1.0 and int((dr > 0).sum()) <= 4, (float(dr.max()), int((dr > 0).sum()))
+    assert int((pa.denom != pb.denom).sum()) <= 4
     assert float((pa.xyz_gradient_accum - pb.xyz_gradient_accum).abs().max()) <= 2e-2 * float(pa.xyz_gradient_accum.abs().max())
     monkeypatch.setenv("DGR_SYNC_MODE", "lazy")
     (c0, c1), pc_, _ = mapping_loop(dev, 8000, 192, 144, keyframes, iters, fused=True, graph=True)
