@@ -14,6 +14,7 @@ $B --sync-mode strict --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3
 $B --tracking --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_tracking.json
 $B --tracking --views-in-flight 1 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_tracking_one_stream.json
 $B --tight-cull --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_tight_cull.json
+$B --lean-loss --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_lean_loss.json
 $B --scene clustered --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_clustered.json
 $B --scene heavy_tail --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_heavy_tail.json
 DGR_ALPHA_MODE=1 $B --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_config3_light_fast_alpha.json
