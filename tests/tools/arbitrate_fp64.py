@@ -51,10 +51,13 @@ for i in range(wanted[-1] + 1):
     f64 = dict(dL_dmeans2D=m2, dL_dmeans3D=leaves["means3D"].grad.numpy(), dL_dscales=leaves["scales"].grad.numpy(),  # (the reference returns d/d(mod * scale): L/cuda_rasterizer/backward.cu:297,324-327 apply no `mod`)
                dL_drotations=leaves["rotations"].grad.numpy(), dL_dopacity=leaves["opacities"].grad.numpy(), dL_dsh=leaves["shs"].grad.numpy())
     print(tag, f"modes track_off={modes[0]} map_off={modes[1]}; float64 forward vs oracle images: {fwd_err:.1e}")
+    if not modes[0]:  # (the two pose paths of forward.cu:196-234 -- projection and depth -- sum into one dL_dviewmatrix)
+        f64["dL_dview"] = (leaves["view_ndc"].grad + leaves["view_depth"].grad).numpy()
     for k, t in f64.items():
         if modes[1] and k != "dL_dview":
             continue
-        a, b, c = (np.asarray(x, np.float64).reshape(s.P, -1) for x in (g[k], gr[k], t))
+        rows = 4 if k == "dL_dview" else s.P
+        a, b, c = (np.asarray(x, np.float64).reshape(rows, -1) for x in (g[k], gr[k], t))
         scale = max(np.abs(c).max(), 1e-300)
         row = int(np.abs(a - b).max(1).argmax())
         print(f"  {k:14s} of scale: HIP-f64 {np.abs(a - c).max() / scale:.2e}  oracle-f64 {np.abs(b - c).max() / scale:.2e}  HIP-oracle "

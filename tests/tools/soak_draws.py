@@ -1,4 +1,6 @@
 """The random draws of tests/tools/soak_parity.py, importable (tests/tools/arbitrate_fp64.py re-creates single draws)."""
+import os
+
 import numpy as np
 
 from util import make_scene
@@ -7,6 +9,10 @@ from util import make_scene
 class Draws:
     def __init__(self, seed):
         self.rng = np.random.default_rng(seed)
+        # DGR_SOAK_HEAVY=1 (round 8): a third of the draws get a heavy tail -- a few percent of the Gaussians with an on-screen sigma
+        # of up to 3x the frame (dgr_amd.synth.heavy_tail_scene): big rectangles for bin_segments' queue walk, clipped rectangles on
+        # tiny frames, full queues.  Drawn from a generator of its own, so that the draws of older seeds stay what they were.
+        self.heavy = np.random.default_rng(seed + 77777) if os.environ.get("DGR_SOAK_HEAVY") == "1" else None
 
     def scene(self, i):
         rng = self.rng
@@ -18,6 +24,10 @@ class Draws:
             from dgr_amd.synth import cluster_scene
             s = cluster_scene(s, frac=float(rng.uniform(0.3, 0.95)), shrink=float(rng.uniform(0.02, 0.5)),
                               shift=(float(rng.uniform(-0.5, 0.5)), float(rng.uniform(-0.3, 0.3))), seed=2000 + i)
+        if self.heavy is not None and self.heavy.random() < 0.34:
+            from dgr_amd.synth import heavy_tail_scene
+            hi = float(self.heavy.uniform(8.0, 3.0 * max(W, H)))
+            s = heavy_tail_scene(s, frac=float(self.heavy.uniform(0.002, 0.08)), sigma_px=(min(4.0, hi / 2), hi), seed=3000 + i)
         mode = rng.choice(["as drawn", "translucent", "opaque"])
         if mode == "translucent":
             s = s._replace(opac=(s.opac * 0.12).astype(np.float32))
