@@ -74,18 +74,22 @@ __device__ __forceinline__ float t_div(float T, float om, float& inv) {
 // LIST_T = type of a list entry: unsigned short (the forward: its LDS footprint decides 8 workgroups per CU) or uint32_t (the
 // backward kernels: two entries arrive as one 8-byte read, ready to be used as addresses -- parting two 16-bit halves costs a
 // v_lshrrev_b32 at 4.2 cycles and a mask at 2.4 per two entries, in loops bound by vector issue).
-template <int NB, typename LIST_T = unsigned short>
+// NLISTS = 4: one list per quadrant wave; 8: one per HALF of a quadrant (lanes 0-31 = its upper four pixel rows, 32-63 = its
+// lower four: build_half_lists) -- the light forward.  KEEP_ID = false: the Gaussian ids are not kept in LDS (the light forward
+// re-reads them from the tile list when it writes the tags back).
+template <int NB, typename LIST_T = unsigned short, int NLISTS = 4, bool KEEP_ID = true>
 struct StagedT {
     typedef LIST_T list_t;
+    static constexpr bool HAS_ID = KEEP_ID;
     static constexpr int SLOTS = NB;
     static constexpr int SENTINEL = NB;       // record slot that can never contribute (opacity 0)
     static constexpr int LIST_LD = NB + 8;    // list row: NB entries + sentinel padding, 8-byte aligned rows
     float4 rec[2 * (NB + 1)];  // [2*slot] = {x, y, a2, c2}, [2*slot+1] = {b2, opacity, slot (int bits), lthr}
                                //  p2 = dx*(a2*dx + b2*dy) + c2*dy*dy = log2(e) * power (pair_p2)
     float4 rgbd[NB + 1];       // {r, g, b, depth}; [NB] = zeros (the sentinel's entry: the branch-free backward reads it)
-    uint32_t id[NB];
-    LIST_T list[4][LIST_LD];          // per consumer wave: byte offsets (slot * 32) into rec, tile-list order
-    int cnt4[4][4];                   // [staging wave][consumer wave] entries contributed
+    uint32_t id[KEEP_ID ? NB : 1];
+    LIST_T list[NLISTS][LIST_LD];     // per consumer wave (half-wave): byte offsets (slot * 32) into rec, tile-list order
+    int cnt4[4][NLISTS];              // [staging wave][consumer] entries contributed
 };
 using Staged = StagedT<DGR_TILE_PIX>;
 
@@ -95,8 +99,9 @@ using Staged = StagedT<DGR_TILE_PIX>;
 // fast rcp / sqrt used here), so every dropped (pixel, Gaussian) pair is one the per-pixel test rejects.
 // (An exact ellipse-vs-quadrant test was measured: it removes almost no list entries beyond the box -- the
 // iterations without a valid lane are finished pixels and sub-pixel splats -- and costs more VALU than it saves.)
-template <int AM, int NB, typename LT>
-__device__ __forceinline__ unsigned stage_one(StagedT<NB, LT>& s, int slot, uint32_t gid, const float4* __restrict__ rec,
+// HALF_CODES: 8 bits, bit 2 q + h = half h (pixel rows 4 h .. 4 h + 3) of quadrant q.
+template <int AM, bool HALF_CODES = false, class S>
+__device__ __forceinline__ unsigned stage_one(S& s, int slot, uint32_t gid, const float4* __restrict__ rec,
                                               float tile_x0, float tile_y0) {
     const float4 q0 = rec[3 * (size_t)gid + 0];
     const float4 q1 = rec[3 * (size_t)gid + 1];
@@ -110,15 +115,22 @@ __device__ __forceinline__ unsigned stage_one(StagedT<NB, LT>& s, int slot, uint
     s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
     s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, o, __int_as_float(slot), lthr);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
-    s.id[slot] = gid;
+    if (S::HAS_ID) s.id[slot] = gid;
     const float tau = 2.0f * 0.6931471805599453f * l2;
     const float det = q1.x * q1.z - q1.y * q1.y;
     if (!(tau > 0.0f)) return 0u;                                       // opacity below 15/255: can never contribute
-    if (!(det > 0.0f && q1.x > 0.0f && q1.z > 0.0f)) return 0xFu;       // degenerate conic: do not cull
+    if (!(det > 0.0f && q1.x > 0.0f && q1.z > 0.0f)) return HALF_CODES ? 0xFFu : 0xFu;  // degenerate conic: do not cull
     const float k = tau * __builtin_amdgcn_rcpf(det);
     const float hx = __builtin_amdgcn_sqrtf(k * q1.z) * 1.001f + 0.05f, hy = __builtin_amdgcn_sqrtf(k * q1.x) * 1.001f + 0.05f;
     const float gx = q0.x - tile_x0, gy = q0.y - tile_y0;              // centre relative to the tile origin
     const bool xl = (gx + hx >= 0.0f) && (gx - hx <= 7.0f), xr = (gx + hx >= 8.0f) && (gx - hx <= 15.0f);
+    if (HALF_CODES) {
+        const float lo = gy - hy, hi = gy + hy;
+        const unsigned xm = (xl ? 0x33u : 0u) | (xr ? 0xCCu : 0u);    // quadrants 0, 2 are the left ones
+        const unsigned ym = ((hi >= 0.0f) && (lo <= 3.0f) ? 0x05u : 0u) | ((hi >= 4.0f) && (lo <= 7.0f) ? 0x0Au : 0u) |
+                            ((hi >= 8.0f) && (lo <= 11.0f) ? 0x50u : 0u) | ((hi >= 12.0f) && (lo <= 15.0f) ? 0xA0u : 0u);
+        return xm & ym;
+    }
     const bool yt = (gy + hy >= 0.0f) && (gy - hy <= 7.0f), yb = (gy + hy >= 8.0f) && (gy - hy <= 15.0f);
     return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
 }
@@ -132,8 +144,8 @@ constexpr int TAG_SHIFT = DGR_TAG_SHIFT;
 constexpr uint32_t ID_MASK = DGR_ID_MASK;
 
 // backward staging: returns the entry's tag; untagged entries are not loaded
-template <int AM, int NB, typename LT>
-__device__ __forceinline__ unsigned stage_tagged(StagedT<NB, LT>& s, int slot, uint32_t entry, const float4* __restrict__ rec) {
+template <int AM, class S>
+__device__ __forceinline__ unsigned stage_tagged(S& s, int slot, uint32_t entry, const float4* __restrict__ rec) {
     constexpr float PSCALE = AlphaPath<AM>::PSCALE;
     const unsigned code = entry >> TAG_SHIFT;
     if (code == 0u) return 0u;
@@ -156,8 +168,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long m) {
 
 // Builds the four per-consumer lists from the staging threads' quadrant codes.  Contains two barriers;
 // returns the (uniform) length of the calling wave's list, padded to a multiple of 4 with sentinels.
-template <int NB, typename LT>
-__device__ __forceinline__ int build_lists(StagedT<NB, LT>& s, unsigned code, int tid, int wave, int lane) {
+template <class S>
+__device__ __forceinline__ int build_lists(S& s, unsigned code, int tid, int wave, int lane) {
+    typedef typename S::list_t LT;
     unsigned long long bal[4];
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -175,7 +188,38 @@ __device__ __forceinline__ int build_lists(StagedT<NB, LT>& s, unsigned code, in
     }
     const int n = __builtin_amdgcn_readfirstlane(s.cnt4[0][wave] + s.cnt4[1][wave] + s.cnt4[2][wave] + s.cnt4[3][wave]);
     __syncthreads();
-    if (lane < 4) s.list[wave][n + lane] = (LT)(StagedT<NB, LT>::SENTINEL * 32);  // own list, own wave: program order suffices
+    if (lane < 4) s.list[wave][n + lane] = (LT)(S::SENTINEL * 32);  // own list, own wave: program order suffices
+    return n;
+}
+
+// The same for eight lists, one per half of a quadrant (code: stage_one<AM, true>).  Returns the length of the LONGER of the
+// calling wave's two lists; the shorter one is padded with sentinels up to it (+ the unroll's padding), so that one loop
+// step serves the upper half's next entry on lanes 0-31 and the lower half's on lanes 32-63.
+template <class S>
+__device__ __forceinline__ int build_half_lists(S& s, unsigned code, int tid, int wave, int lane) {
+    typedef typename S::list_t LT;
+    unsigned long long bal[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        bal[l] = __ballot((code >> l) & 1u);
+        if (lane == 0) s.cnt4[wave][l] = __popcll(bal[l]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        if ((code >> l) & 1u) {
+            int base = 0;
+            for (int sw = 0; sw < wave; sw++) base += s.cnt4[sw][l];
+            s.list[l][base + lanes_below(bal[l])] = (LT)(tid * 32);
+        }
+    }
+    const int l0 = 2 * wave;
+    const int n0 = __builtin_amdgcn_readfirstlane(s.cnt4[0][l0] + s.cnt4[1][l0] + s.cnt4[2][l0] + s.cnt4[3][l0]);
+    const int n1 = __builtin_amdgcn_readfirstlane(s.cnt4[0][l0 + 1] + s.cnt4[1][l0 + 1] + s.cnt4[2][l0 + 1] + s.cnt4[3][l0 + 1]);
+    __syncthreads();
+    const int n = max(n0, n1);
+    for (int i = n0 + lane; i < n + 4; i += 64) s.list[l0][i] = (LT)(S::SENTINEL * 32);      // own lists, own wave: program order
+    for (int i = n1 + lane; i < n + 4; i += 64) s.list[l0 + 1][i] = (LT)(S::SENTINEL * 32);
     return n;
 }
 
@@ -204,8 +248,10 @@ __device__ __forceinline__ float pair_p2(const float4& q0, const float4& q1, f2 
 }
 
 // two consecutive list entries: one LDS read (4 bytes, parted by a mask and a shift; 8 bytes with 32-bit entries)
-template <int NB, typename LT>
-__device__ __forceinline__ void load2(const StagedT<NB, LT>& s, int wave, int k, float4 (&q0)[2], float4 (&q1)[2]) {
+// (`wave`: the list's index -- the wave, or a lane's half-wave list with eight lists)
+template <class S>
+__device__ __forceinline__ void load2(const S& s, int wave, int k, float4 (&q0)[2], float4 (&q1)[2]) {
+    typedef typename S::list_t LT;
     unsigned off[2];
     if (sizeof(LT) == 4) {
         const uint2 pk = *reinterpret_cast<const uint2*>(&s.list[wave][k]);
@@ -227,8 +273,9 @@ __device__ __forceinline__ void load2(const StagedT<NB, LT>& s, int wave, int k,
 
 // sentinel record: p2 = 0 but lthr = +big, so it never passes `p2 >= lthr`; opacity 0, so its alpha is 0.
 // TAGGED (backward staging, stage_tagged): .w carries the byte offset of the sentinel's all-zero rgbd entry instead.
-template <bool TAGGED = false, int NB, typename LT>
-__device__ __forceinline__ void write_sentinel(StagedT<NB, LT>& s) {
+template <bool TAGGED = false, class S>
+__device__ __forceinline__ void write_sentinel(S& s) {
+    constexpr int NB = S::SLOTS;
     s.rec[2 * NB] = make_float4(0.f, 0.f, 0.f, 0.f);
     s.rec[2 * NB + 1] = make_float4(0.f, 0.f, __int_as_float(TAGGED ? NB * 4 : NB), TAGGED ? __int_as_float(NB * 16) : 3.0e38f);
     s.rgbd[NB] = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -21,16 +21,18 @@ namespace {
 
 // ================================================================================ forward
 // contribution tag of the batch staged at list position pos0 -> top bits of the point_list entry (render_common.h)
-__device__ __forceinline__ void flush_tags(const Staged& s, const uint32_t* hit, uint32_t* point_list, uint32_t pos0, int tid) {
+template <class S>
+__device__ __forceinline__ void flush_tags(const S& s, const uint32_t* hit, uint32_t* point_list, uint32_t pos0, int tid) {
     const uint32_t h = hit[tid];
     if (h == 0u) return;
     const uint32_t tag = (h & 1u) | ((h >> 7) & 2u) | ((h >> 14) & 4u) | ((h >> 21) & 8u);
     point_list[pos0 + tid] = s.id[tid] | (tag << TAG_SHIFT);
 }
 
+// Lists: one per HALF of a quadrant, a loop step serves both half-waves (render_common.h: build_half_lists; render_light.hip)
 template <int AM>
 __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullArgs a) {
-    __shared__ Staged s;
+    __shared__ StagedT<DGR_TILE_PIX, unsigned short, 8> s;
     __shared__ uint32_t hit[DGR_TILE_PIX];  // byte w of word j: quadrant wave w blended staged instance j
     __shared__ int s_nvalid;
     __shared__ uint64_t exptab[32];         // ALPHA_GLIBC: exact_math.h
@@ -45,6 +47,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     const size_t pix_id = (size_t)a.W * py + px;
     const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
+    const int my_list = 2 * wave + (lane >> 5);
 
     const uint2 range = make_uint2(slot.y, slot.z);
     const int total = (int)(range.y - range.x);
@@ -68,12 +71,12 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
         last_base = base;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
-        if (tid < cnt) code = stage_one<AM>(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
-        const int n = build_lists(s, code, tid, wave, lane);
+        if (tid < cnt) code = stage_one<AM, true>(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
+        const int n = build_half_lists(s, code, tid, wave, lane);
 
         for (int k = 0; k < n; k += 2) {
             float4 q0[2], q1[2];
-            load2(s, wave, k, q0, q1);
+            load2(s, my_list, k, q0, q1);
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 f2 dxy;

@@ -38,8 +38,11 @@ namespace {
 // ================================================================================ forward
 constexpr int FWD_UNROLL = 2;  // list entries per loop iteration (4 was measured: no faster, more registers)
 
+// HALVES: eight lists, one per half of a quadrant (render_common.h: build_half_lists); the ids stay out of LDS to keep 8 workgroups per CU
+template <bool HALVES>
 struct StagedFwd {
-    Staged f;
+    typedef StagedT<DGR_TILE_PIX, unsigned short, HALVES ? 8 : 4, !HALVES> staged_t;
+    staged_t f;
     float unc[DGR_TILE_PIX];   // per staged instance: sum of (d - gt)^2 alpha T over its median pixels (forward.cu:386)
     uint32_t cnt[DGR_TILE_PIX];
     uint32_t hit[DGR_TILE_PIX];  // byte w of word j != 0 <=> some pixel of quadrant wave w blended staged instance j
@@ -51,11 +54,14 @@ struct StagedFwd {
 // four 0/1 bytes -> four bits
 __device__ __forceinline__ uint32_t pack4(uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); }
 
-__device__ __forceinline__ void flush_slot(const StagedFwd& sf, const RenderFwdLightArgs& a, uint32_t pos0, int tid, bool staged) {
+template <class SF>
+__device__ __forceinline__ void flush_slot(const SF& sf, const RenderFwdLightArgs& a, uint32_t pos0, int tid, bool staged) {
     if (!staged) return;
     const uint32_t tag = pack4(sf.hit[tid]);
     if (tag == 0u) return;  // nothing blended this instance
-    const uint32_t gid = sf.f.id[tid];
+    uint32_t gid;
+    if constexpr (SF::staged_t::HAS_ID) gid = sf.f.id[tid];
+    else gid = a.point_list[pos0 + tid];  // (untagged still: this thread is the entry's only writer)
     if (sf.cnt[tid] != 0u) {
         atomicAdd(&a.gau_uncertainty[gid], sf.unc[tid]);
         atomicAdd(&a.gau_related_pixels[gid], (int)sf.cnt[tid]);
@@ -63,10 +69,10 @@ __device__ __forceinline__ void flush_slot(const StagedFwd& sf, const RenderFwdL
     a.point_list[pos0 + tid] = gid | (tag << TAG_SHIFT);
 }
 
-template <int AM>
+template <int AM, bool HALVES = false>
 __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
-    __shared__ StagedFwd sf;
-    Staged& s = sf.f;
+    __shared__ StagedFwd<HALVES> sf;
+    typename StagedFwd<HALVES>::staged_t& s = sf.f;
     if (a.rep.host && blockIdx.x == 0 && threadIdx.x == 0) report_status(a.rep, a.status);
     const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
@@ -78,6 +84,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
     const size_t pix_id = (size_t)a.W * py + px;
     const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
+    const int my_list = HALVES ? 2 * wave + (lane >> 5) : wave;
 
     const uint2 range = make_uint2(slot.y, slot.z);
     const int total = (int)(range.y - range.x);
@@ -105,12 +112,12 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         have_flush = true;
         const int cnt = min(DGR_TILE_PIX, total - base);
         unsigned code = 0;
-        if (tid < cnt) code = stage_one<AM>(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
-        const int n = build_lists(s, code, tid, wave, lane);
+        if (tid < cnt) code = stage_one<AM, HALVES>(s, tid, a.point_list[range.x + base + tid], a.rec, tile_x0, tile_y0);
+        const int n = HALVES ? build_half_lists(s, code, tid, wave, lane) : build_lists(s, code, tid, wave, lane);
 
         for (int k = 0; k < n; k += FWD_UNROLL) {
             float4 q0[FWD_UNROLL], q1[FWD_UNROLL];
-            load2(s, wave, k, q0, q1);
+            load2(s, my_list, k, q0, q1);
 #pragma unroll
             for (int u = 0; u < FWD_UNROLL; u++) {
                 f2 dxy;
@@ -547,10 +554,16 @@ void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t s
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
+    // DGR_FWD_HALVES=0: one list per quadrant wave (rounds 1-7's lane mapping, kept for A/B: profiles/r8/ab_fwd_halves.txt)
+    static const bool halves = [] { const char* e = getenv("DGR_FWD_HALVES"); return !(e && e[0] == '0'); }();
+    auto go = [&](auto kh, auto kq) {
+        if (halves) launch_blend(kh, dim3(tiles), dim3(256), stream, a);
+        else launch_blend(kq, dim3(tiles), dim3(256), stream, a);
+    };
     switch (alpha_mode) {
-        case ALPHA_FAST: launch_blend(render_fwd_light_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
-        case ALPHA_GLIBC: launch_blend(render_fwd_light_kernel<ALPHA_GLIBC>, dim3(tiles), dim3(256), stream, a); break;
-        default: launch_blend(render_fwd_light_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
+        case ALPHA_FAST: go(render_fwd_light_kernel<ALPHA_FAST, true>, render_fwd_light_kernel<ALPHA_FAST, false>); break;
+        case ALPHA_GLIBC: go(render_fwd_light_kernel<ALPHA_GLIBC, true>, render_fwd_light_kernel<ALPHA_GLIBC, false>); break;
+        default: go(render_fwd_light_kernel<ALPHA_REF, true>, render_fwd_light_kernel<ALPHA_REF, false>);
     }
     return hipGetLastError();
 }
