@@ -6,6 +6,8 @@ timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -v "^$\|amdgpu.ids" | 
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2 > $O/smoke.log
 bash profiles/final_round.sh r8 > $O/final_round.log 2>&1
 cp gpurun_out/prof_r8/r8_* $O/ 2>/dev/null
+# the traffic file the bench lines below read, from THIS run's counter passes (the snapshot's file may predate a kernel change)
+cp gpurun_out/prof_r8/r8_pmc.txt profiles/r8_pmc.txt && python profiles/make_pmc_traffic.py profiles/r8_pmc.txt ${DGR_EVIDENCE_COMMIT:-worktree} > /dev/null && cp profiles/pmc_traffic.json $O/
 B="python bench.py"
 for i in 1 2 3; do $B --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_config3_light_driver_cmd_$i.json; done
 $B 2>/dev/null | tail -1 > $O/bench_config3_light.json
