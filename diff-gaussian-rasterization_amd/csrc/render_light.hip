@@ -9,11 +9,15 @@
 //    {x, y, a2, b2 | c2, opacity, slot, -} plus {r, g, b, depth} and the Gaussian id, one 48-byte gather
 //    per thread;
 //  * while staging, every thread bounds the region where its Gaussian can reach alpha >= 15/255 (the
-//    ellipse q(d) <= 2 ln(255 o / 15), boxed with a safety margin) and tests it against the four
-//    quadrants.  Wave ballots + mbcnt turn those tests into four COMPACTED lists of 16-bit record
-//    offsets, one per consumer wave, in tile-list order;
-//  * each wave walks its own list four entries at a time: one 8-byte LDS read yields four offsets, eight
-//    broadcast ds_read_b128 fetch the records, then pure VALU per pixel.  The loop has no scalar bit
+//    ellipse q(d) <= 2 ln(255 o / 15), boxed with a safety margin) and tests it against the eight
+//    HALVES of the four quadrants (8x4 pixels = lanes 0-31 / 32-63 of the consumer wave).  Wave ballots +
+//    mbcnt turn those tests into eight COMPACTED lists of 16-bit record offsets, one per half-wave, in
+//    tile-list order (the backward: four lists, one per wave, from the forward's contribution tags);
+//  * each wave walks its two lists side by side, two entries per iteration: one 4-byte LDS read per lane
+//    yields two offsets, ds_read_b128 with one address per half-wave fetch the records (the same four
+//    LDS cycles as a broadcast), then pure VALU per pixel.  A splat reaches 16 of a quadrant's 64
+//    pixels on average and more than half of the pairs stay inside one half, so the halves need 0.73
+//    of the steps a quadrant-wide list takes (render_fwd 112 -> 103 us).  The loop has no scalar bit
 //    scans and "pixel finished" is a per-lane threshold register rather than a lane mask: the first
 //    version of this loop spent ~20 SALU instructions per Gaussian and was bound by the CU's single
 //    scalar unit (SQ_INSTS_SALU ~ 0.87 per CU cycle), not by the four SIMDs.
