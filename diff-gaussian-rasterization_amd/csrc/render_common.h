@@ -93,6 +93,9 @@ struct StagedT {
 };
 using Staged = StagedT<DGR_TILE_PIX>;
 
+template <bool HALF_CODES>
+__device__ __forceinline__ unsigned reach_code(const float4& q0, const float4& q1, float l2, float tile_x0, float tile_y0);
+
 // Stage one instance and return the 4-bit "may touch quadrant" code.
 // A quadrant is kept when the bounding box of the region alpha >= 15/255, i.e. q(d) <= tau = 2 ln(255 o / 15), reaches
 // one of its pixels; the box carries a safety margin far above the rounding of the per-pixel evaluation (and of the
@@ -116,6 +119,11 @@ __device__ __forceinline__ unsigned stage_one(S& s, int slot, uint32_t gid, cons
     s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, o, __int_as_float(slot), lthr);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     if (S::HAS_ID) s.id[slot] = gid;
+    return reach_code<HALF_CODES>(q0, q1, l2, tile_x0, tile_y0);
+}
+// which quadrants (HALF_CODES: which halves of the quadrants) the box of the region alpha >= 15/255 reaches; l2 = log2(255 o / 15)
+template <bool HALF_CODES>
+__device__ __forceinline__ unsigned reach_code(const float4& q0, const float4& q1, float l2, float tile_x0, float tile_y0) {
     const float tau = 2.0f * 0.6931471805599453f * l2;
     const float det = q1.x * q1.z - q1.y * q1.y;
     if (!(tau > 0.0f)) return 0u;                                       // opacity below 15/255: can never contribute
@@ -143,11 +151,15 @@ __device__ __forceinline__ unsigned stage_one(S& s, int slot, uint32_t gid, cons
 constexpr int TAG_SHIFT = DGR_TAG_SHIFT;
 constexpr uint32_t ID_MASK = DGR_ID_MASK;
 
-// backward staging: returns the entry's tag; untagged entries are not loaded
-template <int AM, class S>
-__device__ __forceinline__ unsigned stage_tagged(S& s, int slot, uint32_t entry, const float4* __restrict__ rec) {
+// backward staging: returns the entry's tag; untagged entries are not loaded.
+// HALF_CODES (the tracking backward's half-wave lists): the tag spread over the two halves of each tagged quadrant and cut down
+// by the forward's own box test per half (reach_code: the same function of the same record, so every pair the forward blended --
+// it found that pair through the half's list -- is in the half's list here).
+template <int AM, bool HALF_CODES = false, class S>
+__device__ __forceinline__ unsigned stage_tagged(S& s, int slot, uint32_t entry, const float4* __restrict__ rec,
+                                                 float tile_x0 = 0.f, float tile_y0 = 0.f) {
     constexpr float PSCALE = AlphaPath<AM>::PSCALE;
-    const unsigned code = entry >> TAG_SHIFT;
+    unsigned code = entry >> TAG_SHIFT;
     if (code == 0u) return 0u;
     const uint32_t gid = entry & ID_MASK;
     const float4 q0 = rec[3 * (size_t)gid + 0];
@@ -159,6 +171,10 @@ __device__ __forceinline__ unsigned stage_tagged(S& s, int slot, uint32_t entry,
     s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, q0.w, __int_as_float(slot * 4), __int_as_float(slot * 16));
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
+    if (HALF_CODES) {
+        const unsigned spread = ((code & 1u) * 0x03u) | ((code & 2u) * 0x06u) | ((code & 4u) * 0x0Cu) | ((code & 8u) * 0x18u);
+        code = spread & reach_code<true>(q0, q1, __log2f(q0.w * (255.0f / 15.0f)), tile_x0, tile_y0);
+    }
     return code;
 }
 

@@ -188,12 +188,13 @@ constexpr int NACC_LIGHT = 14;
 // list positions staged per batch (256: 5 workgroups per CU, 267 us; 128: 247 us).  The deterministic kernel (DET, below) keeps one
 // accumulator plane per quadrant wave -- four times the accumulators -- and stages 64 positions per batch to stay at 8 workgroups
 // per CU.
-template <bool DET>
+template <bool DET, bool HALVES = false>
 struct StagedBwd {
     static constexpr int NB = DET ? 64 : 128;
     static constexpr int LD = NB + 1;          // accumulator row length
     static constexpr int PLANE = NACC_LIGHT * LD;
-    StagedT<NB, uint32_t> f;
+    typedef StagedT<NB, uint32_t, HALVES ? 8 : 4> staged_t;
+    staged_t f;
     float acc[(DET ? 4 : 1) * PLANE];
     uint32_t inst[DET ? NB : 1];               // DET: the staged entries' rows in the instance-major gradient buffer (~0u: none)
     int max_last;
@@ -216,12 +217,19 @@ struct StagedBwd {
 // kernel then drops what only they feed: the variance term of X and of the depth gradient, and the once-per-pixel median test --
 // five full-rate and three 4.2-cycle instructions per list entry.  Bit-identical to the full kernel fed all-zero images
 // (0 * e^2 adds an exact zero).
-template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false, bool LEAN = false>
+//
+// HALVES (the tracking backward, map_off): one list per HALF-wave and a loop step that serves the upper half's next entry on
+// lanes 0-31 and the lower half's on lanes 32-63, as in the forward.  The lists come from the contribution tags cut down by the
+// forward's box test per half (render_common.h: stage_tagged<AM, true>); each half reduces its three sums over its own 32 lanes
+// (half_reduce3) and delivers them to its own entry's accumulator column: six lane-atomics per step.  The MAPPING backward
+// delivers twelve values per entry and is bound by the LDS array's float atomics in this form.
+template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false, bool LEAN = false, bool HALVES = false>
 __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
-    typedef StagedBwd<DET> SB;
+    static_assert(!HALVES || (!DO_MAP && !DET), "half-wave lists: the tracking backward only");
+    typedef StagedBwd<DET, HALVES> SB;
     constexpr int BWD_NB = SB::NB, BWD_LD = SB::LD;
     __shared__ SB sb;
-    StagedT<BWD_NB, uint32_t>& s = sb.f;
+    typename SB::staged_t& s = sb.f;
     const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -286,10 +294,15 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         // component 10 (median), without it slot 10 = component 10
         const int c = (lane >= 48) ? 12 : wave_reduce12d_comp(lane);  // (rows 2 and 3 hold the same four totals: row 2 delivers)
         my_comp = ((lane & 3) != 0 || c > 11) ? -1 : (c == 10 ? (DO_POSE ? 13 : 10) : c == 11 ? (DO_POSE ? 10 : -1) : c);
+    } else if (HALVES) {
+        const int c = half_reduce3_comp(lane);  // {4: gmx, 5: gmy, 13: pose depth} of the lane's half
+        my_comp = c == 0 ? 4 : c == 1 ? 5 : c == 2 ? 13 : -1;
     } else {
         const int c = wave_reduce4_comp(lane);  // {4: gmx, 5: gmy, 13: pose depth}
         my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
     }
+    const int my_list = HALVES ? 2 * wave + (lane >> 5) : wave;
+    const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
 
     // this lane's accumulator row (column = slot); DET: in its wave's own plane
     float* const my_acc = sb.acc + (DET ? wave * SB::PLANE : 0) + (my_comp >= 0 ? my_comp : 0) * BWD_LD;
@@ -300,19 +313,19 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         const int cnt = hi - lo;
         __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
-        if (tid < cnt) code = stage_tagged<AM>(s, tid, a.point_list[range.x + lo + tid], a.rec);
+        if (tid < cnt) code = stage_tagged<AM, HALVES>(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0);
         if (!DET) {  // (DET: a plane's column is written by its wave iff the entry's tag names the wave -- nothing to clear)
 #pragma unroll
             for (int k = 0; k < NACC_LIGHT; k++)
                 if (BWD_NB == DGR_TILE_PIX || tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
         }
-        const int n = build_lists(s, code, tid, wave, lane);
+        const int n = HALVES ? build_half_lists(s, code, tid, wave, lane) : build_lists(s, code, tid, wave, lane);
         const int rel_last4 = 4 * (last_contributor - lo);  // slots whose 4 * index is below this are at or before the last contributor
 
         // (the list is padded with sentinels to a multiple of 4, so a multiple of 2 is always readable)
         for (int k = ((n + 1) & ~1) - 2; k >= 0; k -= 2) {
             float4 q0[2], q1[2];
-            load2(s, wave, k, q0, q1);
+            load2(s, my_list, k, q0, q1);
 #pragma unroll
             for (int u = 1; u >= 0; u--) {
                 f2 dxy;
@@ -374,11 +387,13 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     g[10] = DO_POSE ? wd : gmed;   // -> accumulator component 13 / 10
                     g[11] = DO_POSE ? gmed : 0.f;  // -> accumulator component 10
                     tot = wave_reduce12d(g);
+                } else if (HALVES) {
+                    tot = half_reduce3(qdx, qdy, wd);
                 } else {
                     float g4[4] = {qdx, qdy, wd, 0.f};
                     tot = wave_reduce4(g4);
                 }
-                // j4 is wave-uniform here (every lane read the same record)
+                // j4 is wave-uniform here (every lane read the same record; HALVES: uniform in each half-wave)
                 if (my_comp >= 0) {
                     float* const cell = reinterpret_cast<float*>(reinterpret_cast<char*>(my_acc) + j4);
                     if (DET) *cell = tot; else atomicAdd(cell, tot);
@@ -526,13 +541,24 @@ __global__ void __launch_bounds__(256) exact_math_test_kernel(int n, const float
     }
 }
 
+// DGR_FWD_HALVES=0: one list per quadrant wave in the forward blend and in the tracking backward (rounds 1-7's lane mapping, kept
+// for A/B: profiles/r8/ab_fwd_halves.txt, ab_track_halves.txt).  One switch for both: the backward's half-wave lists are cut from
+// the forward's tags by the forward's box test.
+bool half_wave_lists() {
+    static const bool on = [] { const char* e = getenv("DGR_FWD_HALVES"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <int AM>
 void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t stream) {
+    const bool halves = half_wave_lists();
     if (AM == ALPHA_REF && !a.det_rows && !a.dL_dpix_median && !a.dL_dpix_var) {
         if (!a.map_off && !a.track_off)
             launch_blend((render_bwd_light_kernel<ALPHA_REF, true, true, false, true>), dim3(tiles), dim3(256), stream, a);
         else if (!a.map_off)
             launch_blend((render_bwd_light_kernel<ALPHA_REF, true, false, false, true>), dim3(tiles), dim3(256), stream, a);
+        else if (halves)
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, false, true, false, true, true>), dim3(tiles), dim3(256), stream, a);
         else
             launch_blend((render_bwd_light_kernel<ALPHA_REF, false, true, false, true>), dim3(tiles), dim3(256), stream, a);
         return;
@@ -550,6 +576,8 @@ void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t s
         launch_blend((render_bwd_light_kernel<AM, true, true>), dim3(tiles), dim3(256), stream, a);
     else if (!a.map_off)
         launch_blend((render_bwd_light_kernel<AM, true, false>), dim3(tiles), dim3(256), stream, a);
+    else if (halves && AM != ALPHA_GLIBC)  // (the glibc form, an A/B mode, spills a register with the eight lists)
+        launch_blend((render_bwd_light_kernel<AM == ALPHA_GLIBC ? ALPHA_REF : AM, false, true, false, false, true>), dim3(tiles), dim3(256), stream, a);
     else
         launch_blend((render_bwd_light_kernel<AM, false, true>), dim3(tiles), dim3(256), stream, a);
 }
@@ -558,8 +586,7 @@ void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t s
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
-    // DGR_FWD_HALVES=0: one list per quadrant wave (rounds 1-7's lane mapping, kept for A/B: profiles/r8/ab_fwd_halves.txt)
-    static const bool halves = [] { const char* e = getenv("DGR_FWD_HALVES"); return !(e && e[0] == '0'); }();
+    const bool halves = half_wave_lists();
     auto go = [&](auto kh, auto kq) {
         if (halves) launch_blend(kh, dim3(tiles), dim3(256), stream, a);
         else launch_blend(kq, dim3(tiles), dim3(256), stream, a);

@@ -113,4 +113,26 @@ __device__ __forceinline__ float wave_reduce4(float (&x)[4]) {
     return z;
 }
 
+// Three values, each HALF of the wave (lanes 0-31, lanes 32-63) on its own: afterwards lane 32 h holds the half's total of a,
+// lane 32 h + 16 that of b, lane 32 h + 8 that of c (half_reduce3_comp).  Two swaps across the two rows of a half, one
+// row_mirror merge that packs (a | b) and c into one register, three DPP adds inside the 8-lane groups.
+__device__ __forceinline__ int half_reduce3_comp(int lane) {
+    const int l = lane & 31;
+    return l == 0 ? 0 : l == 16 ? 1 : l == 8 ? 2 : -1;
+}
+__device__ __forceinline__ float half_reduce3(float a, float b, float c) {
+    float c2 = c;
+    // the swap exchanges the odd rows of its first operand with the even rows of its second
+    asm volatile("s_nop 1\n\t" DGR_SWAP16(0, 1) DGR_SWAP16(2, 3) : "+v"(a), "+v"(b), "+v"(c), "+v"(c2));
+    float u = a + b;   // even rows: a over the half's two rows; odd rows: b over them
+    float v = c + c2;  // every row: c over the half's two rows
+    // lanes 0-7 of a row <- u + mirrored u, lanes 8-15 <- v + mirrored v; then 8 -> 4 -> 2 -> 1 inside the groups
+    asm volatile("s_nop 1\n\t"
+                 DGR_MERGE(0, 1, "row_mirror", "0x3", "0xc")
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                 : "+v"(u), "+v"(v));
+    return quad_sum(u);
+}
+
 }  // namespace dgr
