@@ -114,9 +114,17 @@ __device__ __forceinline__ unsigned stage_one(S& s, int slot, uint32_t gid, cons
     // value and re-tests alpha itself on the rare path, so decisions are those of the linear-domain test.
     const float l2 = __log2f(o * (255.0f / 15.0f));  // = tau / (2 ln 2)
     constexpr float PSCALE = AlphaPath<AM>::PSCALE;
-    const float lthr = (o > 0.f) ? (-l2 * (AlphaPath<AM>::LOG2 ? 1.0f : LN2) - 1.0e-4f) : 3.0e38f;
+    float lthr = (o > 0.f) ? (-l2 * (AlphaPath<AM>::LOG2 ? 1.0f : LN2) - 1.0e-4f) : 3.0e38f;
+    float zword = __int_as_float(slot);
+    if (HALF_CODES) {
+        // The slot rides in the low 8 bits of the threshold (a margin of another 1e-4 covers the 255 ulp that moves it: |lthr| < 8)
+        // and the record's third word becomes four spare BYTES: byte w = "some pixel of the LOWER half of quadrant wave w blended
+        // this instance" (the upper halves' bytes are the kernel's `hit` words) -- contribution tags per half, free of LDS.
+        lthr = __int_as_float((__float_as_int(lthr - 1.0e-4f) & ~0xFF) | slot);
+        zword = 0.f;
+    }
     s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
-    s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, o, __int_as_float(slot), lthr);
+    s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, o, zword, lthr);
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     if (S::HAS_ID) s.id[slot] = gid;
     return reach_code<HALF_CODES>(q0, q1, l2, tile_x0, tile_y0);
@@ -151,13 +159,19 @@ __device__ __forceinline__ unsigned reach_code(const float4& q0, const float4& q
 constexpr int TAG_SHIFT = DGR_TAG_SHIFT;
 constexpr uint32_t ID_MASK = DGR_ID_MASK;
 
+// The instance-major byte array of tags per HALF of a quadrant (bit 2 w + h: half h -- pixel rows 4 h .. 4 h + 3, lanes 32 h .. --
+// of quadrant wave w), written by the light forward beside the 4-bit tag for the backward's half-wave lists.  It lives in the
+// binning buffer's `pair_cov` / `ranks` bytes, which the binning is done with when the blend runs; both blend kernels find it
+// from the capacity the binning kernel left in cursor[2] (sched_flag = cursor + 3).
+__device__ __forceinline__ uint8_t* half_tags(const uint32_t* point_list, const uint32_t* sched_flag) {
+    return carve_binning(reinterpret_cast<char*>(const_cast<uint32_t*>(point_list)), (size_t)sched_flag[-1]).pair_cov;
+}
+
 // backward staging: returns the entry's tag; untagged entries are not loaded.
-// HALF_CODES (the tracking backward's half-wave lists): the tag spread over the two halves of each tagged quadrant and cut down
-// by the forward's own box test per half (reach_code: the same function of the same record, so every pair the forward blended --
-// it found that pair through the half's list -- is in the half's list here).
+// HALF_CODES (half-wave lists): returns the forward's tag per HALF of a quadrant instead (bit 2 w + h; `tag8` = half_tags()).
 template <int AM, bool HALF_CODES = false, class S>
 __device__ __forceinline__ unsigned stage_tagged(S& s, int slot, uint32_t entry, const float4* __restrict__ rec,
-                                                 float tile_x0 = 0.f, float tile_y0 = 0.f) {
+                                                 const uint8_t* __restrict__ tag8 = nullptr) {
     constexpr float PSCALE = AlphaPath<AM>::PSCALE;
     unsigned code = entry >> TAG_SHIFT;
     if (code == 0u) return 0u;
@@ -171,10 +185,7 @@ __device__ __forceinline__ unsigned stage_tagged(S& s, int slot, uint32_t entry,
     s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, q0.w, __int_as_float(slot * 4), __int_as_float(slot * 16));
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
-    if (HALF_CODES) {
-        const unsigned spread = ((code & 1u) * 0x03u) | ((code & 2u) * 0x06u) | ((code & 4u) * 0x0Cu) | ((code & 8u) * 0x18u);
-        code = spread & reach_code<true>(q0, q1, __log2f(q0.w * (255.0f / 15.0f)), tile_x0, tile_y0);
-    }
+    if (HALF_CODES) code = *tag8;
     return code;
 }
 

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
                   const float alpha = fminf(0.99f, alpha_raw<AM>(q1[u].y, p2, exptab));
                   if (alpha >= ALPHA_MIN) {
 #pragma clang fp contract(off)  // T (1 - alpha) and the sum of alpha T round as the reference's do (forward.cu:366-381)
-                    const int j = __float_as_int(q1[u].z);
+                    const int j = __float_as_int(q1[u].w) & 0xFF;  // (stage_one<AM, true>: the slot rides in the threshold's low bits)
                     const float4 cd = s.rgbd[j];
                     reinterpret_cast<unsigned char*>(hit)[4 * j + wave] = 1;  // contribution tag
                     const float w = alpha * T;

@@ -59,9 +59,20 @@ struct StagedFwd {
 __device__ __forceinline__ uint32_t pack4(uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); }
 
 template <class SF>
-__device__ __forceinline__ void flush_slot(const SF& sf, const RenderFwdLightArgs& a, uint32_t pos0, int tid, bool staged) {
+__device__ __forceinline__ void flush_slot(const SF& sf, const RenderFwdLightArgs& a, uint8_t* tag8, uint32_t pos0, int tid, bool staged) {
     if (!staged) return;
-    const uint32_t tag = pack4(sf.hit[tid]);
+    uint32_t tag = pack4(sf.hit[tid]);
+    if constexpr (!SF::staged_t::HAS_ID) {  // (the half-wave kernel) lower halves: the bytes of the record's third word
+        const uint32_t lo = pack4(__float_as_uint(sf.f.rec[2 * tid + 1].z));
+        if ((tag | lo) != 0u) {
+            // bit 2 w <- upper half of wave w, bit 2 w + 1 <- its lower half
+            const uint32_t up = tag;
+            const uint32_t t8 = (up & 1u) | ((up & 2u) << 1) | ((up & 4u) << 2) | ((up & 8u) << 3) |
+                                ((lo & 1u) << 1) | ((lo & 2u) << 2) | ((lo & 4u) << 3) | ((lo & 8u) << 4);
+            tag8[pos0 + tid] = (uint8_t)t8;
+        }
+        tag |= lo;
+    }
     if (tag == 0u) return;  // nothing blended this instance
     uint32_t gid;
     if constexpr (SF::staged_t::HAS_ID) gid = sf.f.id[tid];
@@ -89,6 +100,11 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
     const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
     const int my_list = HALVES ? 2 * wave + (lane >> 5) : wave;
+    // where this lane marks "blended": byte `wave` of hit[j] -- HALVES: lanes 32-63 in byte `wave` of the record's spare word
+    uint8_t* const tag8 = HALVES ? half_tags(a.point_list, a.sched_flag) : nullptr;
+    unsigned char* const mark_base = (HALVES && lane >= 32) ? reinterpret_cast<unsigned char*>(&s.rec[1].z) + wave
+                                                             : reinterpret_cast<unsigned char*>(sf.hit) + wave;
+    const int mark_stride = (HALVES && lane >= 32) ? 32 : 4;
 
     const uint2 range = make_uint2(slot.y, slot.z);
     const int total = (int)(range.y - range.x);
@@ -109,7 +125,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         if (__syncthreads_and(ub < 0.f)) break;
         last_base = base;
         // median statistics of the previous batch: slot tid is flushed by the thread that restages it
-        if (have_flush) flush_slot(sf, a, range.x + base - DGR_TILE_PIX, tid, true);  // (an earlier batch is always full)
+        if (have_flush) flush_slot(sf, a, tag8, range.x + base - DGR_TILE_PIX, tid, true);  // (an earlier batch is always full)
         sf.unc[tid] = 0.f;
         sf.cnt[tid] = 0u;
         sf.hit[tid] = 0u;
@@ -134,9 +150,9 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
                     if (test_T < 0.0001f) {
                         ub = -__builtin_inff();  // done; this Gaussian is not blended (forward.cu:368-373)
                     } else {
-                        const int j = __float_as_int(q1[u].z);
+                        const int j = HALVES ? (__float_as_int(q1[u].w) & 0xFF) : __float_as_int(q1[u].z);
                         const float4 cd = s.rgbd[j];
-                        reinterpret_cast<unsigned char*>(sf.hit)[4 * j + wave] = 1;  // contribution tag
+                        mark_base[j * mark_stride] = 1;  // contribution tag
                         const float w = alpha * T;
                         C0 = __builtin_fmaf(cd.x, w, C0); C1 = __builtin_fmaf(cd.y, w, C1); C2 = __builtin_fmaf(cd.z, w, C2);
                         weight = weight + w;
@@ -157,7 +173,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         }
     }
     __syncthreads();
-    if (have_flush) flush_slot(sf, a, range.x + last_base, tid, tid < total - last_base);
+    if (have_flush) flush_slot(sf, a, tag8, range.x + last_base, tid, tid < total - last_base);
 
     if (inside) {
         const size_t N = (size_t)a.W * a.H;
@@ -219,8 +235,8 @@ struct StagedBwd {
 // (0 * e^2 adds an exact zero).
 //
 // HALVES (the tracking backward, map_off): one list per HALF-wave and a loop step that serves the upper half's next entry on
-// lanes 0-31 and the lower half's on lanes 32-63, as in the forward.  The lists come from the contribution tags cut down by the
-// forward's box test per half (render_common.h: stage_tagged<AM, true>); each half reduces its three sums over its own 32 lanes
+// lanes 0-31 and the lower half's on lanes 32-63, as in the forward.  The lists come from the forward's tags per half
+// (render_common.h: half_tags); each half reduces its three sums over its own 32 lanes
 // (half_reduce3) and delivers them to its own entry's accumulator column: six lane-atomics per step.  The MAPPING backward
 // delivers twelve values per entry and is bound by the LDS array's float atomics in this form.
 template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false, bool LEAN = false, bool HALVES = false>
@@ -302,7 +318,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
     }
     const int my_list = HALVES ? 2 * wave + (lane >> 5) : wave;
-    const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
+    const uint8_t* const tag8 = HALVES ? half_tags(a.point_list, a.sched_flag) : nullptr;
 
     // this lane's accumulator row (column = slot); DET: in its wave's own plane
     float* const my_acc = sb.acc + (DET ? wave * SB::PLANE : 0) + (my_comp >= 0 ? my_comp : 0) * BWD_LD;
@@ -313,7 +329,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         const int cnt = hi - lo;
         __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
-        if (tid < cnt) code = stage_tagged<AM, HALVES>(s, tid, a.point_list[range.x + lo + tid], a.rec, tile_x0, tile_y0);
+        if (tid < cnt) code = stage_tagged<AM, HALVES>(s, tid, a.point_list[range.x + lo + tid], a.rec, tag8 + (range.x + lo + tid));
         if (!DET) {  // (DET: a plane's column is written by its wave iff the entry's tag names the wave -- nothing to clear)
 #pragma unroll
             for (int k = 0; k < NACC_LIGHT; k++)
