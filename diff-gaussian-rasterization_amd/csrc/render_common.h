@@ -250,6 +250,123 @@ __device__ __forceinline__ int build_half_lists(S& s, unsigned code, int tid, in
     return n;
 }
 
+// Paired lists (the mapping backward).  A (quadrant, Gaussian) entry reaches 16 of the wave's 64 pixels on average; 28 % of the
+// entries stay in the quadrant's upper half (lanes 0-31), 28 % in its lower half, 44 % touch both.  Two NEIGHBOURS of the wave's
+// list of which one lives in the upper and the other in the lower half can share a loop step -- no pixel sees both, so every
+// pixel still meets its Gaussians in list order -- and the step's reduction stops before the stage that adds the halves
+// (wave_reduce.h).  Every entry is still delivered exactly once with twelve lane-atomics (half-wave lists, where an entry of both
+// halves is delivered twice, drown in them: DESIGN.md Appendix A).
+//   code8 : stage_tagged<AM, true>'s code (bit 2 w + h: half h of quadrant wave w)
+//   phase 1: the four compacted quadrant lists as in build_lists, entry = record offset | type (1 upper, 2 lower, 3 both);
+//   phase 2: every wave pairs its own list: ranks (2 m, 2 m + 1) first, then (2 m + 1, 2 m + 2) where neither was taken -- a
+//            window of five entries decides, no scan -- and writes the STEP lists in place: list[2 w] = what lanes 0-31 process at
+//            step s, list[2 w + 1] = what lanes 32-63 process (the same entry unless the step is a pair).  0.87 steps per entry.
+// Returns the number of steps (wave-uniform); split[c] bit b: step 64 c + b is a pair (the two halves hold different entries).
+template <class S>
+__device__ __forceinline__ int build_paired_lists(S& s, unsigned code8, int tid, int wave, int lane, unsigned long long (&split)[2]) {
+    typedef typename S::list_t LT;
+    static_assert(sizeof(LT) == 4 && S::SLOTS <= 128, "paired lists: 32-bit entries, at most two ranks per lane");
+    unsigned long long bal[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        bal[w] = __ballot(((code8 >> (2 * w)) & 3u) != 0u);
+        if (lane == 0) s.cnt4[wave][w] = __popcll(bal[w]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const unsigned t = (code8 >> (2 * w)) & 3u;
+        if (t != 0u) {
+            int base = 0;
+            for (int sw = 0; sw < wave; sw++) base += s.cnt4[sw][w];
+            s.list[2 * w][base + lanes_below(bal[w])] = (LT)(tid * 32) | t;
+        }
+    }
+    const int n = __builtin_amdgcn_readfirstlane(s.cnt4[0][wave] + s.cnt4[1][wave] + s.cnt4[2][wave] + s.cnt4[3][wave]);
+    __syncthreads();
+    LT* const LU = s.list[2 * wave];
+    LT* const LL = s.list[2 * wave + 1];
+    if (n <= 64) {
+        // the usual case (a batch of 128 positions leaves ~22 entries per quadrant): one rank per lane, the window of five types
+        // through whole-wave DPP shifts (a lane without a neighbour reads 0 = no entry)
+        const bool have = lane < n;
+        const unsigned e0 = have ? LU[lane] : 0u;
+        const int t0 = (int)(e0 & 3u);
+        const int tm1 = __builtin_amdgcn_update_dpp(0, t0, 0x138, 0xf, 0xf, true);   // wave_shr:1
+        const int tm2 = __builtin_amdgcn_update_dpp(0, tm1, 0x138, 0xf, 0xf, true);
+        const int tp1 = __builtin_amdgcn_update_dpp(0, t0, 0x130, 0xf, 0xf, true);   // wave_shl:1
+        const int tp2 = __builtin_amdgcn_update_dpp(0, tp1, 0x130, 0xf, 0xf, true);
+        const bool odd = (lane & 1) != 0;
+        const bool a_self = odd ? (tm1 * t0 == 2) : (t0 * tp1 == 2);
+        const bool a_side = odd ? (tp1 * tp2 == 2) : (tm2 * tm1 == 2);
+        const bool p2 = !a_self && !a_side && (odd ? (t0 * tp1 == 2) : (tm1 * t0 == 2));
+        const bool first = odd ? p2 : a_self, second = odd ? a_self : p2;
+        const unsigned long long keep = __ballot(have && !second);
+        const int steps = __popcll(keep);
+        if (have) {
+            const int st = lanes_below(keep) - (second ? 1 : 0);
+            const LT o = e0 & ~3u;
+            if (first || second) {
+                (t0 == 1 ? LU : LL)[st] = o;
+            } else {
+                LU[st] = o;
+                LL[st] = o;
+            }
+        }
+        if (lane < 4) {
+            LU[steps + lane] = (LT)(S::SENTINEL * 32);
+            LL[steps + lane] = (LT)(S::SENTINEL * 32);
+        }
+        split[0] = __ballot(lane < steps && LU[lane] != LL[lane]);
+        split[1] = 0ull;
+        return steps;
+    }
+    unsigned e[2];
+    bool first[2], second[2], have[2];
+    unsigned long long keep[2];  // ranks that open a step
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int r = lane + 64 * c;
+        auto type_at = [&](int q) -> unsigned { return (q >= 0 && q < n) ? (unsigned)(LU[q] & 3u) : 0u; };
+        have[c] = r < n;
+        e[c] = have[c] ? LU[r] : 0u;
+        const unsigned tm2 = type_at(r - 2), tm1 = type_at(r - 1), t0 = e[c] & 3u, tp1 = type_at(r + 1), tp2 = type_at(r + 2);
+        // (one entry upper-only, the other lower-only: 1 * 2)
+        const bool odd = (r & 1) != 0;
+        const bool a_self = odd ? (tm1 * t0 == 2u) : (t0 * tp1 == 2u);     // ranks (2 m, 2 m + 1) holding r
+        const bool a_side = odd ? (tp1 * tp2 == 2u) : (tm2 * tm1 == 2u);   // the aligned pair next to r's free side
+        const bool p2 = !a_self && !a_side && (odd ? (t0 * tp1 == 2u) : (tm1 * t0 == 2u));  // (r, r + 1) for odd r, (r - 1, r) for even
+        first[c] = odd ? p2 : a_self;
+        second[c] = odd ? a_self : p2;
+        keep[c] = __ballot(have[c] && !second[c]);
+    }
+    const int n0 = __popcll(keep[0]);
+    const int steps = n0 + __popcll(keep[1]);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {  // (every read of the rank list above precedes these writes: one wave, program order)
+        if (have[c]) {
+            const int st = (c ? n0 : 0) + lanes_below(keep[c]) - (second[c] ? 1 : 0);
+            const LT o = e[c] & ~3u;
+            if (first[c] || second[c]) {
+                ((e[c] & 3u) == 1u ? LU : LL)[st] = o;
+            } else {
+                LU[st] = o;
+                LL[st] = o;
+            }
+        }
+    }
+    if (lane < 4) {
+        LU[steps + lane] = (LT)(S::SENTINEL * 32);
+        LL[steps + lane] = (LT)(S::SENTINEL * 32);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int st = lane + 64 * c;
+        split[c] = __ballot(st < steps && LU[st] != LL[st]);
+    }
+    return steps;
+}
+
 // v_pk_*_f32 operands: gfx950 issues two fp32 operations per lane with one packed instruction
 typedef float f2 __attribute__((ext_vector_type(2)));
 

@@ -239,9 +239,14 @@ struct StagedBwd {
 // (render_common.h: half_tags); each half reduces its three sums over its own 32 lanes
 // (half_reduce3) and delivers them to its own entry's accumulator column: six lane-atomics per step.  The MAPPING backward
 // delivers twelve values per entry and is bound by the LDS array's float atomics in this form.
+//
+// With DO_MAP, HALVES means PAIRED lists (render_common.h: build_paired_lists): neighbouring entries of a wave's list that live
+// in different halves of the quadrant share a loop step (0.87 steps per entry); such a step reduces its twelve sums per half and
+// each half delivers to its own entry's column -- every entry is still delivered once.
 template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false, bool LEAN = false, bool HALVES = false>
 __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
-    static_assert(!HALVES || (!DO_MAP && !DET), "half-wave lists: the tracking backward only");
+    static_assert(!HALVES || !DET, "half-wave / paired lists: not with the deterministic kernel's planes (LDS)");
+    constexpr bool PAIRED = HALVES && DO_MAP;
     typedef StagedBwd<DET, HALVES> SB;
     constexpr int BWD_NB = SB::NB, BWD_LD = SB::LD;
     __shared__ SB sb;
@@ -310,12 +315,22 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         // component 10 (median), without it slot 10 = component 10
         const int c = (lane >= 48) ? 12 : wave_reduce12d_comp(lane);  // (rows 2 and 3 hold the same four totals: row 2 delivers)
         my_comp = ((lane & 3) != 0 || c > 11) ? -1 : (c == 10 ? (DO_POSE ? 13 : 10) : c == 11 ? (DO_POSE ? 10 : -1) : c);
-    } else if (HALVES) {
+    } else if (HALVES) {  // (tracking)
         const int c = half_reduce3_comp(lane);  // {4: gmx, 5: gmy, 13: pose depth} of the lane's half
         my_comp = c == 0 ? 4 : c == 1 ? 5 : c == 2 ? 13 : -1;
     } else {
         const int c = wave_reduce4_comp(lane);  // {4: gmx, 5: gmy, 13: pose depth}
         my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
+    }
+    // PAIRED, a step that serves two entries: byte offsets of the accumulator rows this lane delivers r0 / r1 to (-1: none)
+    int off0 = -1, off1 = -1;
+    if (PAIRED) {
+        auto comp_of = [](int slot) { return slot < 10 ? slot : slot == 10 ? (DO_POSE ? 13 : 10) : (DO_POSE ? 10 : -1); };
+        const int c0 = (lane & 3) == 0 ? comp_of(wave_reduce12d_half_slot0(lane)) : -1;
+        const int s1 = wave_reduce12d_half_slot1(lane);
+        const int c1 = ((lane & 3) == 0 && s1 >= 0) ? comp_of(s1) : -1;
+        off0 = c0 >= 0 ? c0 * BWD_LD * 4 : -1;
+        off1 = c1 >= 0 ? c1 * BWD_LD * 4 : -1;
     }
     const int my_list = HALVES ? 2 * wave + (lane >> 5) : wave;
     const uint8_t* const tag8 = HALVES ? half_tags(a.point_list, a.sched_flag) : nullptr;
@@ -335,7 +350,10 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
             for (int k = 0; k < NACC_LIGHT; k++)
                 if (BWD_NB == DGR_TILE_PIX || tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
         }
-        const int n = HALVES ? build_half_lists(s, code, tid, wave, lane) : build_lists(s, code, tid, wave, lane);
+        unsigned long long split[2] = {0ull, 0ull};  // PAIRED: the steps that serve two entries
+        const int n = PAIRED   ? build_paired_lists(s, code, tid, wave, lane, split)
+                      : HALVES ? build_half_lists(s, code, tid, wave, lane)
+                               : build_lists(s, code, tid, wave, lane);
         const int rel_last4 = 4 * (last_contributor - lo);  // slots whose 4 * index is below this are at or before the last contributor
 
         // (the list is padded with sentinels to a multiple of 4, so a multiple of 2 is always readable)
@@ -402,7 +420,22 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     g[9] = qq;         // sum q
                     g[10] = DO_POSE ? wd : gmed;   // -> accumulator component 13 / 10
                     g[11] = DO_POSE ? gmed : 0.f;  // -> accumulator component 10
-                    tot = wave_reduce12d(g);
+                    if (PAIRED) {
+                        float u0, u1;
+                        wave_reduce12d_head(g, u0, u1);
+                        const int st = k + u;  // (wave-uniform: scalar code)
+                        if ((split[st >> 6] >> (st & 63)) & 1ull) {
+                            // a pair: each half's own totals to its own entry's column (j4 is uniform in each half)
+                            const float r0 = quad_sum(u0), r1 = quad_sum(u1);
+                            char* const col = reinterpret_cast<char*>(sb.acc) + j4;
+                            if (off0 >= 0) atomicAdd(reinterpret_cast<float*>(col + off0), r0);
+                            if (off1 >= 0) atomicAdd(reinterpret_cast<float*>(col + off1), r1);
+                            continue;
+                        }
+                        tot = wave_reduce12d_tail(u0, u1);
+                    } else {
+                        tot = wave_reduce12d(g);
+                    }
                 } else if (HALVES) {
                     tot = half_reduce3(qdx, qdy, wd);
                 } else {
@@ -569,8 +602,12 @@ template <int AM>
 void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t stream) {
     const bool halves = half_wave_lists();
     if (AM == ALPHA_REF && !a.det_rows && !a.dL_dpix_median && !a.dL_dpix_var) {
-        if (!a.map_off && !a.track_off)
+        if (!a.map_off && !a.track_off && halves)
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, true, false, true, true>), dim3(tiles), dim3(256), stream, a);
+        else if (!a.map_off && !a.track_off)
             launch_blend((render_bwd_light_kernel<ALPHA_REF, true, true, false, true>), dim3(tiles), dim3(256), stream, a);
+        else if (!a.map_off && halves)
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, false, false, true, true>), dim3(tiles), dim3(256), stream, a);
         else if (!a.map_off)
             launch_blend((render_bwd_light_kernel<ALPHA_REF, true, false, false, true>), dim3(tiles), dim3(256), stream, a);
         else if (halves)
@@ -588,8 +625,13 @@ void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t s
             launch_blend((render_bwd_light_kernel<ALPHA_REF, false, true, true>), dim3(tiles), dim3(256), stream, a);
         return;
     }
-    if (!a.map_off && !a.track_off)
+    constexpr int AMH = AM == ALPHA_GLIBC ? ALPHA_REF : AM;  // (never launched for the glibc form: see below)
+    if (!a.map_off && !a.track_off && halves && AM != ALPHA_GLIBC)
+        launch_blend((render_bwd_light_kernel<AMH, true, true, false, false, true>), dim3(tiles), dim3(256), stream, a);
+    else if (!a.map_off && !a.track_off)
         launch_blend((render_bwd_light_kernel<AM, true, true>), dim3(tiles), dim3(256), stream, a);
+    else if (!a.map_off && halves && AM != ALPHA_GLIBC)
+        launch_blend((render_bwd_light_kernel<AMH, true, false, false, false, true>), dim3(tiles), dim3(256), stream, a);
     else if (!a.map_off)
         launch_blend((render_bwd_light_kernel<AM, true, false>), dim3(tiles), dim3(256), stream, a);
     else if (halves && AM != ALPHA_GLIBC)  // (the glibc form, an A/B mode, spills a register with the eight lists)

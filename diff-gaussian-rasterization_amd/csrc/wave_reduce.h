@@ -50,7 +50,7 @@ __device__ __forceinline__ int wave_reduce12d_comp(int lane) {
 #define DGR_MERGE(d, s, ctrl, m0, m1) \
     "v_add_f32_dpp %" #d ", %" #d ", %" #d " " ctrl " row_mask:0xf bank_mask:" m0 "\n\t" \
     "v_add_f32_dpp %" #d ", %" #s ", %" #s " " ctrl " row_mask:0xf bank_mask:" m1 "\n\t"
-__device__ __forceinline__ float wave_reduce12d(float (&x)[12]) {
+__device__ __forceinline__ void wave_reduce12d_head(float (&x)[12], float& u0, float& u1) {
     // stage 1 (in place, span 16 -> 8 inside every row): lanes 0-7 of x[2k] <- x[2k], lanes 8-15 <- x[2k+1];
     // stage 2 (span 8 -> 4): banks {0, 2} of x[4m] <- x[4m] (values 4m, 4m+1), banks {1, 3} <- x[4m+2] (values 4m+2, 4m+3).
     // A DPP read needs its source written >= 2 instructions earlier: the order below guarantees it after the leading nop.
@@ -65,11 +65,30 @@ __device__ __forceinline__ float wave_reduce12d(float (&x)[12]) {
     // stage 3 (rows 0+1, 2+3): the swap exchanges the odd rows of its first operand with the even rows of its second
     float z0 = x[0], z1 = x[4], z2 = x[8], z3 = x[8];
     asm volatile("s_nop 1\n\t" DGR_SWAP16(0, 1) DGR_SWAP16(2, 3) : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
-    float u0 = z0 + z1;  // rows 0, 2: values 0..3 ; rows 1, 3: values 4..7
-    float u1 = z2 + z3;  // every row: values 8..11 (rows 0, 1: rows 0+1 ; rows 2, 3: rows 2+3)
-    // stage 4 (halves): afterwards u0 + u1 holds values 0..3 in row 0, 4..7 in row 1, 8..11 in rows 2 and 3
+    u0 = z0 + z1;  // rows 0, 2: values 0..3 ; rows 1, 3: values 4..7
+    u1 = z2 + z3;  // every row: values 8..11 (rows 0, 1: rows 0+1 ; rows 2, 3: rows 2+3)
+}
+// stage 4 (halves): afterwards u0 + u1 holds values 0..3 in row 0, 4..7 in row 1, 8..11 in rows 2 and 3
+__device__ __forceinline__ float wave_reduce12d_tail(float u0, float u1) {
     asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) : "+v"(u0), "+v"(u1));
     return quad_sum(u0 + u1);
+}
+__device__ __forceinline__ float wave_reduce12d(float (&x)[12]) {
+    float u0, u1;
+    wave_reduce12d_head(x, u0, u1);
+    return wave_reduce12d_tail(u0, u1);
+}
+// ... or, without stage 4, the twelve sums of each HALF of the wave on its own (the paired lists of the mapping backward: a
+// step that serves one entry on lanes 0-31 and another on lanes 32-63): r0 = quad_sum(u0) holds the half's values 0..3 in its
+// even row and 4..7 in its odd row, r1 = quad_sum(u1) its values 8..11 in both rows; quad b holds value {0, 2, 1, 3}[b].
+// The same additions as the full network up to its last stage -- which, for an entry that lives in one half, adds exact zeros.
+__device__ __forceinline__ int wave_reduce12d_half_slot0(int lane) {  // r0's value in this lane
+    const int b = (lane >> 2) & 3;
+    return 4 * ((lane >> 4) & 1) + ((b == 1) ? 2 : (b == 2) ? 1 : b);
+}
+__device__ __forceinline__ int wave_reduce12d_half_slot1(int lane) {  // r1's value in this lane (taken from the half's even row)
+    const int b = (lane >> 2) & 3;
+    return ((lane >> 4) & 1) ? -1 : 8 + ((b == 1) ? 2 : (b == 2) ? 1 : b);
 }
 
 // Sixteen values, within-row stages first: 16 -> 8 -> 4 registers with 24 DPP adds, two swaps + one swap across rows.
