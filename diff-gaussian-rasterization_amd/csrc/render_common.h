@@ -258,8 +258,9 @@ __device__ __forceinline__ int build_half_lists(S& s, unsigned code, int tid, in
 // halves is delivered twice, drown in them: DESIGN.md Appendix A).
 //   code8 : stage_tagged<AM, true>'s code (bit 2 w + h: half h of quadrant wave w)
 //   phase 1: the four compacted quadrant lists as in build_lists, entry = record offset | type (1 upper, 2 lower, 3 both);
-//   phase 2: every wave pairs its own list: ranks (2 m, 2 m + 1) first, then (2 m + 1, 2 m + 2) where neither was taken -- a
-//            window of five entries decides, no scan -- and writes the STEP lists in place: list[2 w] = what lanes 0-31 process at
+//   phase 2: every wave pairs its own list (of at most 64 entries: one rank per lane; longer lists stay unpaired): ranks
+//            (2 m, 2 m + 1) first, then (2 m + 1, 2 m + 2) where neither was taken -- a window of five entries, read through
+//            whole-wave DPP shifts, decides; no scan -- and writes the STEP lists in place: list[2 w] = what lanes 0-31 process at
 //            step s, list[2 w + 1] = what lanes 32-63 process (the same entry unless the step is a pair).  0.87 steps per entry.
 // Returns the number of steps (wave-uniform); split[c] bit b: step 64 c + b is a pair (the two halves hold different entries).
 template <class S>
@@ -321,50 +322,16 @@ __device__ __forceinline__ int build_paired_lists(S& s, unsigned code8, int tid,
         split[1] = 0ull;
         return steps;
     }
-    unsigned e[2];
-    bool first[2], second[2], have[2];
-    unsigned long long keep[2];  // ranks that open a step
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int r = lane + 64 * c;
-        auto type_at = [&](int q) -> unsigned { return (q >= 0 && q < n) ? (unsigned)(LU[q] & 3u) : 0u; };
-        have[c] = r < n;
-        e[c] = have[c] ? LU[r] : 0u;
-        const unsigned tm2 = type_at(r - 2), tm1 = type_at(r - 1), t0 = e[c] & 3u, tp1 = type_at(r + 1), tp2 = type_at(r + 2);
-        // (one entry upper-only, the other lower-only: 1 * 2)
-        const bool odd = (r & 1) != 0;
-        const bool a_self = odd ? (tm1 * t0 == 2u) : (t0 * tp1 == 2u);     // ranks (2 m, 2 m + 1) holding r
-        const bool a_side = odd ? (tp1 * tp2 == 2u) : (tm2 * tm1 == 2u);   // the aligned pair next to r's free side
-        const bool p2 = !a_self && !a_side && (odd ? (t0 * tp1 == 2u) : (tm1 * t0 == 2u));  // (r, r + 1) for odd r, (r - 1, r) for even
-        first[c] = odd ? p2 : a_self;
-        second[c] = odd ? a_self : p2;
-        keep[c] = __ballot(have[c] && !second[c]);
-    }
-    const int n0 = __popcll(keep[0]);
-    const int steps = n0 + __popcll(keep[1]);
-#pragma unroll
-    for (int c = 0; c < 2; c++) {  // (every read of the rank list above precedes these writes: one wave, program order)
-        if (have[c]) {
-            const int st = (c ? n0 : 0) + lanes_below(keep[c]) - (second[c] ? 1 : 0);
-            const LT o = e[c] & ~3u;
-            if (first[c] || second[c]) {
-                ((e[c] & 3u) == 1u ? LU : LL)[st] = o;
-            } else {
-                LU[st] = o;
-                LL[st] = o;
-            }
-        }
-    }
+    // more than 64 entries in one quadrant's list of a 128-position batch (big splats, which live in both halves anyway): unpaired
+    const LT ea = lane < n ? LU[lane] : 0u, eb = lane + 64 < n ? LU[lane + 64] : 0u;
+    if (lane < n) { LU[lane] = ea & ~3u; LL[lane] = ea & ~3u; }
+    if (lane + 64 < n) { LU[lane + 64] = eb & ~3u; LL[lane + 64] = eb & ~3u; }
     if (lane < 4) {
-        LU[steps + lane] = (LT)(S::SENTINEL * 32);
-        LL[steps + lane] = (LT)(S::SENTINEL * 32);
+        LU[n + lane] = (LT)(S::SENTINEL * 32);
+        LL[n + lane] = (LT)(S::SENTINEL * 32);
     }
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-        const int st = lane + 64 * c;
-        split[c] = __ballot(st < steps && LU[st] != LL[st]);
-    }
-    return steps;
+    split[0] = split[1] = 0ull;
+    return n;
 }
 
 // v_pk_*_f32 operands: gfx950 issues two fp32 operations per lane with one packed instruction

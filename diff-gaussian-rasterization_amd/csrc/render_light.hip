@@ -301,7 +301,6 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     // per-pixel constants of the loop: -T_final <bg, dL/dpixel> (the background term of dL/dalpha is this times
     // 1/(1 - alpha)) and 2 dL/dvar
     const float bg_term = -T_final * (a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2);
-    const float dvar2 = 2.f * dpix_var;
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     // The reference keeps five "accumulated behind me" recurrences (3 colours, depth, variance: backward.cu:580-608)
     // only to form dL/dalpha = sum_c (c_j - accum_rec_c) dL/dpixel_c.  They are linear, so one scalar suffices:
@@ -321,16 +320,6 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     } else {
         const int c = wave_reduce4_comp(lane);  // {4: gmx, 5: gmy, 13: pose depth}
         my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
-    }
-    // PAIRED, a step that serves two entries: byte offsets of the accumulator rows this lane delivers r0 / r1 to (-1: none)
-    int off0 = -1, off1 = -1;
-    if (PAIRED) {
-        auto comp_of = [](int slot) { return slot < 10 ? slot : slot == 10 ? (DO_POSE ? 13 : 10) : (DO_POSE ? 10 : -1); };
-        const int c0 = (lane & 3) == 0 ? comp_of(wave_reduce12d_half_slot0(lane)) : -1;
-        const int s1 = wave_reduce12d_half_slot1(lane);
-        const int c1 = ((lane & 3) == 0 && s1 >= 0) ? comp_of(s1) : -1;
-        off0 = c0 >= 0 ? c0 * BWD_LD * 4 : -1;
-        off1 = c1 >= 0 ? c1 * BWD_LD * 4 : -1;
     }
     const int my_list = HALVES ? 2 * wave + (lane >> 5) : wave;
     const uint8_t* const tag8 = HALVES ? half_tags(a.point_list, a.sched_flag) : nullptr;
@@ -357,11 +346,20 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
         const int rel_last4 = 4 * (last_contributor - lo);  // slots whose 4 * index is below this are at or before the last contributor
 
         // (the list is padded with sentinels to a multiple of 4, so a multiple of 2 is always readable)
-        for (int k = ((n + 1) & ~1) - 2; k >= 0; k -= 2) {
+        // PAIRED: one step per iteration -- the second step's records in flight cost eight registers that this kernel does not have
+        // (its lists' base is a per-lane value, the half-wave sums cross a branch); the other waves of the SIMD cover the LDS latency
+        constexpr int U = PAIRED ? 1 : 2;
+        for (int k = ((n + U - 1) / U) * U - U; k >= 0; k -= U) {
             float4 q0[2], q1[2];
-            load2(s, my_list, k, q0, q1);
+            if (U == 2) {
+                load2(s, my_list, k, q0, q1);
+            } else {
+                const unsigned off = s.list[my_list][k];
+                q0[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rec) + off);
+                q1[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rec) + off + 16);
+            }
 #pragma unroll
-            for (int u = 1; u >= 0; u--) {
+            for (int u = U - 1; u >= 0; u--) {
                 f2 dxy;
                 const float p2 = pair_p2<AM>(q0[u], q1[u], pxy, dxy);
                 const float dx = dxy.x, dy = dxy.y;
@@ -411,7 +409,7 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                     g[0] = w * dpix0;
                     g[1] = w * dpix1;
                     g[2] = w * dpix2;
-                    g[3] = LEAN ? wd : wd + (dvar2 * w) * e;
+                    g[3] = LEAN ? wd : wd + 2.f * ((dpix_var * w) * e);  // (2 dL/dvar: the factor is exact wherever it stands)
                     g[4] = qdx;        // sum q dx
                     g[5] = qdy;        // sum q dy
                     g[6] = qdx * dx;   // sum q dx^2
@@ -426,10 +424,15 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
                         const int st = k + u;  // (wave-uniform: scalar code)
                         if ((split[st >> 6] >> (st & 63)) & 1ull) {
                             // a pair: each half's own totals to its own entry's column (j4 is uniform in each half)
+                            // (the rows are worked out here, one step in nine, rather than kept in registers through the loop)
                             const float r0 = quad_sum(u0), r1 = quad_sum(u1);
+                            auto comp_of = [](int slot) { return slot < 10 ? slot : slot == 10 ? (DO_POSE ? 13 : 10) : (DO_POSE ? 10 : -1); };
+                            const int s1 = wave_reduce12d_half_slot1(lane);
+                            const int c0 = (lane & 3) == 0 ? comp_of(wave_reduce12d_half_slot0(lane)) : -1;
+                            const int c1 = ((lane & 3) == 0 && s1 >= 0) ? comp_of(s1) : -1;
                             char* const col = reinterpret_cast<char*>(sb.acc) + j4;
-                            if (off0 >= 0) atomicAdd(reinterpret_cast<float*>(col + off0), r0);
-                            if (off1 >= 0) atomicAdd(reinterpret_cast<float*>(col + off1), r1);
+                            if (c0 >= 0) atomicAdd(reinterpret_cast<float*>(col + c0 * (BWD_LD * 4)), r0);
+                            if (c1 >= 0) atomicAdd(reinterpret_cast<float*>(col + c1 * (BWD_LD * 4)), r1);
                             continue;
                         }
                         tot = wave_reduce12d_tail(u0, u1);
