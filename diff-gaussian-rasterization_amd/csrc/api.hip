@@ -1091,6 +1091,14 @@ int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* ou
     HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out12, out4, comp16, comp12, comp4, (hipStream_t)stream));
     return DGR_OK;
 }
+int dgr_debug_half_reduce(void* stream, const float* in, float* r0, float* r1, float* h3, int* slot0, int* slot1, int* comp3) {
+    HIP_TRY(dgr::launch_half_reduce_test(in, r0, r1, h3, slot0, slot1, comp3, (hipStream_t)stream));
+    return DGR_OK;
+}
+int dgr_debug_lane_lists(void* stream, const unsigned char* codes, unsigned* paired, unsigned* halves) {
+    HIP_TRY(dgr::launch_lane_lists_test(codes, paired, halves, (hipStream_t)stream));
+    return DGR_OK;
+}
 int dgr_debug_exact_math(void* stream, int n, const float* x, const float* a, const float* b, float* out_exp, float* out_div) {
     if (n < 0 || (n > 0 && (!x || !a || !b || !out_exp || !out_div))) {
         g_last_error = "dgr_debug_exact_math: bad argument";

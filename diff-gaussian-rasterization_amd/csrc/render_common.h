@@ -117,7 +117,8 @@ __device__ __forceinline__ unsigned stage_one(S& s, int slot, uint32_t gid, cons
     float lthr = (o > 0.f) ? (-l2 * (AlphaPath<AM>::LOG2 ? 1.0f : LN2) - 1.0e-4f) : 3.0e38f;
     float zword = __int_as_float(slot);
     if (HALF_CODES) {
-        // The slot rides in the low 8 bits of the threshold (a margin of another 1e-4 covers the 255 ulp that moves it: |lthr| < 8)
+        // The slot rides in the low 8 bits of the threshold: that moves it by at most 255 ulp -- 6.1e-5 below |lthr| = 4, 1.3e-4 up to
+        // 4.1 (the log2 form at opacity 1), its largest magnitude -- inside the 2e-4 of margin it now has (the exact test decides)
         // and the record's third word becomes four spare BYTES: byte w = "some pixel of the LOWER half of quadrant wave w blended
         // this instance" (the upper halves' bytes are the kernel's `hit` words) -- contribution tags per half, free of LDS.
         lthr = __int_as_float((__float_as_int(lthr - 1.0e-4f) & ~0xFF) | slot);

@@ -199,6 +199,11 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
 // global atomics (16 consecutive lanes = one Gaussian's 64-byte accumulator row).  Global float atomics
 // drop from 14 per valid (pixel, Gaussian) pair to <= 14 per (tile, Gaussian).
 // Tracking mode (map_off) needs only the three sums the pose gradient is built from: a 4-value butterfly.
+// (Twelve values since round 3 -- raw moments, the median term as the twelfth -- in accumulator rows 0..10 and 13.)
+// Round 8: a Gaussian reaches 16 of a quadrant's 64 pixels on average and more than half of the (quadrant, Gaussian) entries
+// live in ONE half of the quadrant.  The forward tags what it blended per half (render_common.h: half_tags); from those tags
+// the tracking kernel walks one list per half-wave like the forward, and the mapping kernel pairs neighbouring entries of its
+// list that live in different halves into one loop step (build_paired_lists) -- see the HALVES note above the kernel.
 constexpr int NACC_LIGHT = 14;
 
 // list positions staged per batch (256: 5 workgroups per CU, 267 us; 128: 247 us).  The deterministic kernel (DET, below) keeps one
@@ -578,6 +583,51 @@ __global__ void __launch_bounds__(64) wave_reduce_test_kernel(const float* in, f
     comp4[lane] = wave_reduce4_comp(lane);
 }
 
+// self-test of the reductions per HALF of the wave (wave_reduce.h): in[c * 64 + lane], twelve values for the paired step of the
+// mapping backward (r0, r1 and the butterfly slot each lane holds), the first three for the tracking backward's half_reduce3
+__global__ void __launch_bounds__(64) half_reduce_test_kernel(const float* in, float* r0, float* r1, float* h3, int* slot0, int* slot1,
+                                                             int* comp3) {
+    const int lane = threadIdx.x;
+    float g[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) g[k] = in[k * 64 + lane];
+    h3[lane] = half_reduce3(g[0], g[1], g[2]);
+    float u0, u1;
+    wave_reduce12d_head(g, u0, u1);
+    r0[lane] = quad_sum(u0);
+    r1[lane] = quad_sum(u1);
+    slot0[lane] = wave_reduce12d_half_slot0(lane);
+    slot1[lane] = wave_reduce12d_half_slot1(lane);
+    comp3[lane] = half_reduce3_comp(lane);
+}
+
+// self-test of the list builders of render_common.h on one batch of 128 staged slots: codes[slot] = the eight bits "half h of
+// quadrant wave w" (bit 2 w + h).  paired[w] / halves[w] (280 words each) = {steps or length, split[0] lo, hi, split[1] lo, hi,
+// list 2 w [0..135], list 2 w + 1 [0..135]} as wave w leaves them (dgr_debug_lane_lists).
+__global__ void __launch_bounds__(256) lane_lists_test_kernel(const unsigned char* codes, uint32_t* paired, uint32_t* halves) {
+    typedef StagedT<128, uint32_t, 8> S;
+    __shared__ S s;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned code = tid < 128 ? codes[tid] : 0u;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = tid; i < 8 * S::LIST_LD; i += 256) (&s.list[0][0])[i] = 0xFFFFFFFFu;
+        __syncthreads();
+        unsigned long long split[2] = {0ull, 0ull};
+        const int n = pass == 0 ? build_paired_lists(s, code, tid, wave, lane, split) : build_half_lists(s, code, tid, wave, lane);
+        uint32_t* const o = (pass == 0 ? paired : halves) + 280 * wave;
+        if (lane == 0) {
+            o[0] = (uint32_t)n;
+            o[1] = (uint32_t)split[0]; o[2] = (uint32_t)(split[0] >> 32);
+            o[3] = (uint32_t)split[1]; o[4] = (uint32_t)(split[1] >> 32);
+        }
+        for (int i = lane; i < S::LIST_LD; i += 64) {
+            o[5 + i] = s.list[2 * wave][i];
+            o[5 + S::LIST_LD + i] = s.list[2 * wave + 1][i];
+        }
+        __syncthreads();
+    }
+}
+
 // self-test of exact_math.h: out_exp[i] = exp_p32(x[i]) (GLIBC: exp_glibc), out_div[i] = div_ref(a[i], b[i]) (dgr_debug_exact_math)
 template <bool GLIBC>
 __global__ void __launch_bounds__(256) exact_math_test_kernel(int n, const float* x, const float* a, const float* b, float* out_exp,
@@ -693,6 +743,15 @@ hipError_t launch_exact_math_test(int n, const float* x, const float* a, const f
 hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12, int* comp4,
                                    hipStream_t stream) {
     launch(wave_reduce_test_kernel, dim3(1), dim3(64), stream, in, out16, out12, out4, comp16, comp12, comp4);
+    return hipGetLastError();
+}
+
+hipError_t launch_half_reduce_test(const float* in, float* r0, float* r1, float* h3, int* slot0, int* slot1, int* comp3, hipStream_t stream) {
+    launch(half_reduce_test_kernel, dim3(1), dim3(64), stream, in, r0, r1, h3, slot0, slot1, comp3);
+    return hipGetLastError();
+}
+hipError_t launch_lane_lists_test(const unsigned char* codes, uint32_t* paired, uint32_t* halves, hipStream_t stream) {
+    launch(lane_lists_test_kernel, dim3(1), dim3(256), stream, codes, paired, halves);
     return hipGetLastError();
 }
 

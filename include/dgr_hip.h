@@ -391,6 +391,17 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
  * first 12 / 4 values), comp16 / comp12 / comp4 [lane] the index of the value that lane's total belongs to.  64 entries each. */
 int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12,
                           int* comp4);
+/* Self-test of the reductions per HALF of a wave (csrc/wave_reduce.h), which the blend backward uses where a loop step serves one
+ * list entry on lanes 0-31 and another on lanes 32-63.  `in` holds 12 values per lane as in[c * 64 + lane].  r0 / r1 [lane]: what
+ * the lane holds after the twelve-value network stopped before its cross-half stage, slot0 / slot1 [lane] the index of the value
+ * that total belongs to (-1: none); h3 [lane]: after the three-value network of the tracking backward (the first three values),
+ * comp3 [lane] the value index (-1: none).  64 entries each. */
+int dgr_debug_half_reduce(void* stream, const float* in, float* r0, float* r1, float* h3, int* slot0, int* slot1, int* comp3);
+/* Self-test of the per-wave list builders of the blend kernels (csrc/render_common.h: build_paired_lists, build_half_lists) on one
+ * batch of 128 staged slots.  codes[slot] (128 device bytes): bit 2 w + h set <=> half h (lanes 32 h ..) of quadrant wave w takes
+ * the slot.  paired / halves (4 x 280 device words, one block per wave): {steps or length, split mask 0 lo, hi, split mask 1 lo,
+ * hi, list 2 w [136], list 2 w + 1 [136]}; list entries are record offsets (32 x slot), 32 x 128 = the sentinel. */
+int dgr_debug_lane_lists(void* stream, const unsigned char* codes, unsigned* paired, unsigned* halves);
 /* Self-test of csrc/exact_math.h, the arithmetic behind the default alpha path: out_exp[i] = the current alpha mode's expf of
  * x[i] (mode 0: exp_p32, mode 2: exp_glibc; x <= 0, clamped at -104) and out_div[i] = div_ref(a[i], b[i]) -- correctly rounded
  * a / b for normal operands.  n device floats each.  tests/test_hip_exact_math.py compares both with the CPU restatement's
