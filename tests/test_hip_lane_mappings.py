@@ -1,0 +1,70 @@
+"""The blend kernels' lane mappings and alpha modes in their combinations, end to end against the oracle.
+
+Round 8's default: the forward walks one list per half-wave and tags what it blended per half of a quadrant; the tracking backward
+walks half-wave lists from those tags, the mapping backward pairs list entries by them.  Two combinations do not get the default
+backward and are not reached by the other parity tests:
+  * alpha_mode 2 (glibc's expf in the double pipe, kept for A/B): half-wave forward, but a backward with one list per quadrant
+    wave from the 4-bit tags (the half-wave forms spill a register there) -- held against the oracle in ITS exp mode 1;
+  * DGR_FWD_HALVES=0 (rounds 1-7's mapping in forward and backward) is a per-process switch: covered by the soak
+    (profiles/r8/soak_final.txt), here only through a child process on one scene.
+Every mode of the backward (mapping + tracking, mapping only, tracking only) at the bars of tests/test_hip_light_parity.py:
+threshold-carrying images bit for bit, gradients at 1e-5 of scale with no outlier rows."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from util import make_scene
+import hip_helpers as hh
+from test_hip_light_parity import assert_images_carry_the_references_bits, check_backward
+
+pytestmark = pytest.mark.gpu
+MODES = [dict(), dict(map_off=True), dict(track_off=True)]
+
+
+@pytest.fixture
+def glibc_alpha(oracle):
+    from dgr_amd import _capi
+    _capi.load()
+    _capi.set_option("alpha_mode", 2)
+    oracle.set_exp_mode(1)
+    yield
+    oracle.set_exp_mode(0)
+    _capi.set_option("alpha_mode", 0)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("case", [(10000, 256, 256, 3, 0), (100000, 640, 480, 3, 0)])
+def test_glibc_alpha_with_the_half_wave_forward(oracle, glibc_alpha, case, mode):
+    P, W, H, deg, seed = case
+    s = make_scene(P, W, H, seed)
+    d, st, ref = check_backward(oracle, s, deg, what=f"glibc alpha P={P}", **mode)
+    assert_images_carry_the_references_bits(d, st, ref, s)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_heavy_tailed_scene_in_every_backward_mode(oracle, mode):
+    """Big splats: lists of more than 64 entries per quadrant and batch (the mapping backward leaves those unpaired), entries that
+    live in both halves everywhere."""
+    from dgr_amd.synth import heavy_tail_scene
+    s = heavy_tail_scene(make_scene(30000, 640, 480, 4), frac=0.05, sigma_px=(10, 200), seed=9)
+    check_backward(oracle, s, 2, what="heavy tail, lane mappings", **mode)
+
+
+def test_the_old_lane_mapping_in_a_child_process():
+    """DGR_FWD_HALVES=0 is read once per process: one scene, all three backward modes, in a child."""
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import conftest  # (puts the package and the oracle on sys.path)\n"
+            "from oracle import oracle as o\n"
+            "from util import make_scene\n"
+            "from test_hip_light_parity import check_backward, assert_images_carry_the_references_bits\n"
+            "o.build()\n"
+            "s = make_scene(20000, 320, 200, 3)\n"
+            "for m in (dict(), dict(map_off=True), dict(track_off=True)):\n"
+            "    d, st, ref = check_backward(o, s, 3, what='old lane mapping', **m)\n"
+            "assert_images_carry_the_references_bits(d, st, ref, s)\n"
+            "print('old mapping ok')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, DGR_FWD_HALVES="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "old mapping ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
