@@ -117,11 +117,12 @@ __device__ __forceinline__ unsigned stage_one(S& s, int slot, uint32_t gid, cons
     float lthr = (o > 0.f) ? (-l2 * (AlphaPath<AM>::LOG2 ? 1.0f : LN2) - 1.0e-4f) : 3.0e38f;
     float zword = __int_as_float(slot);
     if (HALF_CODES) {
-        // The slot rides in the low 8 bits of the threshold: that moves it by at most 255 ulp -- 6.1e-5 below |lthr| = 4, 1.3e-4 up to
-        // 4.1 (the log2 form at opacity 1), its largest magnitude -- inside the 2e-4 of margin it now has (the exact test decides)
+        // The slot rides in the low 8 bits of the threshold, which is first rounded AWAY from zero to a multiple of 256 ulp: a negative
+        // threshold (the only kind anything can pass: p2 <= 0) gets at most 511 ulp more permissive, whatever its magnitude -- a few
+        // more pairs reach the exact test, which decides as before --
         // and the record's third word becomes four spare BYTES: byte w = "some pixel of the LOWER half of quadrant wave w blended
         // this instance" (the upper halves' bytes are the kernel's `hit` words) -- contribution tags per half, free of LDS.
-        lthr = __int_as_float((__float_as_int(lthr - 1.0e-4f) & ~0xFF) | slot);
+        lthr = __int_as_float(((__float_as_int(lthr) + 0xFF) & ~0xFF) | slot);
         zword = 0.f;
     }
     s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
