@@ -234,17 +234,25 @@ __device__ __forceinline__ int build_half_lists(S& s, unsigned code, int tid, in
         if (lane == 0) s.cnt4[wave][l] = __popcll(bal[l]);
     }
     __syncthreads();
+    // lane l < 8 adds up list l's counts ONCE -- those of the staging waves in front of this one (the wave's base in the list) and
+    // all four (the list's length) -- and every use below takes its list's numbers with one v_readlane: the per-list reads of the
+    // count table cost the staging of a big-splat scene (every instance in all eight lists) a tenth of the forward's instructions
+    int before = 0, all = 0;
+    if (lane < 8) {
 #pragma unroll
-    for (int l = 0; l < 8; l++) {
-        if ((code >> l) & 1u) {
-            int base = 0;
-            for (int sw = 0; sw < wave; sw++) base += s.cnt4[sw][l];
-            s.list[l][base + lanes_below(bal[l])] = (LT)(tid * 32);
+        for (int sw = 0; sw < 4; sw++) {
+            const int c = s.cnt4[sw][lane];
+            before += sw < wave ? c : 0;
+            all += c;
         }
     }
+#pragma unroll
+    for (int l = 0; l < 8; l++) {
+        const int base = __builtin_amdgcn_readlane(before, l);
+        if ((code >> l) & 1u) s.list[l][base + lanes_below(bal[l])] = (LT)(tid * 32);
+    }
     const int l0 = 2 * wave;
-    const int n0 = __builtin_amdgcn_readfirstlane(s.cnt4[0][l0] + s.cnt4[1][l0] + s.cnt4[2][l0] + s.cnt4[3][l0]);
-    const int n1 = __builtin_amdgcn_readfirstlane(s.cnt4[0][l0 + 1] + s.cnt4[1][l0 + 1] + s.cnt4[2][l0 + 1] + s.cnt4[3][l0 + 1]);
+    const int n0 = __builtin_amdgcn_readlane(all, l0), n1 = __builtin_amdgcn_readlane(all, l0 + 1);
     __syncthreads();
     const int n = max(n0, n1);
     for (int i = n0 + lane; i < n + 4; i += 64) s.list[l0][i] = (LT)(S::SENTINEL * 32);      // own lists, own wave: program order
@@ -276,16 +284,22 @@ __device__ __forceinline__ int build_paired_lists(S& s, unsigned code8, int tid,
         if (lane == 0) s.cnt4[wave][w] = __popcll(bal[w]);
     }
     __syncthreads();
+    int before = 0, all = 0;  // lane w < 4: list w's entries from the staging waves in front of this one / from all four (build_half_lists)
+    if (lane < 4) {
+#pragma unroll
+        for (int sw = 0; sw < 4; sw++) {
+            const int c = s.cnt4[sw][lane];
+            before += sw < wave ? c : 0;
+            all += c;
+        }
+    }
 #pragma unroll
     for (int w = 0; w < 4; w++) {
         const unsigned t = (code8 >> (2 * w)) & 3u;
-        if (t != 0u) {
-            int base = 0;
-            for (int sw = 0; sw < wave; sw++) base += s.cnt4[sw][w];
-            s.list[2 * w][base + lanes_below(bal[w])] = (LT)(tid * 32) | t;
-        }
+        const int base = __builtin_amdgcn_readlane(before, w);
+        if (t != 0u) s.list[2 * w][base + lanes_below(bal[w])] = (LT)(tid * 32) | t;
     }
-    const int n = __builtin_amdgcn_readfirstlane(s.cnt4[0][wave] + s.cnt4[1][wave] + s.cnt4[2][wave] + s.cnt4[3][wave]);
+    const int n = __builtin_amdgcn_readlane(all, wave);
     __syncthreads();
     LT* const LU = s.list[2 * wave];
     LT* const LL = s.list[2 * wave + 1];
