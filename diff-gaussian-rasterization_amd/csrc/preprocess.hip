@@ -996,8 +996,12 @@ __global__ void __launch_bounds__(256, DGR_PPB_WAVES) preprocess_bwd_kernel(Prep
         const int rad = a.radii[idx];
 
         const float3 m = make_float3(a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]);
-        float c3[6];
-        {
+        // A tracking step (map_off: the pose gradient only) needs the three sums, the mean and the radius: the covariance, the
+        // scale / rotation, the clamp bits and the SH direction derivatives -- 77 of the 157 bytes a Gaussian costs this kernel --
+        // feed only the per-Gaussian gradients.  The test is kernel-uniform and known at launch: no load waits for another.
+        const bool need_map = !a.map_off;
+        float c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (need_map) {
             if (a.cov3D_precomp) {
                 const float* c3p = a.cov3D_precomp + 6 * (size_t)idx;
 #pragma unroll
@@ -1008,12 +1012,16 @@ __global__ void __launch_bounds__(256, DGR_PPB_WAVES) preprocess_bwd_kernel(Prep
         }
         float3 sc_in = make_float3(0.f, 0.f, 0.f);
         float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.scales) {
+        if (need_map && a.scales) {
             sc_in = make_float3(a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]);
             q_in = make_float4(a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2], a.rotations[4 * idx + 3]);
         }
-        const uint8_t cl_in = a.geom.clamped[idx];
-        const float4 shd0 = a.geom.shd[idx], shd1 = a.geom.shd[(size_t)a.P + idx], shd2 = a.geom.shd[2 * (size_t)a.P + idx];
+        uint8_t cl_in = 0;
+        float4 shd0 = make_float4(0.f, 0.f, 0.f, 0.f), shd1 = shd0, shd2 = shd0;
+        if (need_map) {
+            cl_in = a.geom.clamped[idx];
+            shd0 = a.geom.shd[idx]; shd1 = a.geom.shd[(size_t)a.P + idx]; shd2 = a.geom.shd[2 * (size_t)a.P + idx];
+        }
         const bool vis = rad > 0;
         float acc[16];
         if (vis) {
