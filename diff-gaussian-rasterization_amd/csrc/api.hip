@@ -149,7 +149,7 @@ thread_local long g_armed_slot = -1;
 // forward later.  Forwards without a report (callback path, batched entry points, hipGraph capture, direct C-ABI callers that
 // never arm) keep the schedule.  Results do not depend on it: only the order in which tiles are worked on.
 std::atomic<int> g_tile_schedule{[] { const char* e = getenv("DGR_TILE_SCHEDULE"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }()};
-struct SchedHint { int device, W, H, P, on; };
+struct SchedHint { int device, W, H, P, on, longest; };
 std::vector<SchedHint> g_sched_hints;  // (under g_status_mu)
 bool want_schedule(int W, int H, int P) {
     const int mode = g_tile_schedule.load(std::memory_order_relaxed);
@@ -161,15 +161,27 @@ bool want_schedule(int W, int H, int P) {
         if (h.device == dev && h.W == W && h.H == H && h.P == P) return h.on != 0;
     return true;
 }
+// The same report also sizes the binning's row segments (segment_binning.hip: segment_shift): the longest tile list of this shape's
+// last reported frame, or -1 without one.  On a clustered frame the capacity alone says "16 tiles per segment" (the AVERAGE
+// segment fits bin_tiles' LDS) while every segment of the cluster overflows it and takes the dense path.
+int hinted_longest_list(int W, int H, int P) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    for (const auto& h : g_sched_hints)
+        if (h.device == dev && h.W == W && h.H == H && h.P == P) return h.longest;
+    return -1;
+}
 void note_schedule_hint(const StatusSlot& sl, const int* word) {  // (g_status_mu held)
     const long tiles = (long)dgr::tiles_x(sl.W) * dgr::tiles_y(sl.H);
     if (tiles <= 0 || word[1] /* overflow: the lists were left empty */) return;
     const long longest = word[5];
     const int on = (longest >= 0x7fffffff || longest * tiles > 2L * word[0] + 32L * tiles) ? 1 : 0;
+    const int lg = longest >= 0x7fffffff ? -1 : (int)longest;
     for (auto& h : g_sched_hints)
-        if (h.device == sl.device && h.W == sl.W && h.H == sl.H && h.P == sl.P) { h.on = on; return; }
+        if (h.device == sl.device && h.W == sl.W && h.H == sl.H && h.P == sl.P) { h.on = on; h.longest = lg; return; }
     if (g_sched_hints.size() >= 64) g_sched_hints.erase(g_sched_hints.begin());
-    g_sched_hints.push_back(SchedHint{sl.device, sl.W, sl.H, sl.P, on});
+    g_sched_hints.push_back(SchedHint{sl.device, sl.W, sl.H, sl.P, on, lg});
 }
 
 // The armed slot of this thread, taken by a presized forward.  If the call leaves before its binning kernel is enqueued
@@ -375,7 +387,8 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
     if (mode == COUNT_LDS || mode == COUNT_LDS_CALLBACK) {
         const bool cb = mode == COUNT_LDS_CALLBACK;
         const dgr::SegmentTables tb = dgr::carve_segment_tables(binning_base + bin.bytes, c.W, c.H);
-        const int ss = dgr::segment_shift(c.W, c.H, capacity);
+        const int longest = (armed && armed->id >= 0) ? hinted_longest_list(c.W, c.H, c.P) : -1;
+        const int ss = dgr::segment_shift(c.W, c.H, capacity, longest);
         { ScopedStage t(ST_BIN_SEGMENTS, st); HIP_TRY(dgr::launch_bin_segments(c.P, geom, bin, tb, gx, gy, ss, capacity, cb, st)); }
         { ScopedStage t(ST_BIN_TILES, st); HIP_TRY(dgr::launch_bin_tiles(c.P, geom, img, bin, tb, gx, gy, ss, capacity, cb, sched_on, rep, st)); }
         if (!cb) { const int rc = early_status_post(img.status, st); if (rc) return rc; }  // (bin_tiles writes the status word)
@@ -1086,6 +1099,10 @@ int dgr_cov3d_backward(void* stream, int P, const float* scales, const float* ro
     return DGR_OK;
 }
 
+int dgr_debug_bin_tiles_trace(unsigned long long* device_words) {
+    dgr::g_bin_tiles_trace = device_words;
+    return DGR_OK;
+}
 int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12,
                           int* comp4) {
     HIP_TRY(dgr::launch_wave_reduce_test(in, out16, out12, out4, comp16, comp12, comp4, (hipStream_t)stream));

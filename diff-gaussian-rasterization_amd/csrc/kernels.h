@@ -285,9 +285,10 @@ hipError_t launch_emit_instances(int P, GeometryView geom, ImageView img, Binnin
 // (callback path, after scan_blocks)
 bool segment_binning_fits(int W, int H);
 int segment_binning_workgroups(int P);
-int segment_shift(int W, int H, int capacity);  // log2 of the tiles per segment (4, 3 or 2) for this frame and capacity
+int segment_shift(int W, int H, int capacity, int longest_list = -1);  // log2 of the tiles per segment (4, 3 or 2) for this frame, capacity and (if known) longest list
 hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, SegmentTables tb, int grid_x, int grid_y, int seg_shift,
                                int capacity, bool prefixed, hipStream_t stream);
+extern unsigned long long* g_bin_tiles_trace;  // debug: phase time stamps per bin_tiles workgroup (segment_binning.hip)
 hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
                             int seg_shift, int capacity, bool prefixed, bool sched_on, StatusReport rep, hipStream_t stream);
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);

@@ -302,45 +302,44 @@ __device__ __forceinline__ void for_each_pair(const K2Shared& sh, int nwg, uint3
     }
 }
 
-// LONG_LISTS (chosen per launch from the expected list length): lists of 513 .. 1024 entries are the rule, not the exception
-template <bool LONG_LISTS>
+// One wave, one tile list of up to REG_SORT_MAX entries (tile_sort.h).  (Round 8 gave frames of long lists -- LONG_LISTS, chosen per
+// launch from the expected list length -- a network on the full 64-bit keys, because the 32-bit one needed a four-part rank merge
+// above 512 entries; round 9's takes 1024 in one pass and is the faster of the two there as well: bin_tiles 131 -> 82 us at config 4,
+// 103 -> 67 on the heavy-tailed scene, profiles/r9/bin_tiles_ab.txt.)  Inlined at its three call sites (236 registers spilled around
+// them in all): as a real call -- 45 spilled -- the kernel was a third slower everywhere (synth-v1 25.5 -> 34.3 us, config 4 82 -> 104).
 __device__ __forceinline__ void sort_tile_in_wave(uint64_t* src, int n, uint32_t* dst, int lane) {
-    if (LONG_LISTS) {
-        if (n <= 64) sort_wave_regs<1>(src, n, dst, lane);
-        else if (n <= 128) sort_wave_regs<2>(src, n, dst, lane);
-        else if (n <= 256) sort_wave_regs<4>(src, n, dst, lane);
-        else if (n <= 512) sort_wave_regs<8>(src, n, dst, lane);
-        else sort_wave_regs<16>(src, n, dst, lane);
-    } else {
-        if (n <= 64) sort_wave_trunc<1>(src, n, dst, lane);
-        else if (n <= 128) sort_wave_trunc<2>(src, n, dst, lane);
-        else if (n <= 256) sort_wave_trunc<4>(src, n, dst, lane);
-        else if (n <= 512) sort_wave_trunc<8>(src, n, dst, lane);
-        else sort_wave_trunc_1024(src, n, dst, lane);
-    }
+    if (n <= 64) sort_wave_trunc<1>(src, n, dst, lane);
+    else if (n <= 128) sort_wave_trunc<2>(src, n, dst, lane);
+    else if (n <= 256) sort_wave_trunc<4>(src, n, dst, lane);
+    else if (n <= 512) sort_wave_trunc<8>(src, n, dst, lane);
+    else sort_wave_trunc<16>(src, n, dst, lane);
 }
 
 // (xcd_contiguous, dgr_common.h: XCD x gets a contiguous run of segments)
-template <bool LONG_LISTS>
 __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img, uint32_t* __restrict__ point_list,
                                                                   uint64_t* __restrict__ key_scratch, SegmentTables tb,
                                                                   const uint64_t* __restrict__ pair_keys,
                                                                   const uint8_t* __restrict__ pair_cov,
                                                                   const uint32_t* __restrict__ block_tiles, int nblocks, int nwg,
                                                                   int grid_x, int grid_y, int seg_shift, int capacity, int prefixed,
-                                                                  int sched_on, StatusReport rep) {
+                                                                  int sched_on, StatusReport rep, int xp_map, unsigned long long* trace) {
     __shared__ K2Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int SEG = 1 << seg_shift;
     const int sgx = (grid_x + SEG - 1) >> seg_shift;
     const int nseg = grid_y * sgx;
+    // debug trace (dgr_debug_bin_tiles_trace): eight words per workgroup, phase time stamps at 100 MHz
+    auto stamp = [&](int k) { if (trace && tid == 0) trace[(size_t)blockIdx.x * 8 + k] = wall_clock64(); };
+    auto note = [&](int k, unsigned long long v) { if (trace && tid == 0) trace[(size_t)blockIdx.x * 8 + k] = v; };
+    stamp(0);
     // Workgroups 0 .. nseg-1 take a segment each.  Behind them come SEG / 4 - 1 HELPERS per segment, one per further group of
     // four tiles: a helper leaves at once unless its segment is DENSE (more keys than LDS or more pairs than the registers
     // hold), in which case the segment's tiles are shared out four to a workgroup instead of being taken in turn by one --
     // on a clustered frame the dense segments are few and everything else has long finished (profiles/r6/clustered.txt).
     const int helpers = (SEG >> 2) - 1;
     const int part = (int)blockIdx.x < nseg ? 0 : 1 + ((int)blockIdx.x - nseg) % max(helpers, 1);
-    const int s = xcd_contiguous((int)blockIdx.x < nseg ? (int)blockIdx.x : ((int)blockIdx.x - nseg) / max(helpers, 1), nseg);
+    const int s_lin = (int)blockIdx.x < nseg ? (int)blockIdx.x : ((int)blockIdx.x - nseg) / max(helpers, 1);
+    const int s = xp_map ? xcd_contiguous(s_lin, nseg) : s_lin;
     const int ty = s / sgx, sx = s - ty * sgx;
     const int ntl = min(SEG, grid_x - sx * SEG);             // tiles of this segment (the last one of a row may be short)
     const int tile0 = ty * grid_x + sx * SEG;
@@ -388,6 +387,8 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
         return;
     }
     const uint32_t n_pairs = block_scan<K2_THREADS>(sh.run_start, nwg + 1, false, sh.wsum, tid);  // run_start[w] = pairs of the runs < w
+    stamp(1);
+    note(6, (unsigned long long)gcount | ((unsigned long long)n_pairs << 32));
     const bool in_regs = n_pairs <= (uint32_t)(K2_PPT * K2_THREADS);
     const bool dense = !in_regs || gcount > (uint32_t)K2_CAP;
     if (part > 0 && !dense) return;
@@ -423,6 +424,7 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
         });
     }
     __syncthreads();  // (also: every thread is done with sh.src, which shares its bytes with sh.keys)
+    stamp(2);
     if (wave == 0) {
         const uint32_t c = (lane < SEG_MAX) ? sh.tcnt[lane] : 0u;
         uint32_t incl = c;
@@ -436,13 +438,10 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     }
     __syncthreads();
     // General sorter (dense segments, and segments with a list above REG_SORT_MAX): the lists of tiles [ta, tb_) lie in sh.keys
-    // from offset tbase[ta] on.  Lists up to WAVE_MAX entries are dealt to the waves round-robin (tile_sort.h: one wave's
+    // from offset tbase[ta] on.  Lists up to REG_SORT_MAX entries are dealt to the waves round-robin (tile_sort.h: one wave's
     // registers); longer ones are cut into parts of 512, the parts dealt to the waves as well, and every list is then merged
-    // by rank with all threads searching.  WAVE_MAX is 512 here although a wave can take 1024: a workgroup that comes here has
-    // four to six lists for its eight waves, and a single wave's 32-bit network needs a four-part rank merge above 512 entries
-    // (~40 us of dependent LDS reads against ~7 for the workgroup).  Where every wave has a list of its own -- the rule below,
-    // e.g. config 5's 510 +- 20 % entries per tile -- the waves keep whole lists up to REG_SORT_MAX.
-    constexpr int WAVE_MAX = LONG_LISTS ? REG_SORT_MAX : 512;
+    // by rank with all threads searching.
+    constexpr int WAVE_MAX = REG_SORT_MAX;
     auto sort_lists = [&](int ta, int tb_) {
         const uint32_t gb = sh.tbase[ta];
         int w = 0;
@@ -452,7 +451,7 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
             if (n == 0) continue;
             uint64_t* list = sh.keys + (sh.tbase[t] - gb);
             if (n <= WAVE_MAX) {
-                if ((w++ % K2_WAVES) == wave) sort_tile_in_wave<LONG_LISTS>(list, n, point_list + before + sh.tbase[t], lane);
+                if ((w++ % K2_WAVES) == wave) sort_tile_in_wave(list, n, point_list + before + sh.tbase[t], lane);
             } else {
                 for (int p = 0; p < list_parts(n); p++)
                     if ((w++ % K2_WAVES) == wave) sort_list_part(list, n, p, lane);
@@ -483,17 +482,22 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
             if (pc[k] != 0xffffffffu)
                 for (uint32_t x = pc[k] & 15u; x <= (pc[k] >> 4); x++) sh.keys[sh.tbase[x] + atomicAdd(&sh.tfill[x], 1u)] = pk[k];
         __syncthreads();
+        stamp(3);
+        note(7, (unsigned long long)tmax | ((unsigned long long)s << 32));
         if (tmax <= (uint32_t)REG_SORT_MAX) {
             // ---- the rule: every wave sorts whole tile lists in its registers and writes the ids
             for (int t = wave; t < ntl; t += K2_WAVES) {
                 const int n = (int)sh.tcnt[t];
-                if (n > 0) sort_tile_in_wave<LONG_LISTS>(sh.keys + sh.tbase[t], n, point_list + before + sh.tbase[t], lane);
+                if (n > 0) sort_tile_in_wave(sh.keys + sh.tbase[t], n, point_list + before + sh.tbase[t], lane);
             }
+            if (trace) { __syncthreads(); stamp(4); }
             return;
         }
         sort_lists(0, ntl);
+        if (trace) { __syncthreads(); stamp(4); }
         return;
     }
+    note(7, (unsigned long long)tmax | ((unsigned long long)s << 32) | (1ull << 63));
     // ---- dense segment: this workgroup's four tiles (the whole segment where it has no helpers), in consecutive GROUPS
     // whose keys fit LDS together.  Per group ONE pass over the pairs (re-read from the pair array: held in registers across
     // the sorts they would spill) places the keys; a single list above K2_CAP entries is sorted in place in the `keys`
@@ -530,12 +534,16 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
             }
         });
         __syncthreads();
+        stamp(3);
         sort_lists(t0, t1);
         t0 = t1;
     }
+    if (trace) { __syncthreads(); stamp(4); }
 }
 
 }  // namespace
+
+unsigned long long* g_bin_tiles_trace = nullptr;  // (dgr_debug_bin_tiles_trace)
 
 // the segment tables must fit one workgroup's LDS in bin_segments (16 bytes per segment, at the smallest segment size)
 bool segment_binning_fits(int W, int H) {
@@ -548,16 +556,26 @@ bool segment_binning_fits(int W, int H) {
 // `capacity` is what the caller expects to render (the lazy bindings size it 1.5x above the largest count seen, the
 // callback path passes the exact count): segments are sized so that capacity / tiles * segment <= 1.5 K2_CAP, i.e. an
 // average segment fills at most two thirds (lazy) or all (exact) of the budget; denser segments take the per-tile path.
-int segment_shift(int W, int H, int capacity) {
+int segment_shift(int W, int H, int capacity, int longest_list) {
     const int gx = tiles_x(W), gy = tiles_y(H);
     const long tiles = (long)gx * gy;
     const long per_tile = tiles > 0 ? ((long)(capacity > 0 ? capacity : 0) + tiles - 1) / tiles : 0;
+    static const int forced = [] { const char* e = getenv("DGR_SEG_SHIFT"); return (e && e[0] >= '2' && e[0] <= '4' && e[1] == 0) ? e[0] - '0' : 0; }();
+    if (forced) return forced;  // (A/B runs)
     int sh = 2;
     for (int c = 4; c > 2; c--)
         if ((per_tile << c) * 2 <= (long)K2_CAP * 3) { sh = c; break; }
     // small frames: bin_tiles is one workgroup per segment and each is a chain of dependent phases -- 90 workgroups on 256
     // CUs (640x480 at 16 tiles per segment) took as long as 544 (1920x1080); prefer at least two workgroups per CU
     while (sh > 2 && (long)gy * ((gx + (1 << sh) - 1) >> sh) < 512) sh--;
+    // The frame's longest tile list, where the last forward of this shape reported it (api.hip: hinted_longest_list): a frame
+    // whose lists are uneven -- a cluster of 1000-entry lists in a frame that averages 220 -- has segments that overflow the
+    // budget although the average one fits, and each of those takes the dense path (every phase several times slower:
+    // profiles/r9/bin_tiles_trace_before.txt).  Smaller segments, as long as one made of such lists still fits; if not even
+    // four of them do, the capacity's choice stands (the heavy-tailed scene: 108 us at 8 tiles per segment, 133 at 4).
+    if (longest_list > 0)
+        for (int c = sh; c >= 2; c--)
+            if (((long)longest_list << c) <= (long)K2_CAP) { sh = c; break; }
     return sh;
 }
 // Gaussians per bin_segments workgroup (a multiple of 1024, so that workgroup ranges start at a 256-block boundary) and the
@@ -595,13 +613,16 @@ hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, Segmen
 hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
                             int seg_shift, int capacity, bool prefixed, bool sched_on, StatusReport rep, hipStream_t stream) {
     const int nseg = grid_y * ((grid_x + (1 << seg_shift) - 1) >> seg_shift);
-    // expected entries per tile, from the capacity the caller sized the binning buffer with (segment_shift() uses the same)
-    const long tiles = (long)grid_x * grid_y;
-    const bool long_lists = tiles > 0 && (long)capacity / tiles > 900;
     const int helpers = (1 << seg_shift) / 4 - 1;  // per segment (bin_tiles_kernel)
-    launch(long_lists ? bin_tiles_kernel<true> : bin_tiles_kernel<false>, dim3(nseg * (1 + helpers)), dim3(K2_THREADS), stream, img, bin.point_list, bin.keys, tb, bin.pair_keys, bin.pair_cov,
+    // block -> segment map: XCD x takes a contiguous run of segments on a frame known to be even (the last report of this shape
+    // switched the tile schedule off); otherwise consecutive segments go to consecutive XCDs -- the segments of a cluster are
+    // neighbours, and a contiguous map hands all of them to two or three of the eight XCDs (clustered scene: 129 -> 107 us
+    // before anything else changed, profiles/r9/bin_tiles_ab.txt).  DGR_BT_MAP = 0 / 1 forces one (A/B runs).
+    static const int forced_map = [] { const char* e = getenv("DGR_BT_MAP"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
+    const int xp_map = forced_map >= 0 ? forced_map : (sched_on ? 0 : 1);
+    launch(bin_tiles_kernel, dim3(nseg * (1 + helpers)), dim3(K2_THREADS), stream, img, bin.point_list, bin.keys, tb, bin.pair_keys, bin.pair_cov,
            geom.block_tiles, (P + 255) / 256, segment_binning_workgroups(P), grid_x, grid_y, seg_shift, capacity, prefixed ? 1 : 0,
-           sched_on ? 1 : 0, rep);
+           sched_on ? 1 : 0, rep, xp_map, g_bin_tiles_trace);
     return hipGetLastError();
 }
 

@@ -385,6 +385,10 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
                              float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                              int track_off, int map_off);
 
+/* Debug: while `device_words` (8 x uint64 per bin_tiles workgroup, caller-owned device memory) is non-NULL, every bin_tiles
+ * workgroup stores phase time stamps (100 MHz wall clock) and its segment's sizes there: profiles/r9/bin_tiles_trace.py. */
+int dgr_debug_bin_tiles_trace(unsigned long long* device_words);
+
 /* Self-test of the wave64 multi-value butterfly reductions the backward blend relies on (csrc/wave_reduce.h: within-row DPP
  * stages first, then v_permlane16/32_swap as inline asm).  `in` holds 16 values per lane as in[c * 64 + lane]; out16 /
  * out12 / out4 [lane] receive what each lane holds after the 16- / 12- / 4-value network (the 12- and 4-value ones read the

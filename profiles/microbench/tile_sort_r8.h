@@ -2,7 +2,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "tile_sort_net.h"
 
 namespace dgr {
 namespace {
@@ -77,173 +76,132 @@ constexpr uint64_t KEY_INF = ~0ull;
 // cannot order -- entries whose depths agree in the upper 22 bits (2^-13 relative: a handful per tile) -- is settled by a
 // short fix-up on the full keys: the entries of such a run are adjacent after the sort, and each takes the run's start plus
 // the number of its run-mates with a smaller full key as its final position.
+template <int MASK, int LOWBIT>
+__device__ __forceinline__ uint32_t cmpx32(uint32_t v, int lane) {
+    const uint32_t o = xor_lane32<MASK>(v);
+    const bool lower = (lane & LOWBIT) == 0;
+    return lower ? min(v, o) : max(v, o);
+}
+template <int D>
+__device__ __forceinline__ uint32_t disperse32(uint32_t v, int lane) {
+    if constexpr (D > 0) return disperse32<D / 2>(cmpx32<D, D>(v, lane), lane);
+    else return v;
+}
+template <int SIZE>
+__device__ __forceinline__ uint32_t merge_stage32(uint32_t v, int lane) {
+    return disperse32<SIZE / 4>(cmpx32<SIZE - 1, SIZE / 2>(v, lane), lane);
+}
+__device__ __forceinline__ uint32_t chunk_sort64_32(uint32_t v, int lane) {
+    v = merge_stage32<2>(v, lane);
+    v = merge_stage32<4>(v, lane);
+    v = merge_stage32<8>(v, lane);
+    v = merge_stage32<16>(v, lane);
+    v = merge_stage32<32>(v, lane);
+    return merge_stage32<64>(v, lane);
+}
 constexpr uint32_t TRUNC_SLOT_BITS = 10, TRUNC_SLOT_MASK = (1u << TRUNC_SLOT_BITS) - 1u;
 
+// `list`: the n <= 64 NCH <= 1024 keys of one tile in LDS (overwritten).  IDS_OUT: dst_ids[0 .. n) receives the ids in key
+// order; otherwise the list itself ends up sorted (dst_ids unused).  One wave; no barrier.
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-// minimum and maximum of a word over the wave, in every lane (as scalars): four DPP steps inside the rows, then the four row
-// results through v_readlane
-__device__ __forceinline__ void wave_min_max_u32(uint32_t& mn, uint32_t& mx) {
-    mn = min(mn, xor_lane32<1>(mn));  mx = max(mx, xor_lane32<1>(mx));
-    mn = min(mn, xor_lane32<2>(mn));  mx = max(mx, xor_lane32<2>(mx));
-    mn = min(mn, xor_lane32<7>(mn));  mx = max(mx, xor_lane32<7>(mx));
-    mn = min(mn, xor_lane32<15>(mn)); mx = max(mx, xor_lane32<15>(mx));
-    const uint32_t a0 = __builtin_amdgcn_readlane(mn, 0), a1 = __builtin_amdgcn_readlane(mn, 16), a2 = __builtin_amdgcn_readlane(mn, 32),
-                   a3 = __builtin_amdgcn_readlane(mn, 48);
-    const uint32_t b0 = __builtin_amdgcn_readlane(mx, 0), b1 = __builtin_amdgcn_readlane(mx, 16), b2 = __builtin_amdgcn_readlane(mx, 32),
-                   b3 = __builtin_amdgcn_readlane(mx, 48);
-    mn = min(min(a0, a1), min(a2, a3));
-    mx = max(max(b0, b1), max(b2, b3));
-}
-
-// ---- a whole tile list in ONE wave's registers ---------------------------------------------------------------------------
-// `list`: the n <= 64 NCH <= 1024 keys of one tile in LDS (overwritten).  IDS_OUT: dst_ids[0 .. n) receives the ids in key
-// order; otherwise the list itself ends up sorted (dst_ids unused).  One wave; no barrier.
-//
-// A 64-bit compare-exchange costs two cross-lane moves, a 64-bit compare and two selects; the list is at most 1024 entries long,
-// so its order is carried by ONE 32-bit word per entry instead: 22 bits of depth | the entry's position in the unsorted LDS list
-// (10 bits).  Round 9: the 22 bits are not the depth's upper bits but the upper bits of (depth bits - the list's smallest) shifted
-// left by the leading zeros of the list's depth RANGE -- a tile's depths span a few octaves at most (synth-v1: 2.6, 7 bits
-// gained; a wall seen by a SLAM camera: a fraction of one), so two entries share a word prefix about once in a hundred
-// tiles instead of in six tiles of ten, and the runs real maps produce (surfaces: many Gaussians within 2^-13 of each other's
-// depth) stay short.  What the word cannot order -- entries that agree in those 22 bits -- is settled by a fix-up on the full
-// keys: the entries of such a run are adjacent after the sort, and each takes the run's start plus the number of its run-mates
-// with a smaller full key as its final position.
-//
-// The network itself is generated (gen_tile_sort_net.py -> tile_sort_net.h; word index = lane * NCH + register: the frequent
-// small distances are register-to-register, v_med3_u32 and bank-masked DPP min / max replace the compare-select pairs,
-// every step is issued for all of a lane's registers before the next).  Round 8's routine (profiles/microbench/tile_sort_r8.h)
-// needed 3.9 us for 200 entries and 46 us for 1000 (lists above 512 entries went through a four-part rank merge of dependent
-// LDS reads because the three-registers-per-entry epilogue spilled from NCH = 8 on at bin_tiles' 80 registers):
-// profiles/r9/wave_sort.txt.
 template <int NCH, bool IDS_OUT = true>
 __device__ __forceinline__ void sort_wave_trunc(uint64_t* list, int n, uint32_t* __restrict__ dst_ids, int lane) {
     static_assert(NCH * 64 <= (1 << TRUNC_SLOT_BITS), "slot bits");
-    // (LDS accesses below are unconditional with clamped indices wherever a stray read is harmless: a condition per access costs
-    //  an exec-mask region, a branch and a wait each -- 3 of the first version's 7 us at 1000 entries)
     uint32_t v[NCH];
-    uint2* const list2 = reinterpret_cast<uint2*>(list);  // .x = Gaussian id, .y = depth bits
-    const int last = n - 1;
-    uint32_t mn = 0xffffffffu, mx = 0u;
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {  // (where a word enters the network does not matter: coalesced reads)
-        const int e = c * 64 + lane;
-        v[c] = list2[min(e, last)].y;
-        mn = min(mn, e < n ? v[c] : 0xffffffffu);
-        mx = max(mx, e < n ? v[c] : 0u);
-    }
-    wave_min_max_u32(mn, mx);
-    const uint32_t shift = (uint32_t)__builtin_clz((mx - mn) | 1u);
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const int e = c * 64 + lane;
-        v[c] = (e < n) ? ((((v[c] - mn) << shift) & ~TRUNC_SLOT_MASK) | (uint32_t)e) : 0xffffffffu;
+        v[c] = (e < n) ? (((uint32_t)(list[e] >> 32) & ~TRUNC_SLOT_MASK) | (uint32_t)e) : 0xffffffffu;
+        if ((c & 1) && NCH > 1) v[c] = ~v[c];
+        v[c] = chunk_sort64_32(v[c], lane);
     }
-    const NetLane k = net_lane(lane);
-    sort_net<NCH>(v, k);
-    // the word of sorted position p = lane * NCH + c is in v[c].  Two neighbours with the same prefix differ in their slot bits only
-    // (a padding word, all ones, can follow an entry whose prefix is all ones: hence the position tests)
-    if constexpr (IDS_OUT) {
-        bool tie = false;
 #pragma unroll
-        for (int c = 0; c + 1 < NCH; c++) tie |= ((v[c] ^ v[c + 1]) <= TRUNC_SLOT_MASK) && (lane * NCH + c + 1 < n);
-        const uint32_t last_of_left = (uint32_t)__shfl_up((int)v[NCH - 1], 1, 64);
-        tie |= lane > 0 && ((last_of_left ^ v[0]) <= TRUNC_SLOT_MASK) && (lane * NCH < n);
-        if (__ballot(tie) == 0ull) {
-            // ---- the rule (no two entries of the list share a prefix): the ids alone, transposed through LDS so that the global
-            // stores are coalesced -- every lane fetches its entries' ids, THEN the list's bytes are overwritten (16-byte rows of
-            // four ids per lane and register group; a lane with an entry writes all its rows: the list's 8 n bytes hold the
-            // 4 (n + NCH - 1) + 8 bytes that takes, n being above 32 NCH)
-            uint32_t id[NCH];
+    for (int kc = 2; kc <= NCH; kc <<= 1) {  // merge blocks of kc chunks
 #pragma unroll
-            for (int c = 0; c < NCH; c++) id[c] = list2[min((int)(v[c] & TRUNC_SLOT_MASK), last)].x;
-            if constexpr (NCH == 1) {
-                if (lane < n) dst_ids[lane] = id[0];
-                return;
-            } else {
-                wave_lds_fence();
-                uint32_t* const tr = reinterpret_cast<uint32_t*>((reinterpret_cast<uintptr_t>(list) + 15u) & ~(uintptr_t)15u);
-                if (lane * NCH < n) {
-                    if constexpr (NCH == 2) {
-                        *reinterpret_cast<uint2*>(tr + lane * 2) = make_uint2(id[0], id[1]);
-                    } else {
-#pragma unroll
-                        for (int g = 0; g < NCH / 4; g++)
-                            *reinterpret_cast<uint4*>(tr + lane * NCH + 4 * g) = make_uint4(id[4 * g], id[4 * g + 1], id[4 * g + 2], id[4 * g + 3]);
-                    }
-                }
-                wave_lds_fence();
-#pragma unroll
-                for (int c = 0; c < NCH; c++) id[c] = tr[min(c * 64 + lane, last)];
-#pragma unroll
-                for (int c = 0; c < NCH; c++)
-                    if (c * 64 + lane < n) dst_ids[c * 64 + lane] = id[c];
-                return;
-            }
+        for (int c = 0; c < NCH; c++) {
+            const bool have = ((c / (kc / 2)) & 1) != 0;
+            const bool want = (kc < NCH) && (((c / kc) & 1) != 0);
+            if (have != want) v[c] = ~v[c];
         }
-    }
-    // ---- some entries share a prefix (or the caller wants the KEYS sorted in place): every lane fetches its entries' keys, THEN
-    // the list is overwritten in word order
-    uint32_t id[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const uint2 q = list2[min((int)(v[c] & TRUNC_SLOT_MASK), last)];
-        id[c] = q.x;
-        v[c] = q.y;
+        for (int jc = kc / 2; jc >= 1; jc >>= 1) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+                if ((c & jc) == 0) {
+                    const uint32_t lo = min(v[c], v[c + jc]), hi = max(v[c], v[c + jc]);
+                    v[c] = lo; v[c + jc] = hi;
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) v[c] = disperse32<32>(v[c], lane);
     }
+    // full keys in (truncated depth, slot) order: every lane fetches its entries' keys, THEN the list is overwritten
+    uint64_t key[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) key[c] = (c * 64 + lane < n) ? list[v[c] & TRUNC_SLOT_MASK] : KEY_INF;
     wave_lds_fence();
 #pragma unroll
     for (int c = 0; c < NCH; c++)
-        if (lane * NCH + c < n) list2[lane * NCH + c] = make_uint2(id[c], v[c]);
+        if (c * 64 + lane < n) list[c * 64 + lane] = key[c];
     wave_lds_fence();
-    // from here on position i = 64 c + lane (coalesced).  An entry that shares its prefix with a neighbour takes its run's start
-    // plus the number of its run-mates with a smaller full key as its final position (the run is adjacent after the sort).
-    auto prefix = [&](uint32_t depth_bits) { return ((depth_bits - mn) << shift) >> TRUNC_SLOT_BITS; };
-    auto final_position = [&](int i, uint2 q) -> int {
-        const uint32_t t = prefix(q.y);
-        const uint64_t key = ((uint64_t)q.y << 32) | q.x;
-        int pos = i;
-        for (int j = i - 1; j >= 0; j--) {           // run-mates in front of i: those with a LARGER key move behind it
-            const uint64_t o = list[j];
-            if (prefix((uint32_t)(o >> 32)) != t) break;
-            if (o > key) pos--;
-        }
-        for (int j = i + 1; j < n; j++) {            // run-mates behind i: those with a SMALLER key move in front of it
-            const uint64_t o = list[j];
-            if (prefix((uint32_t)(o >> 32)) != t) break;
-            if (o < key) pos++;
-        }
-        return pos;
-    };
-    if constexpr (IDS_OUT) {
+    // fix-up of the runs with equal upper depth bits
+    int final_pos[NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int i = c * 64 + lane;
-            if (i < n) {
-                const uint2 q = list2[i];
-                dst_ids[final_position(i, q)] = q.x;
+    for (int c = 0; c < NCH; c++) {
+        const int i = c * 64 + lane;
+        final_pos[c] = i;
+        if (i < n) {
+            const uint32_t t = (uint32_t)(key[c] >> 32) >> TRUNC_SLOT_BITS;
+            int pos = i;
+            for (int j = i - 1; j >= 0; j--) {           // run-mates in front of i: those with a LARGER key move behind it
+                const uint64_t o = list[j];
+                if (((uint32_t)(o >> 32) >> TRUNC_SLOT_BITS) != t) break;
+                if (o > key[c]) pos--;
             }
-        }
-    } else {
-        uint32_t moved[NCH];
-        uint2 kk[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int i = c * 64 + lane;
-            moved[c] = (uint32_t)i;
-            kk[c] = make_uint2(0u, 0u);
-            if (i < n) {
-                kk[c] = list2[i];
-                moved[c] = (uint32_t)final_position(i, kk[c]);
+            for (int j = i + 1; j < n; j++) {            // run-mates behind i: those with a SMALLER key move in front of it
+                const uint64_t o = list[j];
+                if (((uint32_t)(o >> 32) >> TRUNC_SLOT_BITS) != t) break;
+                if (o < key[c]) pos++;
             }
+            if (IDS_OUT) dst_ids[pos] = (uint32_t)key[c];
+            final_pos[c] = pos;
         }
-        wave_lds_fence();  // every lane has finished reading its neighbours: the moved keys go to their final positions
+    }
+    if (!IDS_OUT) {  // every lane has finished reading its neighbours: the keys go to their final positions
+        wave_lds_fence();
 #pragma unroll
         for (int c = 0; c < NCH; c++)
-            if (moved[c] != (uint32_t)(c * 64 + lane)) list2[moved[c]] = kk[c];
+            if (c * 64 + lane < n) list[final_pos[c]] = key[c];
         wave_lds_fence();
+    }
+}
+
+// 512 < n <= 1024: four parts of 256 sorted as above (keys in place), then merged by rank -- an entry's final position is
+// its position in its own part plus the number of entries of every OTHER part in front of it (binary searches in LDS; keys
+// are unique).  A single 1024-entry pass would hold 48 registers per lane around its key fetch, and two 512-entry passes
+// still spill at the 80 registers bin_tiles has.
+__device__ __forceinline__ void sort_wave_trunc_1024(uint64_t* list, int n, uint32_t* __restrict__ dst_ids, int lane) {
+    constexpr int Q = 256;
+    const int parts = (n + Q - 1) / Q;
+    for (int p = 0; p < parts; p++) sort_wave_trunc<4, false>(list + p * Q, min(Q, n - p * Q), nullptr, lane);
+    for (int i = lane; i < n; i += 64) {
+        const uint64_t k = list[i];
+        const int mine = i / Q;
+        int pos = i - mine * Q;
+        for (int p = 0; p < parts; p++) {
+            if (p == mine) continue;
+            const uint64_t* other = list + p * Q;
+            int lo = 0, hi = min(Q, n - p * Q);  // lower bound of k in part p
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (other[mid] < k) lo = mid + 1; else hi = mid;
+            }
+            pos += lo;
+        }
+        dst_ids[pos] = (uint32_t)k;
     }
 }
 
@@ -274,6 +232,48 @@ __device__ __forceinline__ void merge_list_parts(const uint64_t* list, int n, ui
             pos += lo;
         }
         dst_ids[pos] = (uint32_t)k;
+    }
+}
+
+// ---- the full 64-bit keys in registers: lists of 513 .. 1024 entries where they are the rule (bin_tiles<LONG_LISTS>) --------------
+// (the 32-bit form would hold 16 words + 16 keys per lane around its key fetch, and the four-part merge above is a chain of
+//  dependent LDS reads: 159 against 116 us at config 4's 810 entries per tile)
+__device__ __forceinline__ void cmpx_regs(uint64_t& a, uint64_t& b) {  // a <- min, b <- max
+    const bool sw = b < a;
+    const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+    a = lo; b = hi;
+}
+template <int NCH>
+__device__ __forceinline__ void sort_wave_regs(const uint64_t* __restrict__ src, int n, uint32_t* __restrict__ dst_ids, int lane) {
+    uint64_t v[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int e = c * 64 + lane;
+        v[c] = (e < n) ? src[e] : KEY_INF;
+        if ((c & 1) && NCH > 1) v[c] = ~v[c];
+        v[c] = chunk_sort64(v[c], lane);
+    }
+#pragma unroll
+    for (int kc = 2; kc <= NCH; kc <<= 1) {  // merge blocks of kc chunks
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const bool have = ((c / (kc / 2)) & 1) != 0;                 // complemented by the previous stage
+            const bool want = (kc < NCH) && (((c / kc) & 1) != 0);       // this block must come out descending
+            if (have != want) v[c] = ~v[c];
+        }
+#pragma unroll
+        for (int jc = kc / 2; jc >= 1; jc >>= 1) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+                if ((c & jc) == 0) cmpx_regs(v[c], v[c + jc]);
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; c++) v[c] = chunk_tail64(v[c], lane);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int e = c * 64 + lane;
+        if (e < n) dst_ids[e] = (uint32_t)v[c];
     }
 }
 
