@@ -145,13 +145,16 @@ __device__ __forceinline__ void sort_wave_trunc(uint64_t* list, int n, uint32_t*
     sort_net<NCH>(v, k);
     // the word of sorted position p = lane * NCH + c is in v[c].  Two neighbours with the same prefix differ in their slot bits only
     // (a padding word, all ones, can follow an entry whose prefix is all ones: hence the position tests)
-    if constexpr (IDS_OUT) {
-        bool tie = false;
+    bool tie = false;
 #pragma unroll
-        for (int c = 0; c + 1 < NCH; c++) tie |= ((v[c] ^ v[c + 1]) <= TRUNC_SLOT_MASK) && (lane * NCH + c + 1 < n);
+    for (int c = 0; c + 1 < NCH; c++) tie |= ((v[c] ^ v[c + 1]) <= TRUNC_SLOT_MASK) && (lane * NCH + c + 1 < n);
+    {
         const uint32_t last_of_left = (uint32_t)__shfl_up((int)v[NCH - 1], 1, 64);
         tie |= lane > 0 && ((last_of_left ^ v[0]) <= TRUNC_SLOT_MASK) && (lane * NCH < n);
-        if (__ballot(tie) == 0ull) {
+    }
+    const bool any_tie = __ballot(tie) != 0ull;
+    if constexpr (IDS_OUT) {
+        if (!any_tie) {
             // ---- the rule (no two entries of the list share a prefix): the ids alone, transposed through LDS so that the global
             // stores are coalesced -- every lane fetches its entries' ids, THEN the list's bytes are overwritten (16-byte rows of
             // four ids per lane and register group; a lane with an entry writes all its rows: the list's 8 n bytes hold the
@@ -198,6 +201,9 @@ __device__ __forceinline__ void sort_wave_trunc(uint64_t* list, int n, uint32_t*
     for (int c = 0; c < NCH; c++)
         if (lane * NCH + c < n) list2[lane * NCH + c] = make_uint2(id[c], v[c]);
     wave_lds_fence();
+    if constexpr (!IDS_OUT) {
+        if (!any_tie) return;  // word order IS key order
+    }
     // from here on position i = 64 c + lane (coalesced).  An entry that shares its prefix with a neighbour takes its run's start
     // plus the number of its run-mates with a smaller full key as its final position (the run is adjacent after the sort).
     auto prefix = [&](uint32_t depth_bits) { return ((depth_bits - mn) << shift) >> TRUNC_SLOT_BITS; };

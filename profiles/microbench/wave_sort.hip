@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(512, 6) k(const uint64_t* __restrict__ src, ui
 
 int main(int argc, char** argv) {
     const int tie_every = argc > 1 ? atoi(argv[1]) : 37;
-    const int blocks = 256, reps = 20;
+    const int blocks = argc > 2 ? atoi(argv[2]) : 256, reps = 20;
     std::mt19937_64 rng(1);
     std::vector<uint64_t> h((size_t)blocks * 8 * 1024);
     // keys as bin_tiles meets them: depth bits of z in [1, 6] << 32 | unique id; some depths tied in their upper 22 bits

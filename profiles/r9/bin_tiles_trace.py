@@ -23,13 +23,18 @@ lib = _capi.load()
 hh.hip_forward(s, 3)            # warm-up (and the frame's capacity / hints)
 hh.hip_forward(s, 3)
 nwg = 68 * 30 * 4 + 64
-buf = torch.zeros(nwg * 8, dtype=torch.int64, device="cuda")
+buf = torch.zeros(3 * 2176 * 8, dtype=torch.int64, device="cuda")
 lib.dgr_debug_bin_tiles_trace(buf.data_ptr())
 hh.hip_forward(s, 3)
 torch.cuda.synchronize()
 lib.dgr_debug_bin_tiles_trace(None)
-t = buf.cpu().numpy().view(np.uint64).reshape(-1, 8)
+allw = buf.cpu().numpy().view(np.uint64).reshape(-1, 8)
+t = allw[:2176]
+per_wave = allw[2176:2 * 2176]
+arrive = allw[2 * 2176:]
 used = t[:, 0] != 0
+per_wave = per_wave[used]
+arrive = arrive[used]
 t = t[used]
 t0 = t[:, 0].min()
 start = (t[:, 0] - t0) / 100.0                    # us
@@ -47,7 +52,10 @@ print("longest workgroups: start us | prologue+scan | load+count | ranges..place
 for i in order[:16]:
     if not full[i]:
         continue
-    print(f"  {start[i]:7.1f} | {d(0, 1)[i]:6.1f} | {d(1, 2)[i]:6.1f} | {d(2, 3)[i]:6.1f} | {d(3, 4)[i]:6.1f} | {d(0, 4)[i]:6.1f} | {gcount[i]} {npairs[i]} {tmax[i]} {int(dense[i])}")
+    print(f"  {start[i]:7.1f} | {d(0, 1)[i]:6.1f} | {d(1, 2)[i]:6.1f} | {d(2, 3)[i]:6.1f} | {d(3, 4)[i]:6.1f} | {d(0, 4)[i]:6.1f} | {gcount[i]} {npairs[i]} {tmax[i]} {int(dense[i])}" + (f"  (parts sorted after {d(3, 5)[i]:.1f} us of the sort phase)" if t[i, 5] else ""))
+    if t[i, 5]:
+        print("      per wave (us, entries; p = a 512-entry part): " + "  ".join(f"{(int(x) >> 16) / 100.0:.1f}/{'p' if int(x) & 0x8000 else ''}{int(x) & 0x7fff}" for x in per_wave[i] if x))
+        print("      waves reach the barrier behind the sorts (us after the phase began): " + " ".join(f"{(int(x) - int(t[i, 3])) / 100.0:.1f}" for x in arrive[i] if x))
 for name, m in (("all working", full), ("heavy (gcount > 3000)", full & (gcount > 3000)), ("light", full & (gcount <= 3000))):
     if m.sum():
         print(f"{name}: n {int(m.sum())}  mean us: prologue {d(0, 1)[m].mean():.1f} load+count {d(1, 2)[m].mean():.1f} place {d(2, 3)[m].mean():.1f} sort {d(3, 4)[m].mean():.1f} total {d(0, 4)[m].mean():.1f};  last start {start[m].max():.1f} last end {((end[m] - t0) / 100.0).max():.1f}")
