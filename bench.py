@@ -7,7 +7,8 @@ False) on the synth-v1 scene of BASELINE config 3, inputs resident in HBM before
 By default 21 independent views are in flight on 21 HIP streams (--views-in-flight; three in strict / graph / tracking mode
 and with --gpus N; every view is
 a complete forward + backward with its own state) and the forward checks its status word lazily
-(--sync-mode); `config.ms_per_view_one_stream` is the strictly serial figure.
+(--sync-mode); `config.ms_per_view_one_stream` is the strictly serial figure, `config.ms_per_view_strict_one_stream` the same in the
+library's default status mode (strict), i.e. what a drop-in caller that renders one view at a time sees.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -370,6 +371,7 @@ def main():
         captured.extend(CapturedStep(step, stream=torch.cuda.Stream(device=dev)) for _ in range(K))
     # one view at a time, for reference (short, untimed by the contract)
     serial_ms = None
+    strict_serial_ms = None
     if K > 1:
         drain()
         barrier()
@@ -379,6 +381,21 @@ def main():
         drain()
         barrier()
         serial_ms = (time.perf_counter() - t0) / 20 * 1e3
+        # ... and as a drop-in sees it: the library's default status mode (strict: every forward waits for its own status word,
+        # overflow retried inside the call), one view at a time, CG-SLAM's calling pattern
+        if args.sync_mode == "lazy" and not args.graph and dist is None:
+            os.environ["DGR_SYNC_MODE"] = "strict"
+            for _ in range(3):
+                first(step())
+            drain()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                radii = first(step())
+            drain()
+            barrier()
+            strict_serial_ms = (time.perf_counter() - t0) / 20 * 1e3
+            os.environ["DGR_SYNC_MODE"] = "lazy"
         run(2 * K)  # warm the side streams (allocator pools, status words)
     drain()
     barrier()
@@ -512,7 +529,8 @@ def main():
                        "num_rendered": R, "views_per_s": views_per_s, "sync_mode": args.sync_mode,
                        "autograd_engine_thread": torch.autograd.is_multithreading_enabled(),
                        "tile_schedule": {0: "never", 1: "always", 2: "by the frame (skipped on even frames)"}.get(_capi.get_option("tile_schedule")),
-                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms, "views_per_step": max(1, Vb),
+                       "views_in_flight": K, "ms_per_view_one_stream": serial_ms,
+                       "ms_per_view_strict_one_stream": strict_serial_ms, "views_per_step": max(1, Vb),
                        "ms_per_view": 1e3 * elapsed / args.steps / max(1, Vb), "hipgraph_replay": bool(args.graph),
                        "binning": "two-level segment binning (csrc/segment_binning.hip)" if _capi.get_option("lds_count") else "global tile counters (csrc/binning.hip)",
                        "pair_evals_per_view": pair_evals,

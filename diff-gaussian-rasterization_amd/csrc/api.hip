@@ -247,6 +247,17 @@ std::atomic<int> g_alpha_mode{[] {
 // buffer (64 bytes per tile instance: zero-filled, written and read once) and a smaller batch in the blend backward.  The backward
 // then needs dgr_light_backward_scratch_bytes_r(P, W, H, R) bytes of scratch, R = the value passed as `R` (>= num_rendered).
 std::atomic<int> g_det_grads{[] { const char* e = getenv("DGR_DETERMINISTIC_GRADS"); return (e && e[0] == '1') ? 1 : 0; }()};
+
+// ---- per-THREAD overrides of the three options that change what a call computes (dgr_set_thread_option, round 9).  The options
+// above are process-wide defaults; a tracker thread and a mapper thread of one process -- or a test beside a training loop -- hold
+// their own values here (-1 = inherit).  Every entry point reads its options ONCE, when it is called, and hands them to its
+// launches as template choices / kernel arguments: launches already queued (on any stream) are not affected by a later change.
+// A backward must run with its forward's alpha mode: the autograd bindings snapshot dgr_thread_options_effective() in the
+// forward and swap it in around the backward (which the autograd engine may run on another thread).
+thread_local int t_alpha_mode = -1, t_tight_cull = -1, t_det_grads = -1;
+inline int opt_alpha_mode() { return t_alpha_mode >= 0 ? t_alpha_mode : g_alpha_mode.load(std::memory_order_relaxed); }
+inline int opt_tight_cull() { return t_tight_cull >= 0 ? t_tight_cull : g_tight_cull.load(std::memory_order_relaxed); }
+inline int opt_det_grads() { return t_det_grads >= 0 ? t_det_grads : g_det_grads.load(std::memory_order_relaxed); }
 // dgr_set_option("lds_count", v): how the forward bins tile instances.
 //   1 (default) = the two-level segment binning (csrc/segment_binning.hip) whenever the frame's segment tables fit LDS;
 //   0 = returning global atomics on per-tile counters (csrc/binning.hip; inside preprocess_fwd when presized), which also
@@ -350,7 +361,7 @@ int forward_front(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img
     a.focal_y = c.H / (2.0f * c.tan_fovy);  // rasterizer_impl.cu:228-229
     a.focal_x = c.W / (2.0f * c.tan_fovx);
     a.prefiltered = c.prefiltered;
-    a.tight_cull = g_tight_cull.load();
+    a.tight_cull = opt_tight_cull();
     a.sh_vec_ok = aligned16(c.shs);
     a.geom = geom; a.radii_out = c.radii;
     a.gau_uncertainty = c.gau_uncertainty; a.gau_related_pixels = c.gau_related_pixels;
@@ -416,7 +427,7 @@ int forward_back(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView img,
     r.gau_related_pixels = c.gau_related_pixels;
     r.rep = armed ? armed->rep : dgr::StatusReport{nullptr, 0u, nullptr};
     r.status = img.status;
-    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_light(r, g_alpha_mode.load(), st)); }
+    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_light(r, opt_alpha_mode(), st)); }
     if (armed) armed->handed_over = true;  // (workgroup 0 of the blend delivers the word)
     return DGR_OK;
 }
@@ -432,7 +443,7 @@ int forward_back_full(const FwdCommon& c, float* out_uncertainty, dgr::GeometryV
     r.n_contrib = img.n_contrib; r.n_valid = img.n_valid; r.first_contrib = img.first_contrib; r.final_T = img.final_T;
     r.status = img.status;
     r.rep = armed ? armed->rep : dgr::StatusReport{nullptr, 0u, nullptr};
-    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_full(r, g_alpha_mode.load(), st)); }
+    { ScopedStage t(ST_RENDER_FWD, st); HIP_TRY(dgr::launch_render_fwd_full(r, opt_alpha_mode(), st)); }
     if (armed) armed->handed_over = true;
     return DGR_OK;
 }
@@ -617,7 +628,7 @@ DetScratch carve_det_scratch(char* base, int P, int R) {
 }
 }  // namespace
 size_t dgr_light_backward_scratch_bytes_r(int P, int W, int H, int R) {
-    if (!g_det_grads.load()) return dgr_light_backward_scratch_bytes(P, W, H);
+    if (!opt_det_grads()) return dgr_light_backward_scratch_bytes(P, W, H);
     return carve_det_scratch(nullptr, P, R).bytes;
 }
 
@@ -728,8 +739,8 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
         HIP_TRY(hipMemsetAsync(dL_dview, 0, 16 * 4, st));
         return DGR_OK;
     }
-    const bool det = g_det_grads.load() != 0 && !(track_off && map_off);
-    if (det && g_alpha_mode.load() != 0) { g_last_error = "deterministic_grads needs alpha_mode 0"; return DGR_ERR_BAD_ARGUMENT; }
+    const bool det = opt_det_grads() != 0 && !(track_off && map_off);
+    if (det && opt_alpha_mode() != 0) { g_last_error = "deterministic_grads needs alpha_mode 0"; return DGR_ERR_BAD_ARGUMENT; }
     if (det && R <= 0) { g_last_error = "deterministic_grads: the backward needs R >= num_rendered (it sizes the instance-major row buffer)"; return DGR_ERR_BAD_ARGUMENT; }
     if (scratch_bytes < dgr_light_backward_scratch_bytes_r(P, width, height, R) || !scratch) {
         g_last_error = det ? "backward scratch too small (deterministic_grads: dgr_light_backward_scratch_bytes_r)" : "backward scratch too small";
@@ -760,7 +771,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
         HIP_TRY(dgr::launch_det_offsets(P, geom.rect, ds.blk, geom.goff, st));
         r.det_rows = ds.rows; r.det_rect = geom.rect; r.det_goff = geom.goff; r.det_R = (uint32_t)R;
     }
-    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_light(r, g_alpha_mode.load(), st)); }
+    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_light(r, opt_alpha_mode(), st)); }
     if (det) HIP_TRY(dgr::launch_det_gather(P, geom.rect, geom.goff, ds.rows, (uint32_t)R, sc.acc, st));
 
     dgr::PreprocessBwdArgs b{};
@@ -878,7 +889,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     (void)R; (void)colors_precomp; (void)dpixel_dgc; (void)gau_id_list; (void)pix_id_list; (void)dgc_dCam_position;
     (void)dpixel_dndcs; (void)dgndcs_dviewmatrix; (void)dpixel_dinvcovs; (void)dgc_invcovs_dT; (void)ddepth_dndcs;
     (void)ddepth_dinvcovs;
-    if (g_det_grads.load()) { g_last_error = "deterministic_grads: the light variant's one-view backward only"; return DGR_ERR_BAD_ARGUMENT; }
+    if (opt_det_grads()) { g_last_error = "deterministic_grads: the light variant's one-view backward only"; return DGR_ERR_BAD_ARGUMENT; }
     hipStream_t st = (hipStream_t)stream;
     const bool scratch_clean = g_scratch_clean_armed;
     g_scratch_clean_armed = false;
@@ -906,7 +917,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     r.sched = img.tile_sched; r.ranges = img.ranges; r.sched_flag = img.cursor + 3; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
     r.gt_depth = gt_depth; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.first_contrib = img.first_contrib;
     r.dL_dpix = dL_dpix; r.dL_depths = dL_depths; r.dL_duncertainties = dL_duncertainties; r.acc = sc.acc;
-    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_full(r, g_alpha_mode.load(), st)); }
+    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_full(r, opt_alpha_mode(), st)); }
 
     dgr::PreprocessBwdArgs b{};
     b.P = P; b.D = D; b.M = M; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs; b.scales = scales;
@@ -975,7 +986,7 @@ int dgr_light_forward_batch(void* stream, int n_views, const dgr_light_view* vie
         a.focal_y = height / (2.0f * tan_fovy);  // rasterizer_impl.cu:228-229
         a.focal_x = width / (2.0f * tan_fovx);
         a.prefiltered = prefiltered;
-        a.tight_cull = g_tight_cull.load();
+        a.tight_cull = opt_tight_cull();
         a.sh_vec_ok = aligned16(shs);
         b.V = n_views;
         for (int v = 0; v < n_views; v++) {
@@ -1016,7 +1027,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
                              int track_off, int map_off) {
     (void)colors_precomp;
     hipStream_t st = (hipStream_t)stream;
-    if (g_det_grads.load()) { g_last_error = "deterministic_grads: the light variant's one-view backward only"; return DGR_ERR_BAD_ARGUMENT; }
+    if (opt_det_grads()) { g_last_error = "deterministic_grads: the light variant's one-view backward only"; return DGR_ERR_BAD_ARGUMENT; }
     if (n_views < 1 || n_views > DGR_MAX_BATCH_VIEWS || !views) { g_last_error = "1 .. DGR_MAX_BATCH_VIEWS views per batch"; return DGR_ERR_BAD_ARGUMENT; }
     if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
     for (int v = 0; v < n_views; v++)
@@ -1062,7 +1073,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
         r.gt_depth = w.gt_depth; r.alphas = w.alphas; r.n_contrib = img.n_contrib; r.dL_dpix = w.dL_dpix;
         r.dL_dpix_depth = w.dL_dpix_depth; r.dL_dpix_median = w.dL_dpix_median_depth; r.dL_dpix_var = w.dL_dpix_depth_var;
         r.means3D = means3D; r.view = w.viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
-        { ScopedStage t(ST_RENDER_BWD, sv); HIP_TRY(dgr::launch_render_bwd_light(r, g_alpha_mode.load(), sv)); }
+        { ScopedStage t(ST_RENDER_BWD, sv); HIP_TRY(dgr::launch_render_bwd_light(r, opt_alpha_mode(), sv)); }
         dgr::BwdViewPart& q = bb.v[v];
         q.view = w.viewmatrix; q.proj = w.projmatrix; q.campos = w.cam_pos; q.perspec = w.perspec_matrix;
         q.radii = w.radii ? w.radii : geom.radii; q.geom = geom; q.acc = sc.acc; q.dL_dmean2D = w.dL_dmean2D;
@@ -1121,7 +1132,7 @@ int dgr_debug_exact_math(void* stream, int n, const float* x, const float* a, co
         g_last_error = "dgr_debug_exact_math: bad argument";
         return DGR_ERR_BAD_ARGUMENT;
     }
-    HIP_TRY(dgr::launch_exact_math_test(n, x, a, b, out_exp, out_div, g_alpha_mode.load(), (hipStream_t)stream));
+    HIP_TRY(dgr::launch_exact_math_test(n, x, a, b, out_exp, out_div, opt_alpha_mode(), (hipStream_t)stream));
     return DGR_OK;
 }
 
@@ -1393,6 +1404,40 @@ int dgr_get_option(const char* name) {
     if (n == "batch_streams") return g_batch_streams.load();
     if (n == "batch_order") return g_batch_order.load();
     return DGR_ERR_BAD_ARGUMENT;
+}
+
+int dgr_set_thread_option(const char* name, int value) {
+    const std::string n(name ? name : "");
+    if (n == "alpha_mode") {
+        if (value > 2) { g_last_error = "alpha_mode: 0, 1, 2 (or < 0: the process-wide option)"; return DGR_ERR_BAD_ARGUMENT; }
+        t_alpha_mode = value < 0 ? -1 : value;
+        return DGR_OK;
+    }
+    if (n == "fast_alpha") { t_alpha_mode = value < 0 ? -1 : (value ? 1 : 0); return DGR_OK; }
+    if (n == "tight_cull") { t_tight_cull = value < 0 ? -1 : (value ? 1 : 0); return DGR_OK; }
+    if (n == "deterministic_grads") { t_det_grads = value < 0 ? -1 : (value ? 1 : 0); return DGR_OK; }
+    g_last_error = "not a per-thread option: " + n;
+    return DGR_ERR_BAD_ARGUMENT;
+}
+int dgr_get_thread_option(const char* name) {
+    const std::string n(name ? name : "");
+    if (n == "alpha_mode") return opt_alpha_mode();
+    if (n == "fast_alpha") return opt_alpha_mode() == 1 ? 1 : 0;
+    if (n == "tight_cull") return opt_tight_cull();
+    if (n == "deterministic_grads") return opt_det_grads();
+    return DGR_ERR_BAD_ARGUMENT;
+}
+// the three as one word, each field = value + 1 (0 = "inherit", in an override word): bits 0-3 alpha_mode, 4-7 tight_cull, 8-11
+// deterministic_grads
+int dgr_thread_options_effective(void) { return (opt_alpha_mode() + 1) | ((opt_tight_cull() + 1) << 4) | ((opt_det_grads() + 1) << 8); }
+int dgr_thread_options_swap(int word) {
+    const int prev = (t_alpha_mode + 1) | ((t_tight_cull + 1) << 4) | ((t_det_grads + 1) << 8);
+    if (word >= 0) {
+        t_alpha_mode = (word & 15) - 1;
+        t_tight_cull = ((word >> 4) & 15) - 1;
+        t_det_grads = ((word >> 8) & 15) - 1;
+    }
+    return prev;
 }
 
 int dgr_profile_select(const char* stage) {

@@ -107,6 +107,10 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     __syncthreads();
     if (have_flush) flush_tags(s, hit, a.point_list, range.x + last_base, tid);
 
+    // (an overflowed forward rendered empty lists: NaN images instead of a plausible empty frame -- render_light.hip)
+    if (__builtin_amdgcn_readfirstlane(a.status[1]) != 0) {
+        C0 = C1 = C2 = U = Dd = __builtin_nanf("");
+    }
     if (inside) {
         const size_t N = (size_t)a.W * a.H;
         a.final_T[pix_id] = T;

@@ -175,6 +175,12 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
     __syncthreads();
     if (have_flush) flush_slot(sf, a, tag8, range.x + last_base, tid, tid < total - last_base);
 
+    // A forward whose binning buffer was too small has rendered EMPTY tile lists (bin_tiles left every range {0, 0}): in lazy mode
+    // the host learns of it a call or two later, so the images must not look like a frame -- they are NaN, every value
+    // (strict mode retries inside the call and overwrites them).  One scalar load and a uniform branch.
+    if (__builtin_amdgcn_readfirstlane(a.status[1]) != 0) {
+        C0 = C1 = C2 = weight = Dd = D_median = __builtin_nanf("");
+    }
     if (inside) {
         const size_t N = (size_t)a.W * a.H;
         a.n_contrib[pix_id] = last_contributor;

@@ -677,6 +677,13 @@ inline Tensor zeros_like_image(long c, long H, long W, const c10::Device& dev) {
     return at::zeros({c, H, W}, at::TensorOptions().dtype(at::kFloat).device(dev));
 }
 
+// a block under a word of dgr_thread_options_effective() (include/dgr_hip.h): a backward under its forward's options
+struct UnderOptions {
+    int prev;
+    explicit UnderOptions(int word) : prev(dgr_thread_options_swap(word)) {}
+    ~UnderOptions() { dgr_thread_options_swap(prev); }
+};
+
 struct LightNode : public torch::autograd::Function<LightNode> {
     // inputs 0..9 as L/__init__.py:46-60; then the settings' tensors and scalars (L/__init__.py:180-195) and the binning policy
     static variable_list forward(AutogradContext* ctx, const Tensor& means3D, const Tensor& means2D, const Tensor& sh,
@@ -699,6 +706,7 @@ struct LightNode : public torch::autograd::Function<LightNode> {
         d["scale_modifier"] = scale_modifier; d["tanfovx"] = tanfovx; d["tanfovy"] = tanfovy; d["degree"] = degree;
         d["R"] = (int64_t)(o.rendered >= 0 ? o.rendered : o.cap); d["track_off"] = track_off; d["map_off"] = map_off;
         d["H"] = H; d["W"] = W;
+        d["options"] = (int64_t)dgr_thread_options_effective();  // the backward runs under the forward's per-call options
         // four of the eight outputs (radii, opacity_map, gau_uncertainty, gau_related_pixels) have no gradient input in the
         // backward: no zero-filled gradient tensors for them
         ctx->set_materialize_grads(false);
@@ -724,6 +732,7 @@ struct LightNode : public torch::autograd::Function<LightNode> {
         const Tensor gV = grad[4].defined() ? grad[4] : Tensor();
         bool need = false;  // (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp): tracking needs none
         for (int i = 0; i < 8; i++) need = need || ctx->needs_input_grad(i);
+        const UnderOptions under((int)d["options"].toInt());  // (the engine may run this node on a thread of its own)
         std::vector<Tensor> g = light_backward(sv[13], means3D, sv[6], sv[0], sv[2], sv[3], d["scale_modifier"].toDouble(), sv[4],
                                                sv[5], sv[14], d["tanfovx"].toDouble(), d["tanfovy"].toDouble(), gC, gD, gM, gV, sv[12],
                                                sv[7], d["degree"].toInt(), sv[15], sv[8], d["R"].toInt(), sv[9], sv[10], sv[11], false,
@@ -776,6 +785,7 @@ struct FullNode : public torch::autograd::Function<FullNode> {
         auto& d = ctx->saved_data;
         d["scale_modifier"] = scale_modifier; d["tanfovx"] = tanfovx; d["tanfovy"] = tanfovy; d["degree"] = degree;
         d["R"] = (int64_t)(o.rendered >= 0 ? o.rendered : o.cap); d["H"] = H; d["W"] = W;
+        d["options"] = (int64_t)dgr_thread_options_effective();
         ctx->set_materialize_grads(false);
         ctx->mark_non_differentiable({o.radii});
         return {o.color, o.radii, o.depth, o.unc};
@@ -792,6 +802,7 @@ struct FullNode : public torch::autograd::Function<FullNode> {
         const Tensor gU = grad[3].defined() ? grad[3] : zeros_like_image(1, H, W, dev);
         bool need = false;
         for (int i = 0; i < 8; i++) need = need || ctx->needs_input_grad(i);
+        const UnderOptions under((int)d["options"].toInt());
         std::vector<Tensor> g = full_backward(sv[12], means3D, sv[6], sv[0], sv[2], sv[3], d["scale_modifier"].toDouble(), sv[4], sv[5],
                                               sv[11], sv[13], d["tanfovx"].toDouble(), d["tanfovy"].toDouble(), gC, gD, gU, sv[7],
                                               d["degree"].toInt(), sv[14], sv[8], d["R"].toInt(), sv[9], sv[10], 0, sv[15], need);

@@ -67,6 +67,10 @@ _SIGS = {
     "dgr_sparse_adam_capturable": (_i, [_vp, C.c_long, _i, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _vp]),
     "dgr_set_option": (_i, [C.c_char_p, _i]),
     "dgr_get_option": (_i, [C.c_char_p]),
+    "dgr_set_thread_option": (_i, [C.c_char_p, _i]),
+    "dgr_get_thread_option": (_i, [C.c_char_p]),
+    "dgr_thread_options_effective": (_i, []),
+    "dgr_thread_options_swap": (_i, [_i]),
     "dgr_version": (C.c_char_p, []),
     "dgr_geometry_bytes": (_sz, [_i]),
     "dgr_image_bytes": (_sz, [_i, _i]),
@@ -179,6 +183,44 @@ def set_option(name, value):
 
 def get_option(name):
     return load().dgr_get_option(name.encode())
+
+
+class thread_options:
+    """`with thread_options(alpha_mode=1, tight_cull=1): ...` -- the calling THREAD's rasterizer calls inside the block use these
+    values of the per-call options (include/dgr_hip.h: dgr_set_thread_option) whatever the process-wide ones are; other threads
+    are not affected, and a backward runs under its forward's options wherever autograd runs it.  Names: alpha_mode (fast_alpha),
+    tight_cull, deterministic_grads."""
+
+    def __init__(self, **options):
+        self.options = options
+        self.prev = None
+
+    def __enter__(self):
+        lib = load()
+        self.prev = lib.dgr_thread_options_swap(-1)
+        for k, v in self.options.items():
+            if lib.dgr_set_thread_option(k.encode(), int(v)):
+                lib.dgr_thread_options_swap(self.prev)
+                raise ValueError(last_error())
+        return self
+
+    def __exit__(self, *exc):
+        load().dgr_thread_options_swap(self.prev)
+        return False
+
+
+class under_options:
+    """Runs a block under a word of dgr_thread_options_effective() (a backward under its forward's options)."""
+
+    def __init__(self, word):
+        self.word = word
+
+    def __enter__(self):
+        self.prev = load().dgr_thread_options_swap(self.word)
+
+    def __exit__(self, *exc):
+        load().dgr_thread_options_swap(self.prev)
+        return False
 
 
 def profile_select(stage=""):

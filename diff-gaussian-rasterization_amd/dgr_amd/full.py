@@ -275,6 +275,7 @@ class _RasterizeGaussians(torch.autograd.Function):
          imgBuffer) = _C.rasterize_gaussians(*args)
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        ctx.dgr_options = _capi.load().dgr_thread_options_effective()  # the backward runs under the forward's options
         ctx.num_related_gaussians = num_related_gaussians
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, viewmatrix, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer, gt_depth)
@@ -321,8 +322,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 imgBuffer,
                 num_related_gaussians,
                 raster_settings.perspec_matrix)
-        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-         grad_rotations, grad_viewmatrix) = _C.rasterize_gaussians_backward(*args, need_gaussian_grads=any(ctx.needs_input_grad[:8]))
+        with _capi.under_options(ctx.dgr_options):  # (the autograd engine may run this on a thread of its own)
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+             grad_rotations, grad_viewmatrix) = _C.rasterize_gaussians_backward(*args, need_gaussian_grads=any(ctx.needs_input_grad[:8]))
         _light._consume_post_backward_wait()  # (dgr_amd.multiview.ViewStreams.before_backward)
         grads = (
             grad_means3D,

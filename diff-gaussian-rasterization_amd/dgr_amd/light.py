@@ -91,11 +91,47 @@ def _post_status(status, key):
     _pending_status.append((ticket, key))
 
 
+# Lazy mode is only as safe as its capacity guess (1.5 x the largest count seen for the shape): a count that GROWS -- the camera
+# closing in, splats being scaled up, a map that densifies without changing P -- reaches it within a few frames, and frames rendered
+# past it have empty tile lists.  Three guards (round 9):
+#   * the blend kernels write NaN images for an overflowed forward (csrc/render_light.hip), never a plausible empty frame, and its
+#     backward (empty lists) yields zero gradients: nothing wrong reaches an optimiser unnoticed;
+#   * a shape whose count grew by more than 25 % between two status reads, came within 20 % of the capacity it was rendered with,
+#     or overflowed, is UNSETTLED: its next forwards run strict (exact count, overflow retried inside the call) until three
+#     reads in a row show less than 10 % growth;
+#   * check_async_errors() before optimizer.step() reads every outstanding word (the forwards' words arrive while their backward
+#     kernels are still queued: the wait costs the GPU nothing) and raises -- dgr_amd.slam's loops and examples/mapping.py do.
+_unsettled = {}        # key -> strict forwards still to run
+_GROWTH_STRICT, _SETTLED_READS = 1.25, 3
+
+
+def _note_growth(key, prev, s, capacity_used=None):
+    grew = prev > 0 and s[0] > _GROWTH_STRICT * prev
+    near = capacity_used is not None and s[0] > 0.8 * capacity_used
+    if s[1] or grew or near:
+        _unsettled[key] = _SETTLED_READS
+    elif key in _unsettled and prev > 0 and s[0] <= 1.1 * prev:
+        _unsettled[key] -= 1
+        if _unsettled[key] <= 0:
+            del _unsettled[key]
+
+
+def _strict_read(key, cap, rendered):
+    """A strict forward returned its exact count (and retried an overflow inside the call)."""
+    last = _last_status.get(key)
+    if _sync_mode() == "lazy":
+        _note_growth(key, last[0] if last else 0, (rendered, 0, 0, 0))
+        _last_status[key] = [rendered, 0, 0, last[3] if last else 0]
+    _capacity_cache[key] = max(cap, rendered)
+
+
 def _check_oldest():
     ticket, key = _pending_status.pop(0)
     buf = (C.c_int * 4)()
     _check(_capi.load().dgr_status_poll(ticket, 1, buf))  # waits for that forward only
     s = list(buf)
+    prev = _last_status.get(key, (0, 0, 0, 0))[0]
+    _note_growth(key, prev, s, capacity_used=int(_capacity_cache.get(key, 0) * 1.5) + 4096)
     _capacity_cache[key] = max(_capacity_cache.get(key, 0), s[0])
     _last_status[key] = s
     if s[2]:
@@ -412,7 +448,7 @@ class _CompiledC:
                 _capture_keepalive.append(status)
             rendered = _capacity_cache[key]
         elif mode == 1:
-            _capacity_cache[key] = max(cap, rendered)
+            _strict_read(key, cap, rendered)
         return (rendered, color, depth, median, var, alpha, radii, geom, binning, img, unc, px)
 
     @staticmethod
@@ -454,7 +490,10 @@ def _binning_policy(key, P):
     if _sync_mode() == "lazy" and cap > 0:
         while len(_pending_status) > _LAZY_DEPTH and not torch.cuda.is_current_stream_capturing():
             _check_oldest()  # status words of earlier calls have long completed: no stall
-        return 2, int(cap * 1.5) + 4096, cap
+        if key not in _unsettled or torch.cuda.is_current_stream_capturing():
+            return 2, int(cap * 1.5) + 4096, cap
+        # an unsettled shape (above): strict forwards, which also keep the count history going
+        return 1, int(cap * 1.5) + 4096, cap
     return 1, (int(cap * 1.25) + 4096 if cap else 4 * P + 4096), cap
 
 
@@ -478,7 +517,7 @@ def _rasterize_compiled(means3D, means2D, sh, colors_precomp, opacities, scales,
             _captured_status.append(weakref.ref(status))
             _capture_keepalive.append(status)
     elif mode == 1:
-        _capacity_cache[key] = max(cap, rendered)
+        _strict_read(key, cap, rendered)
     return tuple(out)
 
 
@@ -555,6 +594,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = raster_settings
         ctx.num_rendered = num_rendered
+        ctx.dgr_options = _capi.load().dgr_thread_options_effective()  # the backward runs under the forward's options
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, viewmatrix, radii, sh,
                               geomBuffer, binningBuffer, imgBuffer, opacity_map, gt_depth)
         # Four of the eight outputs (radii, opacity_map, gau_uncertainty, gau_related_pixels) have no gradient input in
@@ -610,17 +650,18 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings.track_off,
                 raster_settings.map_off)
 
-        if raster_settings.debug:
-            cpu_args = cpu_deep_copy_tuple(args)
-            try:
-                out = _C.rasterize_gaussians_backward(*args)
-            except Exception as ex:
-                torch.save(cpu_args, "snapshot_bw.dump")
-                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
-                raise ex
-        else:
-            # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp): tracking needs none
-            out = _C.rasterize_gaussians_backward(*args, need_gaussian_grads=any(ctx.needs_input_grad[:8]))
+        with _capi.under_options(ctx.dgr_options):  # (the autograd engine may run this on a thread of its own)
+            if raster_settings.debug:
+                cpu_args = cpu_deep_copy_tuple(args)
+                try:
+                    out = _C.rasterize_gaussians_backward(*args)
+                except Exception as ex:
+                    torch.save(cpu_args, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                    raise ex
+            else:
+                # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp): tracking needs none
+                out = _C.rasterize_gaussians_backward(*args, need_gaussian_grads=any(ctx.needs_input_grad[:8]))
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations, grad_viewmatrix) = out
         # reference: torch.sum(grad_viewmatrix, dim=0) over a [H*W,4,4] buffer (__init__.py:160-161);

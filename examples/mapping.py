@@ -62,7 +62,7 @@ class MapModel:
 def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None, graph=False, fused=False):
     """Returns (losses of the first and last iteration, model, seconds per iteration).  graph=True records the whole
     iteration (renders, losses, backward passes, statistics, Adam) into one hipGraph after three eager iterations."""
-    from dgr_amd import slam
+    from dgr_amd import light, slam
     from dgr_amd.optim import SparseAdam, add_densification_stats
     from dgr_amd.synth import make_scene
 
@@ -107,6 +107,8 @@ def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None, gr
         for k in range(keyframes):
             add_densification_stats(pts[k], out["radii"][k], pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)
         torch.amax(out["radii"], dim=0, out=seen)
+        if not graph:  # lazy status mode: every outstanding forward reports before the step (an overflowed one raises here)
+            light.check_async_errors()
         opt.step(visible=seen)
         return losses[0] / keyframes   # (the batch loss is the sum over the keyframes)
 
@@ -128,6 +130,8 @@ def mapping_loop(dev, P, W, H, keyframes, iters, views_in_flight=3, log=None, gr
             add_densification_stats(out["viewspace_points"].grad, out["radii"], pc.xyz_gradient_accum, pc.denom,
                                     pc.max_radii2D)
             torch.maximum(seen, out["radii"], out=seen)
+        if not graph:
+            light.check_async_errors()
         opt.step(visible=seen)
         return torch.stack(losses).mean()
 

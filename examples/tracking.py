@@ -35,7 +35,7 @@ def main():
     if args.graph or args.fused:
         # a blocking status read cannot be captured, and a tracking loop has no use for num_rendered on the host: no host wait
         os.environ.setdefault("DGR_SYNC_MODE", "lazy") if not args.graph else os.environ.__setitem__("DGR_SYNC_MODE", "lazy")
-    from dgr_amd import slam
+    from dgr_amd import light, slam
     from dgr_amd.multiview import CapturedStep
     from dgr_amd.synth import camera, make_scene
     from test_slam_render import Model, rot_to_quat
@@ -83,6 +83,8 @@ def main():
         else:
             loss = (out["render"] - obs_c).abs().mean() + 0.5 * (out["depth"] - obs_d).abs().mean()
         loss.backward()
+        if not args.graph:  # lazy status mode: every outstanding forward reports before the step (an overflowed one raises here)
+            light.check_async_errors()
         opt.step()
         return loss.detach()
 

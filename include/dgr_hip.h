@@ -304,6 +304,20 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
 int dgr_set_option(const char* name, int value);
 int dgr_get_option(const char* name);
 
+/* Per-THREAD values of the options that change what a call computes -- "alpha_mode" (and its older name "fast_alpha"),
+ * "tight_cull", "deterministic_grads" -- overriding the process-wide ones above for the calling thread's next calls (value < 0:
+ * inherit again).  A tracker and a mapper thread of one process hold different settings this way, and nothing a thread sets
+ * reaches launches that are already queued: every entry point reads its options once, when it is called.  (The reference has
+ * no options; its one compile-time choice is the variant.)  dgr_get_thread_option = the value the calling thread's next call
+ * uses.  dgr_thread_options_effective() packs the three (each field value + 1: bits 0-3 alpha_mode, 4-7 tight_cull, 8-11
+ * deterministic_grads) and dgr_thread_options_swap(word) installs such a word as the thread's overrides (field 0 = inherit;
+ * word < 0: only read) and returns the previous one -- what an autograd binding uses to run a backward, on whatever thread the
+ * engine picks, under its forward's options. */
+int dgr_set_thread_option(const char* name, int value);
+int dgr_get_thread_option(const char* name);
+int dgr_thread_options_effective(void);
+int dgr_thread_options_swap(int word);
+
 /* ---- work shared by the views of a batch ----
  * The 3D covariance depends on scale and rotation only.  dgr_cov3d_forward evaluates computeCov3D (cr/forward.cu:118-152)
  * once -- bit-identical to what the forward would compute per view -- for use as `cov3D_precomp` of every view of the batch;

@@ -93,3 +93,42 @@ def test_batch_entry_points_reject_bad_view_counts_before_touching_the_gpu():
     assert lib.dgr_get_option(b"batch_order") == 0
     assert lib.dgr_set_option(b"batch_order", 1) == 0 and lib.dgr_get_option(b"batch_order") == 1
     assert lib.dgr_set_option(b"batch_order", 0) == 0
+
+
+def test_thread_options_override_the_process_wide_ones_per_thread():
+    """include/dgr_hip.h: dgr_set_thread_option / dgr_thread_options_swap -- host-side state only, no GPU needed."""
+    import threading
+    lib = _capi.load()
+    assert lib.dgr_get_option(b"alpha_mode") == 0 and lib.dgr_get_thread_option(b"alpha_mode") == 0
+    seen = {}
+
+    def other():
+        seen["before"] = lib.dgr_get_thread_option(b"alpha_mode")
+        with _capi.thread_options(alpha_mode=2, deterministic_grads=1):
+            seen["inside"] = (lib.dgr_get_thread_option(b"alpha_mode"), lib.dgr_get_thread_option(b"deterministic_grads"))
+        seen["after"] = lib.dgr_get_thread_option(b"alpha_mode")
+
+    with _capi.thread_options(alpha_mode=1, tight_cull=1):
+        assert lib.dgr_get_thread_option(b"alpha_mode") == 1 and lib.dgr_get_thread_option(b"tight_cull") == 1
+        assert lib.dgr_get_thread_option(b"fast_alpha") == 1
+        assert lib.dgr_get_option(b"alpha_mode") == 0 and lib.dgr_get_option(b"tight_cull") == 0   # process-wide: untouched
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        word = lib.dgr_thread_options_effective()
+        assert (word & 15) - 1 == 1 and ((word >> 4) & 15) - 1 == 1 and ((word >> 8) & 15) - 1 == 0
+        with _capi.thread_options(alpha_mode=0):                      # nests
+            assert lib.dgr_get_thread_option(b"alpha_mode") == 0 and lib.dgr_get_thread_option(b"tight_cull") == 1
+        assert lib.dgr_get_thread_option(b"alpha_mode") == 1
+    assert seen == {"before": 0, "inside": (2, 1), "after": 0}         # the other thread never saw this thread's values
+    assert lib.dgr_get_thread_option(b"alpha_mode") == 0 and lib.dgr_get_thread_option(b"tight_cull") == 0
+    # a forward's snapshot installed around a backward on another thread, then removed
+    prev = lib.dgr_thread_options_swap(word)
+    assert lib.dgr_get_thread_option(b"alpha_mode") == 1 and lib.dgr_get_thread_option(b"tight_cull") == 1
+    lib.dgr_thread_options_swap(prev)
+    assert lib.dgr_get_thread_option(b"alpha_mode") == 0
+    assert lib.dgr_set_thread_option(b"lds_count", 1) != 0            # not a per-call option
+    with pytest.raises(ValueError):
+        with _capi.thread_options(alpha_mode=7):
+            pass
+    assert lib.dgr_get_thread_option(b"alpha_mode") == 0
