@@ -530,7 +530,10 @@ def main():
                        "autograd_engine_thread": torch.autograd.is_multithreading_enabled(),
                        "tile_schedule": {0: "never", 1: "always", 2: "by the frame (skipped on even frames)"}.get(_capi.get_option("tile_schedule")),
                        "views_in_flight": K, "ms_per_view_one_stream": serial_ms,
-                       "ms_per_view_strict_one_stream": strict_serial_ms, "views_per_step": max(1, Vb),
+                       "ms_per_view_strict_one_stream": strict_serial_ms,
+                       # which binding ran (the per-step figures depend on it): the compiled autograd node with raw TensorImpl
+                       # output views (1), with at::from_blob windows (0), or the ctypes binding (None)
+                       "binding": {"compiled": light._C is light._CompiledC, "raw_views": (light._CompiledC.ext.raw_views() if light._CompiledC.ext is not None else None)}, "views_per_step": max(1, Vb),
                        "ms_per_view": 1e3 * elapsed / args.steps / max(1, Vb), "hipgraph_replay": bool(args.graph),
                        "binning": "two-level segment binning (csrc/segment_binning.hip)" if _capi.get_option("lds_count") else "global tile counters (csrc/binning.hip)",
                        "pair_evals_per_view": pair_evals,

@@ -134,6 +134,9 @@ struct StatusSlot {
     int W = 0, H = 0, P = 0;     // the forward that took the arm (key of the schedule hint below)
     hipStream_t stream = nullptr;  // ... and the stream its kernels were enqueued on (dgr_status_poll watches it while it waits)
     bool enqueued = false;         // the forward's blend kernel -- which delivers the word -- has been enqueued
+    bool quarantined = false;      // a poll gave this slot up (timeout, stream error) while its forward may still be queued: the
+                                   // blend kernel can still write words 0-5 and its tag here, so the slot is not handed out again
+                                   // before that stream has drained (status_slot_acquire)
 };
 std::mutex g_status_mu;
 std::vector<StatusSlot> g_status_slots;
@@ -1214,8 +1217,17 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
 static long status_slot_acquire() {
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    for (size_t i = 0; i < g_status_slots.size(); i++)
-        if (!g_status_slots[i].busy && g_status_slots[i].device == dev) return (long)i;
+    for (size_t i = 0; i < g_status_slots.size(); i++) {
+        StatusSlot& c = g_status_slots[i];
+        if (c.busy || c.device != dev) continue;
+        if (c.quarantined) {  // (given up by a poll: reusable once the stream its forward was queued on has drained)
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(c.stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) continue;  // a query would invalidate the capture
+            if (hipStreamQuery(c.stream) != hipSuccess) { (void)hipGetLastError(); continue; }
+            c.quarantined = false;
+        }
+        return (long)i;
+    }
     StatusSlot sl;
     HIP_TRY(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&sl.pinned, 8 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1288,12 +1300,15 @@ int dgr_status_poll(long ticket, int wait, int* host_status4) {
             // issued, it never arrives -- so every millisecond the stream itself is asked: an error ends the wait with that error, a
             // stream that has finished all its work without the tag having been written ends it too, and so does a hard limit
             // (DGR_STATUS_TIMEOUT_MS, default 30 000).
-            static const long limit_ms = [] { const char* e = getenv("DGR_STATUS_TIMEOUT_MS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 30000L; }();
+            // (DGR_STATUS_TIMEOUT_MS = 0: no limit -- profiler replays and collectives' stragglers can legitimately hold a queue
+            //  for longer than any default)
+            static const long limit_ms = [] { const char* e = getenv("DGR_STATUS_TIMEOUT_MS"); return e ? (atol(e) > 0 ? atol(e) : 0L) : 30000L; }();
             const auto t0 = std::chrono::steady_clock::now();
             auto next_query = t0 + std::chrono::milliseconds(1);
-            auto release = [&](const char* why) {
+            auto release = [&](const char* why, bool quarantine) {
                 std::lock_guard<std::mutex> lk(g_status_mu);
                 g_status_slots[(size_t)ticket].busy = false;
+                g_status_slots[(size_t)ticket].quarantined = quarantine;  // the forward may still be queued and write the slot later
                 g_last_error = why;
                 return DGR_ERR_HIP;
             };
@@ -1303,19 +1318,23 @@ int dgr_status_poll(long ticket, int wait, int* host_status4) {
                 if (now < next_query) continue;
                 next_query = now + std::chrono::milliseconds(1);
                 if (enqueued) {
-                    const hipError_t e = hipStreamQuery(stream);
-                    if (e == hipSuccess) {  // everything enqueued on the stream has completed: the tag is there, or it never will be
-                        if (tag_here()) break;
-                        return release("dgr_status_poll: the forward's stream is idle and its status word never arrived (was the forward "
-                                       "issued while the stream was being captured?)");
-                    }
-                    if (e != hipErrorNotReady) {
-                        (void)release("");
-                        return hip_fail(e, "dgr_status_poll: hipStreamQuery on the forward's stream");
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    const bool capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+                    if (!capturing) {  // (a query on a capturing stream invalidates the capture)
+                        const hipError_t e = hipStreamQuery(stream);
+                        if (e == hipSuccess) {  // everything enqueued on the stream has completed: the tag is there, or it never will be
+                            if (tag_here()) break;
+                            return release("dgr_status_poll: the forward's stream is idle and its status word never arrived (was the forward "
+                                           "issued while the stream was being captured?)", false);
+                        }
+                        if (e != hipErrorNotReady) {
+                            (void)release("", true);
+                            return hip_fail(e, "dgr_status_poll: hipStreamQuery on the forward's stream");
+                        }
                     }
                 }
-                if (now - t0 > std::chrono::milliseconds(limit_ms))
-                    return release("dgr_status_poll: timed out waiting for the forward's status word (DGR_STATUS_TIMEOUT_MS)");
+                if (limit_ms > 0 && now - t0 > std::chrono::milliseconds(limit_ms))
+                    return release("dgr_status_poll: timed out waiting for the forward's status word (DGR_STATUS_TIMEOUT_MS; 0 = no limit)", true);
             }
         }
         const volatile int* w = pinned;

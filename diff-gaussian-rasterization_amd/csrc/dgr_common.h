@@ -151,7 +151,9 @@ struct BinningView {
     // segment binning (segment_binning.hip): one PAIR per (Gaussian, tile row, 16-tile segment) it touches
     uint64_t* pair_keys;   // [cap] (depth bits << 32 | gaussian id), grouped by producing workgroup, then by segment
     uint8_t* pair_cov;     // [cap] columns covered inside the segment: first | last << 4  (shares the bytes of `ranks`:
-                           //       a forward uses either the global-atomic count or the segment binning)
+                           //       a forward uses either the global-atomic count or the segment binning).  CLOBBERED by the
+                           //       light forward's blend, which keeps its contribution tags per half of a quadrant in these
+                           //       bytes for the backward (render_common.h: half_tags / stage_tagged): part of a view's state
     size_t bytes;
 };
 __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {

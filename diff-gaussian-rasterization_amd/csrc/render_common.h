@@ -122,6 +122,9 @@ __device__ __forceinline__ unsigned stage_one(S& s, int slot, uint32_t gid, cons
         // more pairs reach the exact test, which decides as before --
         // and the record's third word becomes four spare BYTES: byte w = "some pixel of the LOWER half of quadrant wave w blended
         // this instance" (the upper halves' bytes are the kernel's `hit` words) -- contribution tags per half, free of LDS.
+        // (an infinite opacity has the threshold -inf, whose bits would become a NaN's with the slot in them -- and nothing passes a
+        //  NaN, where the reference blends such a Gaussian at alpha = min(0.99, inf) = 0.99: a finite floor first)
+        lthr = fmaxf(lthr, -3.0e38f);
         lthr = __int_as_float(((__float_as_int(lthr) + 0xFF) & ~0xFF) | slot);
         zword = 0.f;
     }
@@ -171,6 +174,10 @@ __device__ __forceinline__ uint8_t* half_tags(const uint32_t* point_list, const 
 
 // backward staging: returns the entry's tag; untagged entries are not loaded.
 // HALF_CODES (half-wave lists): returns the forward's tag per HALF of a quadrant instead (bit 2 w + h; `tag8` = half_tags()).
+// INVARIANT: *tag8 is read only for an entry whose 4-bit point_list tag is non-zero -- the byte array shares its bytes with the
+// binning's ranks / pair_cov, which the forward's binning leaves there and NOTHING clears: a byte is a tag only where the same
+// forward's blend wrote it, and it wrote it exactly where it also set the 4-bit tag (render_light.hip: flush_slot).  Whoever keeps a
+// view's state between forward and backward must treat ranks / pair_cov as clobbered by the blend (BinningView, dgr_common.h).
 template <int AM, bool HALF_CODES = false, class S>
 __device__ __forceinline__ unsigned stage_tagged(S& s, int slot, uint32_t entry, const float4* __restrict__ rec,
                                                  const uint8_t* __restrict__ tag8 = nullptr) {

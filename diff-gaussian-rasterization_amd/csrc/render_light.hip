@@ -562,8 +562,13 @@ __global__ void __launch_bounds__(256) det_gather_kernel(int P, const ushort4* _
     uint32_t n = rect_tiles(rect[g]);
     if (n == 0u) return;
     const uint32_t first = goff[g];
-    if (first >= R) return;
-    n = min(n, R - first);
+    // R (the caller's: a lazy forward's capacity, or a wrong value) smaller than the rectangles' total: this Gaussian's rows were
+    // not all written -- a truncated sum would be a plausible gradient, so the row is NaN instead (and every gradient of the
+    // Gaussian with it: preprocess_bwd reads the row)
+    if (first >= R || n > R - first) {
+        acc[(size_t)g * DGR_ACC_STRIDE + comp] = __builtin_nanf("");
+        return;
+    }
     const float* r = rows + (size_t)first * DGR_ACC_STRIDE + comp;
     float v = 0.f;
     for (uint32_t i = 0; i < n; i++) v += r[(size_t)i * DGR_ACC_STRIDE];

@@ -159,8 +159,10 @@ std::atomic<int> g_raw_views{-1};  // -1: not decided yet, 0: dispatcher views, 
 inline bool decide_raw_views(const Tensor& base, size_t byte_off, c10::IntArrayRef sizes, at::ScalarType dt) {
     const char* e = getenv("DGR_RAW_VIEWS");
     if (e && e[0] == '0') return false;
-#if !(defined(TORCH_VERSION_MAJOR) && TORCH_VERSION_MAJOR == 2 && TORCH_VERSION_MINOR == 10)
-    if (!(e && e[0] == '1')) return false;  // a PyTorch this was not validated on
+    // validated on PyTorch 2.10; later releases take the self-check below (which the first view of every process runs anyway),
+    // earlier ones the dispatcher's windows unless DGR_RAW_VIEWS=1 asks for the check
+#if !(defined(TORCH_VERSION_MAJOR) && (TORCH_VERSION_MAJOR > 2 || (TORCH_VERSION_MAJOR == 2 && TORCH_VERSION_MINOR >= 10)))
+    if (!(e && e[0] == '1')) return false;
 #endif
     bool ok = false;
     try {
@@ -988,5 +990,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("status_poll", &status_poll);
     // which kind of views the outputs are: 1 = raw TensorImpl windows, 0 = dispatcher views, -1 = not decided yet (no view made)
     m.def("raw_views", [] { return g_raw_views.load(); });
+    // TEST-ONLY (tests/test_hip_binding_guard.py): not synchronised with forwards in flight on other threads
     m.def("set_raw_views", [](long v) { g_raw_views.store(v < 0 ? -1 : v ? 1 : 0); });
 }

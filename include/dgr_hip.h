@@ -211,7 +211,10 @@ int dgr_status_poll(long ticket, int wait, int* host_status4);
  * A blocking poll (wait != 0) of an armed ticket cannot spin for ever: every millisecond it asks the forward's stream -- a HIP
  * error there ends the wait with DGR_ERR_HIP, and so does a stream that has finished all its work without the word having
  * arrived (a forward issued into a capturing stream, a faulted kernel) -- and it gives up after DGR_STATUS_TIMEOUT_MS
- * (environment, default 30 000).  The ticket is released on every such return. */
+ * (environment, default 30 000; 0 = no limit: profiler replays and a collective's stragglers can hold a queue for longer).  The
+ * stream is not asked while it records a hipGraph (a query would invalidate the capture).  The ticket is released on every such
+ * return; after a timeout or a stream error its slot stays out of use until that stream has drained (the forward may still be
+ * queued and would write into a slot that had been handed to another forward meanwhile). */
 long dgr_status_arm(void);
 int dgr_stream_is_capturing(void* stream);
 int dgr_early_status_arm(void);
