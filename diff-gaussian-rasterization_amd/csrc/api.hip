@@ -889,10 +889,12 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
                       float* dgc_invcovs_dT, float* dL_dview, float* dL_dgau_depth, float* ddepth_dndcs,
                       float* ddepth_dinvcovs, const float* gt_depth, const float* dL_duncertainties, char* scratch,
                       size_t scratch_bytes) {
-    (void)R; (void)colors_precomp; (void)dpixel_dgc; (void)gau_id_list; (void)pix_id_list; (void)dgc_dCam_position;
+    (void)colors_precomp; (void)dpixel_dgc; (void)gau_id_list; (void)pix_id_list; (void)dgc_dCam_position;
     (void)dpixel_dndcs; (void)dgndcs_dviewmatrix; (void)dpixel_dinvcovs; (void)dgc_invcovs_dT; (void)ddepth_dndcs;
     (void)ddepth_dinvcovs;
-    if (opt_det_grads()) { g_last_error = "deterministic_grads: the light variant's one-view backward only"; return DGR_ERR_BAD_ARGUMENT; }
+    const bool det = opt_det_grads() != 0;  // (round 9: the scheme of the light variant, csrc/render_light.hip: DET)
+    if (det && opt_alpha_mode() != 0) { g_last_error = "deterministic_grads needs alpha_mode 0"; return DGR_ERR_BAD_ARGUMENT; }
+    if (det && R <= 0) { g_last_error = "deterministic_grads: the backward needs R >= num_rendered (it sizes the instance-major row buffer)"; return DGR_ERR_BAD_ARGUMENT; }
     hipStream_t st = (hipStream_t)stream;
     const bool scratch_clean = g_scratch_clean_armed;
     g_scratch_clean_armed = false;
@@ -901,8 +903,8 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
         HIP_TRY(hipMemsetAsync(dL_dview, 0, 16 * 4, st));
         return DGR_OK;
     }
-    if (scratch_bytes < dgr_light_backward_scratch_bytes(P, width, height) || !scratch) {
-        g_last_error = "backward scratch too small";
+    if (scratch_bytes < dgr_light_backward_scratch_bytes_r(P, width, height, R) || !scratch) {
+        g_last_error = det ? "backward scratch too small (deterministic_grads: dgr_light_backward_scratch_bytes_r)" : "backward scratch too small";
         return DGR_ERR_BAD_ARGUMENT;
     }
     // (the 3D covariance is not kept by the forward: the backward re-forms it from scale and rotation -- the SAME tensors the
@@ -914,15 +916,24 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     dgr::BackwardScratch sc = dgr::carve_backward_scratch(scratch, P);
     const int gx = dgr::tiles_x(width), gy = dgr::tiles_y(height);
     if (!scratch_clean) { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(sc.acc, sc.zero_bytes, st)); }
+    DetScratch ds{nullptr, nullptr, nullptr, 0};
+    if (det) {
+        ds = carve_det_scratch(scratch, P, R);
+        { ScopedStage t(ST_ZERO, st); HIP_TRY(dgr::launch_zero_fill(ds.rows, sizeof(float) * DGR_ACC_STRIDE * (size_t)R, st)); }
+        HIP_TRY(dgr::launch_det_offsets(P, geom.rect, ds.blk, geom.goff, st));
+    }
 
     dgr::RenderBwdFullArgs r{};
     r.W = width; r.H = height; r.grid_x = gx; r.grid_y = gy;
     r.sched = img.tile_sched; r.ranges = img.ranges; r.sched_flag = img.cursor + 3; r.point_list = (const uint32_t*)binning_buffer; r.rec = geom.rec; r.bg = background;
     r.gt_depth = gt_depth; r.final_T = img.final_T; r.n_contrib = img.n_contrib; r.first_contrib = img.first_contrib;
     r.dL_dpix = dL_dpix; r.dL_depths = dL_depths; r.dL_duncertainties = dL_duncertainties; r.acc = sc.acc;
-    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_full(r, opt_alpha_mode(), st)); }
+    if (det) { r.det_rows = ds.rows; r.det_rect = geom.rect; r.det_goff = geom.goff; r.det_R = (uint32_t)R; }
+    { ScopedStage t(ST_RENDER_BWD, st); HIP_TRY(dgr::launch_render_bwd_full(r, opt_alpha_mode(), st, det)); }
+    if (det) HIP_TRY(dgr::launch_det_gather(P, geom.rect, geom.goff, ds.rows, (uint32_t)R, sc.acc, st));
 
     dgr::PreprocessBwdArgs b{};
+    b.det_pose = det ? ds.pose : nullptr;
     b.P = P; b.D = D; b.M = M; b.means3D = means3D; b.radii = radii ? radii : geom.radii; b.shs = shs; b.scales = scales;
     b.rotations = rotations; b.scale_modifier = scale_modifier; b.cov3D_precomp = cov3D_precomp; b.view = viewmatrix;
     b.proj = projmatrix; b.campos = campos; b.perspec = perspec_matrix; b.tan_fovx = tan_fovx; b.tan_fovy = tan_fovy;
@@ -1030,7 +1041,8 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
                              int track_off, int map_off) {
     (void)colors_precomp;
     hipStream_t st = (hipStream_t)stream;
-    if (opt_det_grads()) { g_last_error = "deterministic_grads: the light variant's one-view backward only"; return DGR_ERR_BAD_ARGUMENT; }
+    const bool det = opt_det_grads() != 0 && !(track_off && map_off);  // (round 9: per view the scheme of the one-view backward)
+    if (det && opt_alpha_mode() != 0) { g_last_error = "deterministic_grads needs alpha_mode 0"; return DGR_ERR_BAD_ARGUMENT; }
     if (n_views < 1 || n_views > DGR_MAX_BATCH_VIEWS || !views) { g_last_error = "1 .. DGR_MAX_BATCH_VIEWS views per batch"; return DGR_ERR_BAD_ARGUMENT; }
     if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
     for (int v = 0; v < n_views; v++)
@@ -1040,9 +1052,10 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
         for (int v = 0; v < n_views; v++) HIP_TRY(hipMemsetAsync(views[v].dL_dview, 0, 16 * 4, st));
         return DGR_OK;
     }
-    const size_t need = dgr_light_backward_scratch_bytes(P, width, height);
     for (int v = 0; v < n_views; v++) {
         const dgr_light_view_grad& w = views[v];
+        if (det && w.num_rendered <= 0) { g_last_error = "deterministic_grads: every view needs num_rendered (it sizes the view's row buffer)"; return DGR_ERR_BAD_ARGUMENT; }
+        const size_t need = dgr_light_backward_scratch_bytes_r(P, width, height, w.num_rendered);
         if (!w.scratch || w.scratch_bytes < need) { g_last_error = "backward scratch too small"; return DGR_ERR_BAD_ARGUMENT; }
         if (!w.geometry_buffer || !w.image_buffer || !w.viewmatrix || !w.projmatrix || !w.cam_pos || !w.perspec_matrix || !w.alphas ||
             !w.dL_dpix || !w.dL_dpix_depth || !w.dL_dpix_median_depth || !w.dL_dpix_depth_var) {
@@ -1076,8 +1089,17 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
         r.gt_depth = w.gt_depth; r.alphas = w.alphas; r.n_contrib = img.n_contrib; r.dL_dpix = w.dL_dpix;
         r.dL_dpix_depth = w.dL_dpix_depth; r.dL_dpix_median = w.dL_dpix_median_depth; r.dL_dpix_var = w.dL_dpix_depth_var;
         r.means3D = means3D; r.view = w.viewmatrix; r.acc = sc.acc; r.track_off = track_off; r.map_off = map_off;
+        DetScratch ds{nullptr, nullptr, nullptr, 0};
+        if (det) {
+            ds = carve_det_scratch(w.scratch, P, w.num_rendered);
+            { ScopedStage t(ST_ZERO, sv); HIP_TRY(dgr::launch_zero_fill(ds.rows, sizeof(float) * DGR_ACC_STRIDE * (size_t)w.num_rendered, sv)); }
+            HIP_TRY(dgr::launch_det_offsets(P, geom.rect, ds.blk, geom.goff, sv));
+            r.det_rows = ds.rows; r.det_rect = geom.rect; r.det_goff = geom.goff; r.det_R = (uint32_t)w.num_rendered;
+        }
         { ScopedStage t(ST_RENDER_BWD, sv); HIP_TRY(dgr::launch_render_bwd_light(r, opt_alpha_mode(), sv)); }
+        if (det) HIP_TRY(dgr::launch_det_gather(P, geom.rect, geom.goff, ds.rows, (uint32_t)w.num_rendered, sc.acc, sv));
         dgr::BwdViewPart& q = bb.v[v];
+        q.det_pose = det ? ds.pose : nullptr;
         q.view = w.viewmatrix; q.proj = w.projmatrix; q.campos = w.cam_pos; q.perspec = w.perspec_matrix;
         q.radii = w.radii ? w.radii : geom.radii; q.geom = geom; q.acc = sc.acc; q.dL_dmean2D = w.dL_dmean2D;
         q.pose_part = sc.pose_part; q.ticket = sc.ticket; q.dL_dview = w.dL_dview;

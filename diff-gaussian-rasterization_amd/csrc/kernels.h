@@ -150,6 +150,7 @@ struct BwdViewPart {
     double* pose_part;
     uint32_t* ticket;
     float* dL_dview;      // [16]
+    double* det_pose;     // deterministic gradients: this view's [blocks, 12] per-block pose partials (NULL otherwise; all views alike)
 };
 struct PreprocessBwdBatchArgs {
     PreprocessBwdArgs base;  // the per-view members unused; the dense outputs receive the SUM over the views
@@ -240,6 +241,11 @@ struct RenderBwdFullArgs {
     const float* dL_depths;
     const float* dL_duncertainties;
     float* acc;  // [P,16]
+    // deterministic gradients (render_light.hip: DET): the finished row of a (tile, Gaussian) pair is stored to det_rows instead
+    float* det_rows;
+    const ushort4* det_rect;
+    const uint32_t* det_goff;
+    uint32_t det_R;
 };
 
 // ---- launchers (each enqueues on `stream` and returns the hipError_t of the launch) ----
@@ -300,7 +306,7 @@ hipError_t launch_tile_schedule(ImageView img, int tiles, hipStream_t stream);
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, hipStream_t stream);
 hipError_t launch_render_bwd_light(const RenderBwdLightArgs& a, int alpha_mode, hipStream_t stream);
 hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hipStream_t stream);
-hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream);
+hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream, bool deterministic = false);
 hipError_t launch_det_offsets(int P, const ushort4* rect, uint32_t* blk, uint32_t* goff, hipStream_t stream);
 hipError_t launch_det_gather(int P, const ushort4* rect, const uint32_t* goff, const float* rows, uint32_t R, float* acc, hipStream_t stream);
 hipError_t launch_half_reduce_test(const float* in, float* r0, float* r1, float* h3, int* slot0, int* slot1, int* comp3, hipStream_t stream);

@@ -923,26 +923,8 @@ __device__ __forceinline__ void pose_block_reduce(const float (&pose)[12], doubl
     pose_finish_if_last((uint32_t)__builtin_amdgcn_readfirstlane((int)t), pose_part, dL_dview, ticket, clear);
 }
 
-// Deterministic form (dgr_set_option("deterministic_grads", 1)): double atomics on the 64 bucket rows arrive in any order, and a
-// double sum depends on its order in the last bit.  Here every block STORES its partial to its own row of `det_pose` and the block
-// that draws the last ticket adds the rows in a fixed order: lane l of wave 0 the rows l, l + 64, ... ascending, then lanes 0..11
-// the 64 lane sums ascending.
-__device__ __forceinline__ void pose_block_reduce_det(const float (&pose)[12], double* det_pose, uint32_t* ticket, float* dL_dview,
-                                                      double (*red)[12], bool clear) {
-    __shared__ double lane_sum[64][12];
-    pose_rows_to_lds(pose, red);
-    __syncthreads();
-    if (threadIdx.x >= 64) return;
-    if (threadIdx.x < 12) {
-        double part = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; r++) part += red[r][threadIdx.x];
-        __hip_atomic_store(det_pose + (size_t)blockIdx.x * 12 + threadIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores are acknowledged before the ticket is taken
-    uint32_t t = 0u;
-    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)t) != gridDim.x - 1) return;
+// the block that drew a view's last ticket adds the per-block partials in a fixed order (wave 0 only)
+__device__ __forceinline__ void pose_finish_det(const double* det_pose, uint32_t* ticket, float* dL_dview, double (*lane_sum)[12], bool clear) {
     {   // (a row's twelve loads in flight together, two rows per trip: one memory round trip per 128 rows, not per value)
         double acc[12];
 #pragma unroll
@@ -973,6 +955,29 @@ __device__ __forceinline__ void pose_block_reduce_det(const float (&pose)[12], d
         if (threadIdx.x < 12) dL_dview[(threadIdx.x / 3) * 4 + threadIdx.x % 3] = out;
         if (threadIdx.x < 4) dL_dview[threadIdx.x * 4 + 3] = 0.0f;
     }
+}
+
+// Deterministic form (dgr_set_option("deterministic_grads", 1)): double atomics on the 64 bucket rows arrive in any order, and a
+// double sum depends on its order in the last bit.  Here every block STORES its partial to its own row of `det_pose` and the block
+// that draws the last ticket adds the rows in a fixed order: lane l of wave 0 the rows l, l + 64, ... ascending, then lanes 0..11
+// the 64 lane sums ascending.
+__device__ __forceinline__ void pose_block_reduce_det(const float (&pose)[12], double* det_pose, uint32_t* ticket, float* dL_dview,
+                                                      double (*red)[12], bool clear) {
+    __shared__ double lane_sum[64][12];
+    pose_rows_to_lds(pose, red);
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    if (threadIdx.x < 12) {
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) part += red[r][threadIdx.x];
+        __hip_atomic_store(det_pose + (size_t)blockIdx.x * 12 + threadIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores are acknowledged before the ticket is taken
+    uint32_t t = 0u;
+    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)__builtin_amdgcn_readfirstlane((int)t) != gridDim.x - 1) return;
+    pose_finish_det(det_pose, ticket, dL_dview, lane_sum, clear);
 }
 
 // Fused per-Gaussian backward.  Order of the dL_dmean3D accumulation follows the reference's kernel
@@ -1275,6 +1280,28 @@ __global__ void __launch_bounds__(256, DGR_BWD_BATCH_WAVES) preprocess_bwd_batch
     // (issued back to back: one L2 round trip for the batch) and finishes the views whose last block this is.
     __syncthreads();
     if (threadIdx.x >= 64) return;
+    if (b.v[0].det_pose) {
+        // deterministic gradients: every view's partial of this block STORED to the view's own [blocks, 12] array, the views'
+        // tickets drawn together, and whoever drew a view's last one adds its rows in a fixed order (pose_block_reduce_det)
+        __shared__ double lane_sum[64][12];
+#pragma unroll 1
+        for (int v = 0; v < V; v++)
+            if (threadIdx.x < 12) {
+                double part = 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; r++) part += red[v][r][threadIdx.x];
+                __hip_atomic_store(b.v[v].det_pose + (size_t)blockIdx.x * 12 + threadIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t td = 0u;
+#pragma unroll 1
+        for (int v = 0; v < V; v++)
+            if ((int)threadIdx.x == v) td = __hip_atomic_fetch_add(b.v[v].ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll 1
+        for (int v = 0; v < V; v++)
+            if ((uint32_t)__builtin_amdgcn_readlane((int)td, v) == gridDim.x - 1) pose_finish_det(b.v[v].det_pose, b.v[v].ticket, b.v[v].dL_dview, lane_sum, false);
+        return;
+    }
 #pragma unroll 1
     for (int v = 0; v < V; v++) pose_add_partial(red[v], b.v[v].pose_part);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -138,19 +138,28 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
 // ================================================================================ backward
 constexpr int NACC_FULL = 15;
 
-constexpr int BWD_NB = 128;          // list positions staged per batch (occupancy: see render_light.hip)
-constexpr int BWD_LD = BWD_NB + 1;
+// list positions staged per batch (occupancy: see render_light.hip).  DET (dgr_set_option("deterministic_grads", 1); round 9 for this
+// variant): one accumulator plane per quadrant wave, plain stores, the planes added in wave order, the finished row of a
+// (tile, Gaussian) pair STORED to its own row of an instance-major buffer that det_gather_kernel adds up per Gaussian in ascending
+// order -- render_light.hip has the scheme; four planes are four times the accumulators, hence 64 positions per batch.
+template <bool DET>
 struct StagedBwdFull {
-    StagedT<BWD_NB, uint32_t> f;
-    float acc[NACC_FULL * BWD_LD];
+    static constexpr int NB = DET ? 64 : 128;
+    static constexpr int LD = NB + 1;
+    static constexpr int PLANE = NACC_FULL * LD;
+    StagedT<NB, uint32_t> f;
+    float acc[(DET ? 4 : 1) * PLANE];
+    uint32_t inst[DET ? NB : 1];
     int max_last;
     uint64_t exptab[32];  // ALPHA_GLIBC: exact_math.h
 };
 
-template <int AM>
+template <int AM, bool DET = false>
 __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullArgs a) {
-    __shared__ StagedBwdFull sb;
-    StagedT<BWD_NB, uint32_t>& s = sb.f;
+    typedef StagedBwdFull<DET> SB;
+    constexpr int BWD_NB = SB::NB, BWD_LD = SB::LD;
+    __shared__ SB sb;
+    StagedT<SB::NB, uint32_t>& s = sb.f;
     const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -202,7 +211,8 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     const int c16 = wave_reduce16d_comp(lane);
     const int my_comp = ((lane & 3) == 0 && c16 < NACC_FULL) ? c16 : -1;
-    float* const my_acc = sb.acc + (my_comp >= 0 ? my_comp : 0) * BWD_LD;  // this lane's accumulator row (column = slot)
+    // this lane's accumulator row (column = slot); DET: in its wave's own plane
+    float* const my_acc = sb.acc + (DET ? wave * SB::PLANE : 0) + (my_comp >= 0 ? my_comp : 0) * BWD_LD;
 
     for (int hi = total; hi > 0; hi -= BWD_NB) {
         const int lo = max(0, hi - BWD_NB);
@@ -210,9 +220,11 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
         __syncthreads();
         unsigned code = 0;
         if (tid < cnt) code = stage_tagged<AM>(s, tid, a.point_list[range.x + lo + tid], a.rec);
+        if (!DET) {  // (DET: a plane's column is written by its wave iff the entry's tag names the wave -- nothing to clear)
 #pragma unroll
-        for (int k = 0; k < NACC_FULL; k++)
-            if (tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
+            for (int k = 0; k < NACC_FULL; k++)
+                if (tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
+        }
         const int n = build_lists(s, code, tid, wave, lane);
         // (the staged record carries 4 * slot: render_common.h, stage_tagged)
         const int rel_last4 = 4 * (last_contributor - lo);
@@ -279,10 +291,32 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
                 g[14] = fq * dy;
                 g[15] = 0.f;
                 const float tot = wave_reduce16d(g);  // (within-row stages first: wave_reduce.h)
-                if (my_comp >= 0) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(my_acc) + j4), tot);
+                if (my_comp >= 0) {
+                    float* const cell = reinterpret_cast<float*>(reinterpret_cast<char*>(my_acc) + j4);
+                    if (DET) *cell = tot; else atomicAdd(cell, tot);
+                }
             }
         }
         __syncthreads();
+        if (DET && tid < BWD_NB) {
+            // the four planes in wave order into plane 0 (a wave whose tag bit is clear never wrote its column), and the pair's row
+            uint32_t row = ~0u;
+            if (code != 0u) {
+#pragma unroll
+                for (int k = 0; k < NACC_FULL; k++) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; w++)
+                        if ((code >> w) & 1u) v += sb.acc[w * SB::PLANE + k * BWD_LD + tid];
+                    sb.acc[k * BWD_LD + tid] = v;
+                }
+                const uint32_t gid = s.id[tid];
+                const ushort4 rc = a.det_rect[gid];
+                row = a.det_goff[gid] + (uint32_t)(ty - (int)rc.y) * (uint32_t)(rc.z - rc.x) + (uint32_t)(tx - (int)rc.x);
+            }
+            sb.inst[tid] = row;
+        }
+        if (DET) __syncthreads();
         // moments -> gradients per staged Gaussian: every "d/d(ndc)" sum is -(a Sx + b Sy) W/2, -(c Sy + b Sx) H/2
         if (code != 0u) {
             constexpr float UN = AlphaPath<AM>::PUNSCALE;  // (undoes the scale of the staged conic)
@@ -301,7 +335,15 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
             sb.acc[9 * BWD_LD + tid] *= __builtin_amdgcn_rcpf(r1.y);
         }
         __syncthreads();
-        flush_acc<NACC_FULL, BWD_LD>(sb.acc, s.id, cnt, a.acc, tid);
+        if (DET) {  // 16 consecutive lanes store one pair's 64-byte row (component 15 stays zero)
+            const int comp = tid & 15;
+            for (int r = tid >> 4; r < cnt; r += 16) {
+                const uint32_t row = sb.inst[r];
+                if (row < a.det_R && comp < NACC_FULL) a.det_rows[(size_t)row * DGR_ACC_STRIDE + comp] = sb.acc[comp * BWD_LD + r];
+            }
+        } else {
+            flush_acc<NACC_FULL, BWD_LD>(sb.acc, s.id, cnt, a.acc, tid);
+        }
     }
 }
 
@@ -317,9 +359,13 @@ hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hi
     }
     return hipGetLastError();
 }
-hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream) {
+hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream, bool deterministic) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
+    if (deterministic) {  // (alpha_mode 0 only: api.hip)
+        launch_blend(render_bwd_full_kernel<ALPHA_REF, true>, dim3(tiles), dim3(256), stream, a);
+        return hipGetLastError();
+    }
     switch (alpha_mode) {
         case ALPHA_FAST: launch_blend(render_bwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
         case ALPHA_GLIBC: launch_blend(render_bwd_full_kernel<ALPHA_GLIBC>, dim3(tiles), dim3(256), stream, a); break;

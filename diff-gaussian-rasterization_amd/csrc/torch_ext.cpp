@@ -606,7 +606,7 @@ std::vector<Tensor> full_backward(const Tensor& background, const Tensor& means3
         for (int i = 0; i < 8; i++) gp[i] = ptr<float>(g[i]);
     }
     Tensor dview = at::empty({4, 4}, at::TensorOptions().dtype(at::kFloat).device(dev));
-    const size_t nscr = up256(dgr_light_backward_scratch_bytes(P, (int)W, (int)H));
+    const size_t nscr = up256(dgr_light_backward_scratch_bytes_r(P, (int)W, (int)H, (int)R));  // (deterministic_grads: + rows per instance)
     void* st = stream_of(dev);
     bool resident = false;
     const Tensor scratch = backward_scratch(dev, st, nscr, &resident);
@@ -903,7 +903,7 @@ std::vector<Tensor> light_backward_batch(const Tensor& background, const Tensor&
                                          const Tensor& dL_dout_var, const Tensor& gt_depths_, const Tensor& sh_, long degree,
                                          const Tensor& campos_, const Tensor& geom, const Tensor& binning, const Tensor& img,
                                          const Tensor& alphas_, const Tensor& perspec_, bool track_off, bool map_off,
-                                         bool need_gaussian_grads, bool need_means2D) {
+                                         bool need_gaussian_grads, bool need_means2D, const std::vector<long>& num_rendered) {
     const c10::Device dev = means3D_.device();
     c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const int P = (int)means3D_.size(0);
@@ -930,7 +930,10 @@ std::vector<Tensor> light_backward_batch(const Tensor& background, const Tensor&
         map_off = true;  // nobody reads the per-Gaussian sums: the blend kernels form the three pose sums only
     }
     Tensor dview = at::empty({V, 4, 4}, f32);
-    const size_t nscr = std::max<size_t>(dgr_light_backward_scratch_bytes(P, (int)W, (int)H), 1);
+    // (deterministic_grads: + 64 bytes per tile instance of the view with the most of them; the views' rows are equally long)
+    long rmax = 0;
+    for (long r : num_rendered) rmax = std::max(rmax, r);
+    const size_t nscr = std::max<size_t>(up256(dgr_light_backward_scratch_bytes_r(P, (int)W, (int)H, (int)rmax)), 256);
     Tensor scratch = at::empty({V, (long long)nscr}, at::TensorOptions().dtype(at::kByte).device(dev));
     dgr_light_view_grad w[DGR_MAX_BATCH_VIEWS];
     for (long v = 0; v < V; v++) {
@@ -938,7 +941,7 @@ std::vector<Tensor> light_backward_batch(const Tensor& background, const Tensor&
                                    row<float>(projs, v), row<float>(campos, v), ptr<float>(perspec), row<float>(alphas, v),
                                    row<float>(gts, v), row<int>(radii, v), row<float>(gC, v), row<float>(gD, v), row<float>(gM, v),
                                    row<float>(gV, v), d2.defined() ? row<float>(d2, v) : nullptr, row<float>(dview, v),
-                                   row_bytes(scratch, v), nscr};
+                                   row_bytes(scratch, v), nscr, (size_t)v < num_rendered.size() ? (int)num_rendered[v] : 0};
     }
     // gp: [1] colors [2] opacity [3] means3D [4] cov3D [5] sh [6] scales [7] rotations
     check(dgr_light_backward_batch(stream_of(dev), (int)V, w, P, (int)degree, M, ptr<float>(bg), (int)W, (int)H, ptr<float>(means3D),

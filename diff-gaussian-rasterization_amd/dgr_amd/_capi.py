@@ -38,7 +38,7 @@ class LightViewGrad(C.Structure):  # dgr_light_view_grad: the per-camera argumen
                 ("projmatrix", _vp), ("cam_pos", _vp), ("perspec_matrix", _vp), ("alphas", _vp), ("gt_depth", _vp),
                 ("radii", _vp), ("dL_dpix", _vp), ("dL_dpix_depth", _vp), ("dL_dpix_median_depth", _vp),
                 ("dL_dpix_depth_var", _vp), ("dL_dmean2D", _vp), ("dL_dview", _vp), ("scratch", _vp),
-                ("scratch_bytes", _sz)]
+                ("scratch_bytes", _sz), ("num_rendered", _i)]
 
 
 MAX_BATCH_VIEWS = 8  # DGR_MAX_BATCH_VIEWS

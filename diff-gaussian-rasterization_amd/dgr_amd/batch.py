@@ -173,13 +173,17 @@ def _forward_batch(bg, means3D, colors, opacity, scales, rotations, scale_modifi
 
 def _backward_batch(bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices, projmatrices,
                     tanfovx, tanfovy, gC, gD, gM, gV, gt_depths, sh, degree, campos, geom, binning, img, alphas,
-                    perspec_matrix, track_off, map_off, need_gaussian_grads, need_means2D):
+                    perspec_matrix, track_off, map_off, need_gaussian_grads, need_means2D, num_rendered=None):
+    """`num_rendered`: per view, what the one-view backward takes as R (>= the view's instance count); read by the library only
+    under deterministic_grads, where it sizes the views' row buffers."""
+    V_ = viewmatrices.size(0)
+    num_rendered = [int(r) for r in (num_rendered if num_rendered is not None else [0] * V_)]
     ext = _ext()
     if ext is not None:
         g = ext.light_backward_batch(bg, means3D, radii, colors, scales, rotations, float(scale_modifier), cov3D_precomp,
                                      viewmatrices, projmatrices, float(tanfovx), float(tanfovy), gC, gD, gM, gV, gt_depths, sh,
                                      int(degree), campos, geom, binning, img, alphas, perspec_matrix, bool(track_off),
-                                     bool(map_off), bool(need_gaussian_grads), bool(need_means2D))
+                                     bool(map_off), bool(need_gaussian_grads), bool(need_means2D), num_rendered)
         return tuple(g)
     lib = _lib()
     dev = means3D.device
@@ -202,7 +206,7 @@ def _backward_batch(bg, means3D, radii, colors, scales, rotations, scale_modifie
         d3 = dsh = dop = dsc = drot = dcov = dcol = d2 = None
         map_off = True  # nobody reads the per-Gaussian sums: the blend kernels form the three pose sums only
     dview = torch.empty((V, 4, 4), **f32)
-    nscr = max(lib.dgr_light_backward_scratch_bytes(P, W, H), 1)
+    nscr = (max(lib.dgr_light_backward_scratch_bytes_r(P, W, H, max(num_rendered + [0])), 1) + 255) // 256 * 256
     scratch = torch.empty((V, nscr), dtype=torch.uint8, device=dev)
     views = (_ViewGrad * V)()
     pp = _capi.ptr(perspec_matrix)
@@ -213,6 +217,7 @@ def _backward_batch(bg, means3D, radii, colors, scales, rotations, scale_modifie
         w.alphas, w.gt_depth, w.radii = _row(alphas, v), _row(gt_depths, v), _row(radii, v)
         w.dL_dpix, w.dL_dpix_depth, w.dL_dpix_median_depth, w.dL_dpix_depth_var = _row(gC, v), _row(gD, v), _row(gM, v), _row(gV, v)
         w.dL_dmean2D, w.dL_dview, w.scratch, w.scratch_bytes = _row(d2, v), _row(dview, v), _row(scratch, v), nscr
+        w.num_rendered = num_rendered[v]
     p = _capi.ptr
     q = lambda t: None if t is None else p(t)  # noqa: E731
     _light._check(lib.dgr_light_backward_batch(
@@ -236,6 +241,7 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         (num_rendered, color, depth, depth_median, depth_var, opacity_map, radii, geom, binning, img, unc, px) = out
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.dgr_options = _capi.load().dgr_thread_options_effective()  # the backward runs under the forward's options
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, viewmatrices, radii, sh, geom, binning,
                               img, opacity_map, gt_depths)
         ctx.set_materialize_grads(False)
@@ -254,12 +260,12 @@ class _RasterizeGaussiansBatch(torch.autograd.Function):
         grad_depth_median = zeros(1) if grad_depth_median is None else grad_depth_median
         grad_depth_var = zeros(1) if grad_depth_var is None else grad_depth_var
         need = ctx.needs_input_grad
-        with _capi.on_device(means3D.device):
+        with _capi.on_device(means3D.device), _capi.under_options(ctx.dgr_options):
             (g2, gcol, gop, g3, gcov, gsh, gsc, grot, gview) = _backward_batch(
                 rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, viewmatrices,
                 rs.projmatrices, rs.tanfovx, rs.tanfovy, grad_color, grad_depth, grad_depth_median, grad_depth_var, gt_depths, sh,
                 rs.sh_degree, rs.campos, geom, binning, img, opacity_map, rs.perspec_matrix, rs.track_off, rs.map_off,
-                need_gaussian_grads=any(need[:8]), need_means2D=bool(need[1]))
+                need_gaussian_grads=any(need[:8]), need_means2D=bool(need[1]), num_rendered=ctx.num_rendered)
         _light._consume_post_backward_wait()
         return g3, g2, gsh, gcol, gop, gsc, grot, gcov, gview, None, None
 

@@ -145,7 +145,7 @@ class _C:
         names = ("means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations")
         seg = _grad_arena(P, M, f32) if need_gaussian_grads else dict.fromkeys(names)
         dL_dview = torch.empty((4, 4), **f32)
-        scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes(P, W, H), 1),), dtype=torch.uint8, device=dev)
+        scratch = torch.empty((max(lib.dgr_light_backward_scratch_bytes_r(P, W, H, int(R)), 1),), dtype=torch.uint8, device=dev)
         p = lambda t: None if t is None else _capi.ptr(t)  # noqa: E731
         _check(lib.dgr_full_backward(
             _capi.stream_handle(dev.index), P, int(degree), M, int(R), p(background), W, H, p(means3D), p(sh), p(colors),

@@ -390,8 +390,11 @@ typedef struct dgr_light_view_grad {   /* the per-camera arguments of dgr_light_
     const float* dL_dpix_depth_var;
     float* dL_dmean2D;                  /* [P,3] of THIS view (densification statistics are per view); may be NULL */
     float* dL_dview;                    /* [16] of this view */
-    char* scratch;                      /* dgr_light_backward_scratch_bytes(), one per view */
+    char* scratch;                      /* dgr_light_backward_scratch_bytes(), one per view (deterministic_grads:
+                                           dgr_light_backward_scratch_bytes_r(P, width, height, num_rendered)) */
     size_t scratch_bytes;
+    int num_rendered;                   /* this view's R as passed to dgr_light_backward (>= its num_rendered); read only with
+                                           deterministic_grads, where it sizes the view's instance-major row buffer */
 } dgr_light_view_grad;
 /* dL_dopacity [P], dL_dcolor [P,3] (may be NULL), dL_dmean3D [P,3], dL_dcov3D [P,6] (may be NULL), dL_dsh [P,M,3] (NULL when
  * M == 0), dL_dscale [P,3], dL_drot [P,4]: the SUM over the views.  Every one of them may be NULL (tracking: map_off = 1). */

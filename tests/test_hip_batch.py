@@ -77,7 +77,7 @@ def batch_backward(ss, deg, out, cams, grads, alphas=None, colors_precomp=None, 
     g = B._backward_batch(T(s.bg), T(s.means), radii, E() if use_sh else T(colors_precomp), T(s.scales) if use_sr else E(),
                           T(s.rots) if use_sr else E(), 1.0, E() if use_sr else T(cov3D_precomp), views, projs, s.tanfovx,
                           s.tanfovy, gC, gD, gM, gV, gts, T(s.shs) if use_sh else E(), deg, campos, geom, binning, img, alpha,
-                          T(s.persp), track_off, map_off, need_gaussian_grads, True)
+                          T(s.persp), track_off, map_off, need_gaussian_grads, True, num_rendered=R)
     names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations",
              "dL_dview"]
     return {n: (None if v is None else v.cpu().numpy()) for n, v in zip(names, g)}

@@ -7,7 +7,8 @@ to 4e-3 on single ill-conditioned rows), and a parity bar near that noise is set
   * the sums are taken in a fixed order (waves of a tile, tiles of a Gaussian ascending, blocks ascending), so the distance to the
     oracle -- which sums in double and rounds once -- is arithmetic, not arrival order: the 1e-5-of-scale bars of the default path
     tighten to 2e-6 at configs 1-3;
-  * the full variant and the batched entry points refuse the option (light variant, one-view backward only)."""
+  * round 9: the full variant's backward and the batched light backward take the option too (they refused it before): the same
+    scheme per view, the batch's per-Gaussian sums over the views formed in view order in registers."""
 import numpy as np
 import pytest
 import torch
@@ -116,15 +117,44 @@ def test_through_the_autograd_surface(deterministic, monkeypatch, sync_mode):
         assert np.array_equal(res[1][k].view(np.uint32), res[2][k].view(np.uint32)), k  # (run 0 sized the lazy capacity)
 
 
-def test_the_other_entry_points_refuse_the_option(deterministic):
-    from dgr_amd import full as F  # noqa: F401
-    s = make_scene(2000, 64, 48, 1)
-    out, d = hh.hip_full_forward(s, 0)
-    with pytest.raises(RuntimeError, match="deterministic_grads"):
-        hh.hip_full_backward(s, 0, out)
+@pytest.mark.parametrize("case", [(2000, 64, 48, 0, 1), (10000, 256, 256, 3, 0), (100000, 640, 480, 3, 0)])
+def test_full_variant_two_runs_give_the_same_bits_and_agree_with_the_oracle(deterministic, oracle, case):
+    """BASELINE config 2 is this variant: F/cuda_rasterizer/backward.cu:540-836 sums with float atomics like the light one."""
+    P, W, H, deg, seed = case
+    s = make_scene(P, W, H, seed)
+    grads = tuple(g * (W * H) ** 0.5 for g in (s.gC, s.gD, s.gV))
+    out, d = hh.hip_full_forward(s, deg)
+    a = hh.hip_full_backward(s, deg, out, grads=grads)
+    torch.cuda.synchronize()
+    b = hh.hip_full_backward(s, deg, out, grads=grads)
+    names = ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations", "dL_dview")
+    for k in names:
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (k, int((a[k] != b[k]).sum()))
+    assert np.abs(a["dL_dmeans3D"]).max() > 0 and np.abs(a["dL_dview"]).max() > 0
+    from util import assert_grad_close
+    _, _, gr = hh.oracle_full(oracle, s, deg, grads=grads)
+    for k in names[:-1]:
+        assert_grad_close(a[k], gr[k], k, rel_to_max=4e-6, elem_rtol=2e-3, elem_frac=1e-3)
+
+
+@pytest.mark.parametrize("case", [(2000, 70, 45, 3, 1, 3), (20000, 320, 200, 3, 0, 4)])
+@pytest.mark.parametrize("mode", [dict(), dict(map_off=True)])
+def test_batched_backward_two_runs_give_the_same_bits_and_match_the_one_view_calls(deterministic, case, mode):
     import test_hip_batch as tb
-    ss = tb.scenes(2000, 64, 48, 2, 0)
-    outb, cams = tb.batch_forward(ss, 0)
-    grads = [(x.gC, x.gD, x.gM, x.gV) for x in ss]
-    with pytest.raises(RuntimeError, match="deterministic_grads"):
-        tb.batch_backward(ss, 0, outb, cams, grads)
+    P, W, H, deg, seed, V = case
+    ss = tb.scenes(P, W, H, V, seed)
+    outb, cams = tb.batch_forward(ss, deg)
+    grads = [tuple(g * (W * H) ** 0.5 for g in (x.gC, x.gD, x.gM, x.gV)) for x in ss]
+    a = tb.batch_backward(ss, deg, outb, cams, grads, **mode)
+    torch.cuda.synchronize()
+    b = tb.batch_backward(ss, deg, outb, cams, grads, **mode)
+    for k, v in a.items():
+        if v is not None:
+            assert np.array_equal(v.view(np.uint32), b[k].view(np.uint32)), (k, int((v != b[k]).sum()))
+    assert np.abs(a["dL_dview"]).max() > 0
+    # every view's pose gradient and screen-space gradients are those of a deterministic one-view backward of that view, bit for bit
+    for v in range(V):
+        one = hh.hip_backward(ss[v], deg, tb.one_view_dict(outb, v), grads=grads[v], **mode)
+        assert np.array_equal(one["dL_dview"].view(np.uint32), a["dL_dview"][v].view(np.uint32)), v
+        if not mode.get("map_off"):
+            assert np.array_equal(one["dL_dmeans2D"].view(np.uint32), a["dL_dmeans2D"][v].view(np.uint32)), v
