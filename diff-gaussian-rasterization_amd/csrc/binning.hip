@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img,
         img.status[0] = (int)total;
         img.status[1] = overflow ? 1 : 0;
         img.cursor[2] = (uint32_t)capacity;
-        img.cursor[3] = (uint32_t)sched_on;
+        img.cursor[3] = (uint32_t)sched_on | (overflow ? 2u : 0u);  // bit 0: the blend kernels walk tile_sched; bit 1: this frame overflowed
         if (fused) {  // (otherwise scan_blocks initialised them)
             img.status[2] = (int)img.cursor[1];  // prefiltered violation
             img.status[3] = 0;                   // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend

@@ -37,7 +37,8 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     __shared__ int s_nvalid;
     __shared__ uint64_t exptab[32];         // ALPHA_GLIBC: exact_math.h
     if (a.rep.host && blockIdx.x == 0 && threadIdx.x == 0) report_status(a.rep, a.status);
-    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
+    bool overflowed;
+    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y, &overflowed);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     if (have_flush) flush_tags(s, hit, a.point_list, range.x + last_base, tid);
 
     // (an overflowed forward rendered empty lists: NaN images instead of a plausible empty frame -- render_light.hip)
-    if (__builtin_amdgcn_readfirstlane(a.status[1]) != 0) {
+    if (overflowed) {
         C0 = C1 = C2 = U = Dd = __builtin_nanf("");
     }
     if (inside) {
@@ -154,7 +155,9 @@ struct StagedBwdFull {
     uint64_t exptab[32];  // ALPHA_GLIBC: exact_math.h
 };
 
-template <int AM, bool DET = false>
+// LEAN (round 9, as in the light variant): the caller passed no gradient image for the "uncertainty" output (NULL: the loss did not
+// use it) -- the variance recurrence and its two terms drop out: bit-identical to the kernel fed an all-zero image.
+template <int AM, bool DET = false, bool LEAN = false>
 __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullArgs a) {
     typedef StagedBwdFull<DET> SB;
     constexpr int BWD_NB = SB::NB, BWD_LD = SB::LD;
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
         dpix1 = a.dL_dpix[N + pix_id];
         dpix2 = a.dL_dpix[2 * N + pix_id];
         dL_depth = a.dL_depths[pix_id];
-        dL_dunc = a.dL_duncertainties[pix_id];
+        if (!LEAN && a.dL_duncertainties) dL_dunc = a.dL_duncertainties[pix_id];
         gt_px = a.gt_depth[pix_id];
     }
     const float bg_term = -T_final * (a.bg[0] * dpix0 + a.bg[1] * dpix1 + a.bg[2] * dpix2);  // times 1/(1 - alpha): background term of dL/dalpha
@@ -258,13 +261,13 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
                 const float Xc = cd.x * dpix0 + cd.y * dpix1 + cd.z * dpix2, Xd = cd.w, Xu = e * e;
                 const float dcol = Xc - Sc;
                 const float ddep = Xd - Sd;
-                float dL_dalpha = dcol + ddep * dL_depth + (Xu - Su) * dL_dunc;
+                float dL_dalpha = LEAN ? dcol + ddep * dL_depth : dcol + ddep * dL_depth + (Xu - Su) * dL_dunc;
                 dL_dalpha *= T;
                 dL_dalpha += bg_term * inv;
                 // what the NEXT valid pair (towards the front) subtracts: S <- alpha X + (1 - alpha) S
                 Sc = am * Xc + om * Sc;
                 Sd = am * Xd + om * Sd;
-                Su = am * Xu + om * Su;
+                if (!LEAN) Su = am * Xu + om * Su;
                 const float qq = oGm * dL_dalpha;
                 const float qc = oGm * (T * dcol);  // sum_ch dL_dpixel[ch] * dpixel_dalpha[ch] = T * dcol (backward.cu:693)
                 // the pair ComputePG matches last: its dd_dvK survive (backward.cu:1278-1289)
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
                 g[0] = w * dpix0;
                 g[1] = w * dpix1;
                 g[2] = w * dpix2;
-                g[3] = w * dL_depth + (dunc2 * w) * e;  // backward.cu:708
+                g[3] = LEAN ? w * dL_depth : w * dL_depth + (dunc2 * w) * e;  // backward.cu:708
                 g[4] = qdx;
                 g[5] = qdy;
                 g[6] = qdx * dx;
@@ -362,14 +365,18 @@ hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hi
 hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream, bool deterministic) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
+    const bool lean = a.dL_duncertainties == nullptr;
     if (deterministic) {  // (alpha_mode 0 only: api.hip)
-        launch_blend(render_bwd_full_kernel<ALPHA_REF, true>, dim3(tiles), dim3(256), stream, a);
+        if (lean) launch_blend(render_bwd_full_kernel<ALPHA_REF, true, true>, dim3(tiles), dim3(256), stream, a);
+        else launch_blend(render_bwd_full_kernel<ALPHA_REF, true>, dim3(tiles), dim3(256), stream, a);
         return hipGetLastError();
     }
     switch (alpha_mode) {
-        case ALPHA_FAST: launch_blend(render_bwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+        case ALPHA_FAST: launch_blend(render_bwd_full_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;   // (reads NULL as zero below)
         case ALPHA_GLIBC: launch_blend(render_bwd_full_kernel<ALPHA_GLIBC>, dim3(tiles), dim3(256), stream, a); break;
-        default: launch_blend(render_bwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
+        default:
+            if (lean) launch_blend(render_bwd_full_kernel<ALPHA_REF, false, true>, dim3(tiles), dim3(256), stream, a);
+            else launch_blend(render_bwd_full_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
     }
     return hipGetLastError();
 }

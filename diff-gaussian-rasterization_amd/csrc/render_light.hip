@@ -89,7 +89,8 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
     __shared__ StagedFwd<HALVES> sf;
     typename StagedFwd<HALVES>::staged_t& s = sf.f;
     if (a.rep.host && blockIdx.x == 0 && threadIdx.x == 0) report_status(a.rep, a.status);
-    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
+    bool overflowed;
+    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y, &overflowed);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -177,8 +178,8 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
 
     // A forward whose binning buffer was too small has rendered EMPTY tile lists (bin_tiles left every range {0, 0}): in lazy mode
     // the host learns of it a call or two later, so the images must not look like a frame -- they are NaN, every value
-    // (strict mode retries inside the call and overwrites them).  One scalar load and a uniform branch.
-    if (__builtin_amdgcn_readfirstlane(a.status[1]) != 0) {
+    // (strict mode retries inside the call and overwrites them).  The flag came with the schedule word (blend_slot): a uniform branch.
+    if (overflowed) {
         C0 = C1 = C2 = weight = Dd = D_median = __builtin_nanf("");
     }
     if (inside) {

@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
             img.status[3] = 0;          // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
         }
         img.cursor[2] = (uint32_t)capacity;
-        img.cursor[3] = (uint32_t)sched_on;
+        img.cursor[3] = (uint32_t)sched_on | (overflow ? 2u : 0u);  // bit 0: the blend kernels walk tile_sched; bit 1: this frame overflowed
     }
     if (overflow || gcount == 0u) {  // (empty tiles keep {0, 0}: the reference clears the table and writes only tiles that own instances)
         if (part == 0 && tid < ntl) img.ranges[tile0 + tid] = make_uint2(0u, 0u);

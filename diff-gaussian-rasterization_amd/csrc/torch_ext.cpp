@@ -801,7 +801,8 @@ struct FullNode : public torch::autograd::Function<FullNode> {
         const long H = d["H"].toInt(), W = d["W"].toInt();
         const Tensor gC = grad[0].defined() ? grad[0] : zeros_like_image(3, H, W, dev);
         const Tensor gD = grad[2].defined() ? grad[2] : zeros_like_image(1, H, W, dev);
-        const Tensor gU = grad[3].defined() ? grad[3] : zeros_like_image(1, H, W, dev);
+        // (no gradient image for the uncertainty output: NULL at the C ABI, which then runs the lean blend backward)
+        const Tensor gU = grad[3].defined() ? grad[3] : Tensor();
         bool need = false;
         for (int i = 0; i < 8; i++) need = need || ctx->needs_input_grad(i);
         const UnderOptions under((int)d["options"].toInt());

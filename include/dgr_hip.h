@@ -162,7 +162,10 @@ int dgr_full_forward_presized(void* stream, char* geometry_buffer, char* binning
  * scratch of the reference; they are not materialised here and may be NULL.  dL_dview receives the 4x4 gradient
  * with the well-defined semantics of ComputePG: every recorded (pixel, Gaussian) pair is consumed.  (The reference
  * lets threads of pixels without a valid contributor return before the block-wide loads, F/cr/backward.cu:875-878,
- * 935-938, which makes its own result undefined for the other pixels of such a tile; DESIGN.md "full variant".) */
+ * 935-938, which makes its own result undefined for the other pixels of such a tile; DESIGN.md "full variant".)
+ * dL_duncertainties may be NULL (the loss did not use the uncertainty output): it reads as zero, and the blend backward
+ * drops the variance recurrence (bit-identical to an all-zero image).  R: as in dgr_light_backward; read only with
+ * "deterministic_grads", where it sizes the instance-major row buffer (scratch: dgr_light_backward_scratch_bytes_r). */
 int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* background, int width, int height,
                       const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                       float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,

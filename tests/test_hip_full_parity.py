@@ -108,3 +108,31 @@ def test_full_precomputed_colors_and_covariances(oracle):
         names += ["dL_dcov3D"] if "cov3D_precomp" in kw else ["dL_dscales", "dL_drotations"]
         for k in names:
             assert_grad_close(g[k], gr[k], k, rel_to_max=1e-5, elem_rtol=2e-3, elem_frac=0.1 if k == "dL_dview" else 2e-3)
+
+
+def test_full_backward_without_an_uncertainty_gradient_is_the_lean_kernel_and_equals_a_zero_image():
+    """A loss on colour and depth only hands the compiled node no gradient for the uncertainty output: NULL at the C ABI, the
+    lean blend backward (csrc/render_full.hip: LEAN) -- the same bits as an explicit all-zero image, up to the order of float
+    atomics (F/cuda_rasterizer/backward.cu:701-708 is the term that drops out)."""
+    import torch
+    from dgr_amd import full as F
+    s = make_scene(10000, 256, 256, 0)
+    T = hh.T
+    got = []
+    for explicit_zero in (False, True):
+        leaves = [T(a).requires_grad_() for a in (s.means, s.shs, s.opac, s.scales, s.rots, s.view)]
+        m2 = torch.zeros((s.P, 3), device=hh.dev(), requires_grad=True)
+        rast = F.GaussianRasterizer(F.GaussianRasterizationSettings(
+            image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=T(s.bg), scale_modifier=1.0,
+            viewmatrix=T(s.view), projmatrix=T(s.proj), sh_degree=3, campos=T(s.campos), prefiltered=False, perspec_matrix=T(s.persp)))
+        color, radii, depth, unc = rast(means3D=leaves[0], means2D=m2, opacities=leaves[2], shs=leaves[1], scales=leaves[3],
+                                        rotations=leaves[4], viewmatrix=leaves[5], gt_depth=T(s.gt))
+        outs, grads = [color, depth], [T(s.gC), T(s.gD[None])]
+        if explicit_zero:
+            outs.append(unc)
+            grads.append(torch.zeros_like(unc))
+        torch.autograd.backward(outs, grads)
+        got.append([x.grad.cpu().numpy() for x in leaves])
+    for a, b in zip(*got):
+        assert np.abs(b).max() > 0
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
