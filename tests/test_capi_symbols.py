@@ -85,8 +85,9 @@ def test_batch_entry_points_reject_bad_view_counts_before_touching_the_gpu():
     grads = (_capi.LightViewGrad * 1)()
     assert lib.dgr_light_backward_batch(None, 0, grads, 0, 3, 16, None, 64, 48, None, None, None, None, 1.0, None, None, 0.6,
                                         0.45, None, None, None, None, None, None, None, 0, 0) == _capi.DGR_ERR_BAD_ARGUMENT
-    # the ctypes structs mirror the C layout: 17 / 18 eight-byte slots (the int is padded to pointer alignment)
-    assert ctypes.sizeof(_capi.LightView) == 17 * 8 and ctypes.sizeof(_capi.LightViewGrad) == 18 * 8
+    # the ctypes structs mirror the C layout: 17 / 19 eight-byte slots (an int is padded to pointer alignment; round 9 added
+    # dgr_light_view_grad.num_rendered behind scratch_bytes)
+    assert ctypes.sizeof(_capi.LightView) == 17 * 8 and ctypes.sizeof(_capi.LightViewGrad) == 19 * 8
     assert lib.dgr_get_option(b"batch_streams") == 2
     assert lib.dgr_set_option(b"batch_streams", 1) == 0 and lib.dgr_get_option(b"batch_streams") == 1
     assert lib.dgr_set_option(b"batch_streams", 2) == 0
