@@ -46,4 +46,5 @@ except Exception as e:
     print(sys.argv[1], "ERR", e)
 PY
 done > $O/summary.txt
+find gpurun_out -name "*.db" -size +1M -delete   # (the raw profiler databases: gpurun merges at most 64 MiB back)
 cat $O/pytest.log $O/smoke.log $O/appendix_c.txt $O/summary.txt $O/tracking_example_*.txt $O/mapping_example.txt
