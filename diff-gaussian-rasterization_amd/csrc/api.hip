@@ -251,6 +251,14 @@ std::atomic<int> g_alpha_mode{[] {
 // then needs dgr_light_backward_scratch_bytes_r(P, W, H, R) bytes of scratch, R = the value passed as `R` (>= num_rendered).
 std::atomic<int> g_det_grads{[] { const char* e = getenv("DGR_DETERMINISTIC_GRADS"); return (e && e[0] == '1') ? 1 : 0; }()};
 
+// dgr_set_option("lane_lists", v): the lists the LIGHT blend kernels walk (csrc/render_light.hip).
+//   1 = one list per half of a quadrant wave in the forward and the tracking backward, paired lists in the mapping backward (round 8);
+//   0 = one list per quadrant wave everywhere (rounds 1-7);
+//   2 (default) = decided per FRAME on the device by the binning kernel, from the frame's own run statistics (segment_binning.hip:
+//       bin_tiles_kernel; big splats -> 0) and recorded in the frame's state, where forward and backward read it.
+// Initial value from DGR_FWD_HALVES = 0 / 1 (the switch's name when it was per process; A/B runs).
+std::atomic<int> g_lane_lists{[] { const char* e = getenv("DGR_FWD_HALVES"); return (e && (e[0] == '0' || e[0] == '1') && e[1] == 0) ? e[0] - '0' : 2; }()};
+
 // ---- per-THREAD overrides of the three options that change what a call computes (dgr_set_thread_option, round 9).  The options
 // above are process-wide defaults; a tracker thread and a mapper thread of one process -- or a test beside a training loop -- hold
 // their own values here (-1 = inherit).  Every entry point reads its options ONCE, when it is called, and hands them to its
@@ -397,6 +405,8 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
     const int gx = dgr::tiles_x(c.W), gy = dgr::tiles_y(c.H), tiles = gx * gy;
     // the tile schedule: always, unless this shape's last reported frame had even lists (want_schedule above)
     const bool sched_on = !(armed && armed->id >= 0) ? (g_tile_schedule.load(std::memory_order_relaxed) != 0) : want_schedule(c.W, c.H, c.P);
+    const int lists = g_lane_lists.load(std::memory_order_relaxed);
+    const int blend_flags = (sched_on ? dgr::BLEND_SCHEDULE : 0) | (lists == 0 ? dgr::BLEND_LISTS_QUADRANT : lists == 2 ? dgr::BLEND_LISTS_AUTO : 0);
     const dgr::StatusReport rep = armed ? armed->rep : dgr::StatusReport{nullptr, 0u, nullptr};
     if (mode == COUNT_LDS || mode == COUNT_LDS_CALLBACK) {
         const bool cb = mode == COUNT_LDS_CALLBACK;
@@ -404,14 +414,14 @@ int binning_stages(const FwdCommon& c, dgr::GeometryView geom, dgr::ImageView im
         const int longest = (armed && armed->id >= 0) ? hinted_longest_list(c.W, c.H, c.P) : -1;
         const int ss = dgr::segment_shift(c.W, c.H, capacity, longest);
         { ScopedStage t(ST_BIN_SEGMENTS, st); HIP_TRY(dgr::launch_bin_segments(c.P, geom, bin, tb, gx, gy, ss, capacity, cb, st)); }
-        { ScopedStage t(ST_BIN_TILES, st); HIP_TRY(dgr::launch_bin_tiles(c.P, geom, img, bin, tb, gx, gy, ss, capacity, cb, sched_on, rep, st)); }
+        { ScopedStage t(ST_BIN_TILES, st); HIP_TRY(dgr::launch_bin_tiles(c.P, geom, img, bin, tb, gx, gy, ss, capacity, cb, blend_flags, rep, st)); }
         if (!cb) { const int rc = early_status_post(img.status, st); if (rc) return rc; }  // (bin_tiles writes the status word)
         if (sched_on) { ScopedStage t(ST_TILE_SCHED, st); HIP_TRY(dgr::launch_tile_schedule(img, tiles, st)); }
         return DGR_OK;
     }
     const bool fused = mode == COUNT_FUSED;
     if (!fused) { ScopedStage t(ST_COUNT_RANK, st); HIP_TRY(dgr::launch_count_rank(c.P, geom, img, bin, gx, capacity, st)); }
-    { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, gx, capacity, fused, sched_on, rep, st)); }
+    { ScopedStage t(ST_SCAN, st); HIP_TRY(dgr::launch_scan_tiles(img, tiles, gx, capacity, fused, blend_flags, rep, st)); }
     if (fused) { const int rc = early_status_post(img.status, st); if (rc) return rc; }
     { ScopedStage t(ST_EMIT, st); HIP_TRY(dgr::launch_emit_instances(c.P, geom, img, bin, gx, st)); }
     { ScopedStage t(ST_SORT, st); HIP_TRY(dgr::launch_sort_tiles(img, bin, tiles, st)); }
@@ -456,7 +466,8 @@ int check_common(const FwdCommon& c) {
     if ((unsigned)c.P > DGR_ID_MASK) { g_last_error = "more than 2^28 Gaussians"; return DGR_ERR_BAD_ARGUMENT; }
     if (c.P > 0 && !c.shs && !c.colors_precomp) { g_last_error = "need SHs or precomputed colours"; return DGR_ERR_BAD_ARGUMENT; }
     if (c.P > 0 && !c.cov3D_precomp && (!c.scales || !c.rotations)) { g_last_error = "need scale/rotation or cov3D"; return DGR_ERR_BAD_ARGUMENT; }
-    if (dgr::tiles_x(c.W) > 65535 || dgr::tiles_y(c.H) > 65535) { g_last_error = "image too large"; return DGR_ERR_BAD_ARGUMENT; }
+    // (2^30 pixels: the blend kernels index pixels, and the three colour planes, with 32-bit words)
+    if (dgr::tiles_x(c.W) > 65535 || dgr::tiles_y(c.H) > 65535 || (long long)c.W * c.H > (1ll << 30)) { g_last_error = "image too large"; return DGR_ERR_BAD_ARGUMENT; }
     return DGR_OK;
 }
 
@@ -737,7 +748,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     hipStream_t st = (hipStream_t)stream;
     const bool scratch_clean = g_scratch_clean_armed;
     g_scratch_clean_armed = false;
-    if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
+    if (P < 0 || width <= 0 || height <= 0 || (long long)width * height > (1ll << 30)) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
     if (P == 0) {  // L/rasterize_points.cu:188: nothing runs, gradients stay zero
         HIP_TRY(hipMemsetAsync(dL_dview, 0, 16 * 4, st));
         return DGR_OK;
@@ -898,7 +909,7 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
     hipStream_t st = (hipStream_t)stream;
     const bool scratch_clean = g_scratch_clean_armed;
     g_scratch_clean_armed = false;
-    if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
+    if (P < 0 || width <= 0 || height <= 0 || (long long)width * height > (1ll << 30)) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
     if (P == 0) {
         HIP_TRY(hipMemsetAsync(dL_dview, 0, 16 * 4, st));
         return DGR_OK;
@@ -1044,7 +1055,7 @@ int dgr_light_backward_batch(void* stream, int n_views, const dgr_light_view_gra
     const bool det = opt_det_grads() != 0 && !(track_off && map_off);  // (round 9: per view the scheme of the one-view backward)
     if (det && opt_alpha_mode() != 0) { g_last_error = "deterministic_grads needs alpha_mode 0"; return DGR_ERR_BAD_ARGUMENT; }
     if (n_views < 1 || n_views > DGR_MAX_BATCH_VIEWS || !views) { g_last_error = "1 .. DGR_MAX_BATCH_VIEWS views per batch"; return DGR_ERR_BAD_ARGUMENT; }
-    if (P < 0 || width <= 0 || height <= 0) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
+    if (P < 0 || width <= 0 || height <= 0 || (long long)width * height > (1ll << 30)) { g_last_error = "bad sizes"; return DGR_ERR_BAD_ARGUMENT; }
     for (int v = 0; v < n_views; v++)
         if (!views[v].dL_dview) { g_last_error = "view without dL_dview"; return DGR_ERR_BAD_ARGUMENT; }
     if (P > 0 && !cov3D_precomp && (!scales || !rotations)) { g_last_error = "backward: need scale/rotation or cov3D"; return DGR_ERR_BAD_ARGUMENT; }
@@ -1425,6 +1436,7 @@ int dgr_set_option(const char* name, int value) {
         return DGR_OK;
     }
     if (n == "lds_count") { g_lds_count.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
+    if (n == "lane_lists") { g_lane_lists.store(value < 0 ? 0 : value > 2 ? 2 : value); return DGR_OK; }
     if (n == "deterministic_grads") { g_det_grads.store(value ? 1 : 0); return DGR_OK; }
     if (n == "profile_every") { g_profile_every.store(value > 0 ? value : 1); return DGR_OK; }
     if (n == "batch_order") { g_batch_order.store(value ? 1 : 0); return DGR_OK; }
@@ -1440,6 +1452,7 @@ int dgr_get_option(const char* name) {
     if (n == "fast_alpha") return g_alpha_mode.load() == 1 ? 1 : 0;
     if (n == "alpha_mode") return g_alpha_mode.load();
     if (n == "lds_count") return g_lds_count.load();
+    if (n == "lane_lists") return g_lane_lists.load();
     if (n == "deterministic_grads") return g_det_grads.load();
     if (n == "profile_every") return g_profile_every.load();
     if (n == "batch_streams") return g_batch_streams.load();

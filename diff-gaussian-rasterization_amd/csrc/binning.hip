@@ -95,7 +95,9 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_tiles_kernel(ImageView img,
         img.status[0] = (int)total;
         img.status[1] = overflow ? 1 : 0;
         img.cursor[2] = (uint32_t)capacity;
-        img.cursor[3] = (uint32_t)sched_on | (overflow ? 2u : 0u);  // bit 0: the blend kernels walk tile_sched; bit 1: this frame overflowed
+        // bit 0: the blend kernels walk tile_sched; bit 1: this frame overflowed; bit 2: quadrant lists in the light blend kernels
+        // (segment_binning.hip decides that per frame; this path has no run statistics and takes only the forced setting)
+        img.cursor[3] = (uint32_t)(sched_on & 1) | (overflow ? 2u : 0u) | ((sched_on & BLEND_LISTS_QUADRANT) ? 4u : 0u);
         if (fused) {  // (otherwise scan_blocks initialised them)
             img.status[2] = (int)img.cursor[1];  // prefiltered violation
             img.status[3] = 0;                   // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
@@ -381,9 +383,9 @@ hipError_t launch_tile_schedule(ImageView img, int tiles, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, bool sched_on, StatusReport rep,
+hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, int blend_flags, StatusReport rep,
                              hipStream_t stream) {
-    launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, grid_x, capacity, fused ? 1 : 0, sched_on ? 1 : 0, rep);
+    launch(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), stream, img, tiles, grid_x, capacity, fused ? 1 : 0, blend_flags, rep);
     return hipGetLastError();
 }
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,

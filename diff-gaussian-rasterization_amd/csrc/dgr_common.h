@@ -73,12 +73,17 @@ __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
     return g;
 }
 
+// what the forward asks of the binning kernel that writes ImageView::cursor[3] (launch_bin_tiles / launch_scan_tiles: blend_flags)
+enum { BLEND_SCHEDULE = 1, BLEND_LISTS_QUADRANT = 4, BLEND_LISTS_AUTO = 8 };
+
 struct ImageView {
     int* status;          // [4] {num_rendered, overflow, prefiltered violation, reserved}
     uint32_t* cursor;     // [4] presized path: {instances handed out so far (preprocess_fwd's blocks bump it to place their
                           //     ranks), prefiltered violation seen}; cleared together with the tile counters.
                           //     [2] = capacity the binning buffer was carved with (scan_tiles / bin_tiles)
-                          //     [3] = 1: tile_sched holds this frame's schedule, 0: the blend kernels use the static band map
+                          //     [3] = the frame's blend flags: bit 0: tile_sched holds this frame's schedule (0: the blend kernels use the
+                          //           static band map); bit 1: the binning buffer overflowed; bit 2: the light blend kernels walk
+                          //           quadrant lists rather than half-wave lists (BLEND_* below: what the host asks the binning for)
     uint32_t* tile_count; // [tiles * DGR_COUNT_STRIDE] instances per tile (histogram filled by count_rank), one per line
     uint2* ranges;        // [tiles] {start, end} into point_list
     uint4* tile_sched;    // [tiles] the blend kernels' schedule: workgroup b works on tile .x, whose list is [.y, .z) --

@@ -280,7 +280,7 @@ hipError_t launch_mark_visible(int P, const float* means, const float* view, uin
 // binning: tile_count -> ranges (+ total in status[0], overflow in status[1]); emit keys; sort tiles
 // `fused`: preprocess_fwd counted (no scan_blocks ran): scan_tiles then also fills status[2] (from the cursor's violation
 // word) and status[3]
-hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, bool sched_on, StatusReport rep,
+hipError_t launch_scan_tiles(ImageView img, int tiles, int grid_x, int capacity, bool fused, int blend_flags, StatusReport rep,
                              hipStream_t stream);
 hipError_t launch_count_rank(int P, GeometryView geom, ImageView img, BinningView bin, int grid_x, int capacity,
                              hipStream_t stream);
@@ -296,7 +296,7 @@ hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, Segmen
                                int capacity, bool prefixed, hipStream_t stream);
 extern unsigned long long* g_bin_tiles_trace;  // debug: phase time stamps per bin_tiles workgroup (segment_binning.hip)
 hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
-                            int seg_shift, int capacity, bool prefixed, bool sched_on, StatusReport rep, hipStream_t stream);
+                            int seg_shift, int capacity, bool prefixed, int blend_flags, StatusReport rep, hipStream_t stream);
 hipError_t launch_sort_tiles(ImageView img, BinningView bin, int tiles, hipStream_t stream);
 // ranges -> the blend kernels' schedule (img.tile_sched): tiles by descending list length, so that the longest lists
 // start first and every XCD gets its share of a cluster

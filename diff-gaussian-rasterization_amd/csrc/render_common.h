@@ -16,12 +16,16 @@ namespace dgr {
 // Which of the two a frame uses is recorded in its image state by the binning kernel (cursor[3]) for forward and backward alike.
 // The same word's bit 1 says that the frame's binning buffer OVERFLOWED (every tile list is empty): the forward kernels then write NaN
 // images instead of a plausible empty frame (a lazy caller learns of the overflow a call or two later).  It rides in this word
-// because the status word itself is no place to read from here: the full forward's workgroups add their valid-pair counts to
+// Bit 2: the frame's lane lists (light blend kernels): one per quadrant wave instead of one per half-wave -- the binning kernel decides
+// it per frame (segment_binning.hip) and forward and backward of the frame take the same uniform branch on it.
+// The flags ride in this word because the status word itself is no place to read from here: the full forward's workgroups add their valid-pair counts to
 // status[3] with atomics as they finish, and a load of that line queues behind them -- 34 -> 60 us for render_fwd at config 2.
 __device__ __forceinline__ uint4 blend_slot(const uint4* __restrict__ sched, const uint2* __restrict__ ranges,
-                                            const uint32_t* __restrict__ sched_flag, int tiles, bool* overflowed = nullptr) {
+                                            const uint32_t* __restrict__ sched_flag, int tiles, bool* overflowed = nullptr,
+                                            bool* quadrant_lists = nullptr) {
     const int flag = __builtin_amdgcn_readfirstlane((int)*sched_flag);
     if (overflowed) *overflowed = (flag & 2) != 0;
+    if (quadrant_lists) *quadrant_lists = (flag & 4) != 0;
     if (flag & 1) return sched[blockIdx.x];
     const int tile = xcd_contiguous((int)blockIdx.x, tiles);
     const uint2 r = ranges[tile];

@@ -84,20 +84,16 @@ __device__ __forceinline__ void flush_slot(const SF& sf, const RenderFwdLightArg
     a.point_list[pos0 + tid] = gid | (tag << TAG_SHIFT);
 }
 
-template <int AM, bool HALVES = false>
-__global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
-    __shared__ StagedFwd<HALVES> sf;
+template <int AM, bool HALVES>
+__device__ __forceinline__ void render_fwd_light_body(const RenderFwdLightArgs& a, StagedFwd<HALVES>& sf, const uint4 slot, const bool overflowed) {
     typename StagedFwd<HALVES>::staged_t& s = sf.f;
-    if (a.rep.host && blockIdx.x == 0 && threadIdx.x == 0) report_status(a.rep, a.status);
-    bool overflowed;
-    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y, &overflowed);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int px = tx * DGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
     const int py = ty * DGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
-    const size_t pix_id = (size_t)a.W * py + px;
+    const uint32_t pix_id = (uint32_t)a.W * (uint32_t)py + (uint32_t)px;  // (W H <= 2^30: api.hip)
     const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
     const int my_list = HALVES ? 2 * wave + (lane >> 5) : wave;
@@ -183,7 +179,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         C0 = C1 = C2 = weight = Dd = D_median = __builtin_nanf("");
     }
     if (inside) {
-        const size_t N = (size_t)a.W * a.H;
+        const uint32_t N = (uint32_t)a.W * (uint32_t)a.H;
         a.n_contrib[pix_id] = last_contributor;
         a.out_color[pix_id] = C0 + T * a.bg[0];
         a.out_color[N + pix_id] = C1 + T * a.bg[1];
@@ -193,6 +189,20 @@ __global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLight
         a.out_median[pix_id] = D_median;
         a.out_depth_var[pix_id] = 0.0f;  // forward.cu:317,410
     }
+}
+
+// One kernel, both lane mappings: which one a frame takes is the frame's own flag (ImageView::cursor[3] bit 2, written by its binning
+// kernel) -- a uniform branch on a word the workgroup reads anyway, so that the choice can be made on the DEVICE for the frame at
+// hand (no host policy, nothing to carry from forward to backward: the backward kernels branch on the same word).  The two bodies
+// share the workgroup's LDS (a union: 20.0 KB, 8 workgroups per CU) and the register budget of the launch bounds.
+template <int AM>
+__global__ void __launch_bounds__(256, 8) render_fwd_light_kernel(RenderFwdLightArgs a) {
+    __shared__ union { StagedFwd<true> h; StagedFwd<false> q; } sf;
+    if (a.rep.host && blockIdx.x == 0 && threadIdx.x == 0) report_status(a.rep, a.status);
+    bool overflowed, quadrant_lists;
+    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y, &overflowed, &quadrant_lists);  // {tile, list start, list end}
+    if (quadrant_lists) render_fwd_light_body<AM, false>(a, sf.q, slot, overflowed);
+    else render_fwd_light_body<AM, true>(a, sf.h, slot, overflowed);
 }
 
 // ================================================================================ backward
@@ -255,23 +265,21 @@ struct StagedBwd {
 // With DO_MAP, HALVES means PAIRED lists (render_common.h: build_paired_lists): neighbouring entries of a wave's list that live
 // in different halves of the quadrant share a loop step (0.87 steps per entry); such a step reduces its twelve sums per half and
 // each half delivers to its own entry's column -- every entry is still delivered once.
-template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false, bool LEAN = false, bool HALVES = false>
-__global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
+template <int AM, bool DO_MAP, bool DO_POSE, bool DET, bool LEAN, bool HALVES>
+__device__ __forceinline__ void render_bwd_light_body(const RenderBwdLightArgs& a, StagedBwd<DET, HALVES>& sb, const uint4 slot) {
     static_assert(!HALVES || !DET, "half-wave / paired lists: not with the deterministic kernel's planes (LDS)");
     constexpr bool PAIRED = HALVES && DO_MAP;
     typedef StagedBwd<DET, HALVES> SB;
     constexpr int BWD_NB = SB::NB, BWD_LD = SB::LD;
-    __shared__ SB sb;
     typename SB::staged_t& s = sb.f;
-    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int px = tx * DGR_BLOCK_X + (wave & 1) * 8 + (lane & 7);
     const int py = ty * DGR_BLOCK_Y + (wave >> 1) * 8 + (lane >> 3);
     const bool inside = px < a.W && py < a.H;
-    const size_t pix_id = (size_t)a.W * py + px;
-    const size_t N = (size_t)a.W * a.H;
+    const uint32_t pix_id = (uint32_t)a.W * (uint32_t)py + (uint32_t)px;  // (W H <= 2^30: api.hip)
+    const uint32_t N = (uint32_t)a.W * (uint32_t)a.H;
     const float pxf = (float)px, pyf = (float)py;
     const f2 pxy = {pxf, pyf};
 
@@ -519,6 +527,20 @@ __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLight
     }
 }
 
+// BY_FRAME: half-wave / paired lists or quadrant lists by the frame's flag (render_fwd_light_kernel above: the forward that wrote the
+// tags took the same branch; the half-wave body needs the tags per half that only the half-wave forward writes).  Without it:
+// quadrant lists, which the 4-bit tags of either forward serve -- the deterministic kernels (LDS for the planes) and the glibc form
+// (an A/B mode that spills a register with eight lists).
+template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false, bool LEAN = false, bool BY_FRAME = false>
+__global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
+    static_assert(!BY_FRAME || !DET, "the deterministic kernel walks quadrant lists");
+    __shared__ union { StagedBwd<DET, BY_FRAME> h; StagedBwd<DET, false> q; } sb;
+    bool quadrant_lists = true;
+    const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y, nullptr, BY_FRAME ? &quadrant_lists : nullptr);
+    if (BY_FRAME && !quadrant_lists) render_bwd_light_body<AM, DO_MAP, DO_POSE, DET, LEAN, BY_FRAME>(a, sb.h, slot);
+    else render_bwd_light_body<AM, DO_MAP, DO_POSE, DET, LEAN, false>(a, sb.q, slot);
+}
+
 // ---- deterministic gradients: the kernels around the DET blend backward
 // n = tiles of a Gaussian's rectangle; goff = exclusive prefix of n over the Gaussians (the reference's point_offsets,
 // L/cuda_rasterizer/rasterizer_impl.cu:283, which the segment binning never needs): per-block sums, then per-block bases.
@@ -655,30 +677,16 @@ __global__ void __launch_bounds__(256) exact_math_test_kernel(int n, const float
     }
 }
 
-// DGR_FWD_HALVES=0: one list per quadrant wave in the forward blend and in the tracking backward (rounds 1-7's lane mapping, kept
-// for A/B: profiles/r8/ab_fwd_halves.txt, ab_track_halves.txt).  One switch for both: the backward's half-wave lists are cut from
-// the forward's tags by the forward's box test.
-bool half_wave_lists() {
-    static const bool on = [] { const char* e = getenv("DGR_FWD_HALVES"); return !(e && e[0] == '0'); }();
-    return on;
-}
-
 template <int AM>
 void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t stream) {
-    const bool halves = half_wave_lists();
+    // (the lane lists -- half-wave / paired or per quadrant -- are the frame's own choice: render_bwd_light_kernel)
     if (AM == ALPHA_REF && !a.det_rows && !a.dL_dpix_median && !a.dL_dpix_var) {
-        if (!a.map_off && !a.track_off && halves)
+        if (!a.map_off && !a.track_off)
             launch_blend((render_bwd_light_kernel<ALPHA_REF, true, true, false, true, true>), dim3(tiles), dim3(256), stream, a);
-        else if (!a.map_off && !a.track_off)
-            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, true, false, true>), dim3(tiles), dim3(256), stream, a);
-        else if (!a.map_off && halves)
-            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, false, false, true, true>), dim3(tiles), dim3(256), stream, a);
         else if (!a.map_off)
-            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, false, false, true>), dim3(tiles), dim3(256), stream, a);
-        else if (halves)
-            launch_blend((render_bwd_light_kernel<ALPHA_REF, false, true, false, true, true>), dim3(tiles), dim3(256), stream, a);
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, true, false, false, true, true>), dim3(tiles), dim3(256), stream, a);
         else
-            launch_blend((render_bwd_light_kernel<ALPHA_REF, false, true, false, true>), dim3(tiles), dim3(256), stream, a);
+            launch_blend((render_bwd_light_kernel<ALPHA_REF, false, true, false, true, true>), dim3(tiles), dim3(256), stream, a);
         return;
     }
     if (AM == ALPHA_REF && a.det_rows) {
@@ -690,34 +698,23 @@ void launch_bwd_light_mode(const RenderBwdLightArgs& a, int tiles, hipStream_t s
             launch_blend((render_bwd_light_kernel<ALPHA_REF, false, true, true>), dim3(tiles), dim3(256), stream, a);
         return;
     }
-    constexpr int AMH = AM == ALPHA_GLIBC ? ALPHA_REF : AM;  // (never launched for the glibc form: see below)
-    if (!a.map_off && !a.track_off && halves && AM != ALPHA_GLIBC)
-        launch_blend((render_bwd_light_kernel<AMH, true, true, false, false, true>), dim3(tiles), dim3(256), stream, a);
-    else if (!a.map_off && !a.track_off)
-        launch_blend((render_bwd_light_kernel<AM, true, true>), dim3(tiles), dim3(256), stream, a);
-    else if (!a.map_off && halves && AM != ALPHA_GLIBC)
-        launch_blend((render_bwd_light_kernel<AMH, true, false, false, false, true>), dim3(tiles), dim3(256), stream, a);
+    constexpr bool BF = AM != ALPHA_GLIBC;  // (the glibc form, an A/B mode, spills a register with the eight lists: quadrant lists)
+    if (!a.map_off && !a.track_off)
+        launch_blend((render_bwd_light_kernel<AM, true, true, false, false, BF>), dim3(tiles), dim3(256), stream, a);
     else if (!a.map_off)
-        launch_blend((render_bwd_light_kernel<AM, true, false>), dim3(tiles), dim3(256), stream, a);
-    else if (halves && AM != ALPHA_GLIBC)  // (the glibc form, an A/B mode, spills a register with the eight lists)
-        launch_blend((render_bwd_light_kernel<AM == ALPHA_GLIBC ? ALPHA_REF : AM, false, true, false, false, true>), dim3(tiles), dim3(256), stream, a);
+        launch_blend((render_bwd_light_kernel<AM, true, false, false, false, BF>), dim3(tiles), dim3(256), stream, a);
     else
-        launch_blend((render_bwd_light_kernel<AM, false, true>), dim3(tiles), dim3(256), stream, a);
+        launch_blend((render_bwd_light_kernel<AM, false, true, false, false, BF>), dim3(tiles), dim3(256), stream, a);
 }
 }  // namespace
 
 hipError_t launch_render_fwd_light(const RenderFwdLightArgs& a, int alpha_mode, hipStream_t stream) {
     const int tiles = a.grid_x * a.grid_y;
     if (tiles <= 0) return hipSuccess;
-    const bool halves = half_wave_lists();
-    auto go = [&](auto kh, auto kq) {
-        if (halves) launch_blend(kh, dim3(tiles), dim3(256), stream, a);
-        else launch_blend(kq, dim3(tiles), dim3(256), stream, a);
-    };
     switch (alpha_mode) {
-        case ALPHA_FAST: go(render_fwd_light_kernel<ALPHA_FAST, true>, render_fwd_light_kernel<ALPHA_FAST, false>); break;
-        case ALPHA_GLIBC: go(render_fwd_light_kernel<ALPHA_GLIBC, true>, render_fwd_light_kernel<ALPHA_GLIBC, false>); break;
-        default: go(render_fwd_light_kernel<ALPHA_REF, true>, render_fwd_light_kernel<ALPHA_REF, false>);
+        case ALPHA_FAST: launch_blend(render_fwd_light_kernel<ALPHA_FAST>, dim3(tiles), dim3(256), stream, a); break;
+        case ALPHA_GLIBC: launch_blend(render_fwd_light_kernel<ALPHA_GLIBC>, dim3(tiles), dim3(256), stream, a); break;
+        default: launch_blend(render_fwd_light_kernel<ALPHA_REF>, dim3(tiles), dim3(256), stream, a);
     }
     return hipGetLastError();
 }

@@ -372,15 +372,31 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     for (int ww = 0; ww < K2_WAVES; ww++) { before += sh.red[0][ww]; upto += sh.red[1][ww]; total += sh.red[2][ww]; flag |= sh.red[3][ww]; }
     const bool overflow = total > (uint32_t)capacity;
     const uint32_t gcount = upto - before;
-    if (s == 0 && part == 0 && tid == 0) {
-        img.status[0] = (int)total;
-        img.status[1] = overflow ? 1 : 0;
-        if (!prefixed) {
-            img.status[2] = (int)flag;  // prefiltered violation
-            img.status[3] = 0;          // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
+    if (s == 0 && part == 0 && wave == 0) {  // (one wave of one workgroup: the frame's status word and blend flags)
+        // bit 2 of the flags: the light blend kernels walk one list per QUADRANT wave instead of one per half-wave (render_common.h:
+        // blend_slot) -- forced by the caller (BLEND_LISTS_QUADRANT) or, with BLEND_LISTS_AUTO, decided here for THIS frame: a frame of
+        // big splats (mean run of tiles per Gaussian, tile row and segment above 2.5; the uniform scene has 1.7-1.9, the heavy-tailed
+        // one 2.9-4.6 depending on the segment size) has nearly every entry in both halves of its quadrants -- nothing for half-wave
+        // lists to skip, nothing to pair -- and pays 3 % for the finer lists (profiles/r8/ab_scenes_halves.txt, r9/ab_lists_fused.txt)
+        bool quadrant_lists = (sched_on & BLEND_LISTS_QUADRANT) != 0;
+        if (sched_on & BLEND_LISTS_AUTO) {
+            uint32_t runs = 0;  // every (Gaussian, tile row, segment) run of the frame: the ends of the workgroups' pair regions less their starts
+            for (int w = lane; w < nwg; w += 64) runs += tb.pair_off[(size_t)nseg * nwg + w] - tb.pair_off[w];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) runs += __shfl_xor(runs, off, 64);
+            quadrant_lists = 2ull * total > 5ull * runs;
         }
-        img.cursor[2] = (uint32_t)capacity;
-        img.cursor[3] = (uint32_t)sched_on | (overflow ? 2u : 0u);  // bit 0: the blend kernels walk tile_sched; bit 1: this frame overflowed
+        if (lane == 0) {
+            img.status[0] = (int)total;
+            img.status[1] = overflow ? 1 : 0;
+            if (!prefixed) {
+                img.status[2] = (int)flag;  // prefiltered violation
+                img.status[3] = 0;          // full variant: number of valid (pixel, Gaussian) pairs, summed by its forward blend
+            }
+            img.cursor[2] = (uint32_t)capacity;
+            // bit 0: the blend kernels walk tile_sched; bit 1: this frame overflowed
+            img.cursor[3] = (uint32_t)(sched_on & 1) | (overflow ? 2u : 0u) | (quadrant_lists ? 4u : 0u);
+        }
     }
     if (overflow || gcount == 0u) {  // (empty tiles keep {0, 0}: the reference clears the table and writes only tiles that own instances)
         if (part == 0 && tid < ntl) img.ranges[tile0 + tid] = make_uint2(0u, 0u);
@@ -611,7 +627,7 @@ hipError_t launch_bin_segments(int P, GeometryView geom, BinningView bin, Segmen
     return hipGetLastError();
 }
 hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView bin, SegmentTables tb, int grid_x, int grid_y,
-                            int seg_shift, int capacity, bool prefixed, bool sched_on, StatusReport rep, hipStream_t stream) {
+                            int seg_shift, int capacity, bool prefixed, int blend_flags, StatusReport rep, hipStream_t stream) {
     const int nseg = grid_y * ((grid_x + (1 << seg_shift) - 1) >> seg_shift);
     const int helpers = (1 << seg_shift) / 4 - 1;  // per segment (bin_tiles_kernel)
     // block -> segment map: XCD x takes a contiguous run of segments on a frame known to be even (the last report of this shape
@@ -619,10 +635,10 @@ hipError_t launch_bin_tiles(int P, GeometryView geom, ImageView img, BinningView
     // neighbours, and a contiguous map hands all of them to two or three of the eight XCDs (clustered scene: 129 -> 107 us
     // before anything else changed, profiles/r9/bin_tiles_ab.txt).  DGR_BT_MAP = 0 / 1 forces one (A/B runs).
     static const int forced_map = [] { const char* e = getenv("DGR_BT_MAP"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1; }();
-    const int xp_map = forced_map >= 0 ? forced_map : (sched_on ? 0 : 1);
+    const int xp_map = forced_map >= 0 ? forced_map : ((blend_flags & 1) ? 0 : 1);
     launch(bin_tiles_kernel, dim3(nseg * (1 + helpers)), dim3(K2_THREADS), stream, img, bin.point_list, bin.keys, tb, bin.pair_keys, bin.pair_cov,
            geom.block_tiles, (P + 255) / 256, segment_binning_workgroups(P), grid_x, grid_y, seg_shift, capacity, prefixed ? 1 : 0,
-           sched_on ? 1 : 0, rep, xp_map, g_bin_tiles_trace);
+           blend_flags, rep, xp_map, g_bin_tiles_trace);
     return hipGetLastError();
 }
 

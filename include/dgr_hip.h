@@ -182,7 +182,8 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
 /* ---- stage-wise access for tests and profiling (views into the opaque state buffers) ---- */
 /* Copies one named array of a state buffer to `dst` (device or host pointer).  Names: "depths", "radii",
  * "means2D", "conic_opacity", "rgb", "clamped", "tiles_touched" (geometry); "point_list", "keys" (binning);
- * "ranges", "tile_sched", "sched_flag" (one word: whether this frame's blend kernels use the schedule), "n_contrib", "n_valid",
+ * "ranges", "tile_sched", "sched_flag" (one word, the frame's blend flags: bit 0 = its blend kernels use the schedule, bit 1 = the
+ * binning buffer overflowed, bit 2 = quadrant lane lists: option "lane_lists"), "n_contrib", "n_valid",
  * "final_T" (image; the last two: full variant).  Layout conversion to the reference's element types is done on the fly.
  * `num_rendered` instances are exported; `binning_capacity` is the capacity the binning buffer was carved with
  * (= num_rendered after dgr_*_forward, the caller's capacity after *_presized).  Returns the element count, or < 0. */
@@ -294,6 +295,12 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
  *     came back through dgr_status_arm also reports its longest tile list, and the next forward of that shape (device, P, width,
  *     height) skips the schedule kernel when that list was within twice the mean + 32 -- on an even frame the schedule is a
  *     launch and 11 us in front of the blend for nothing.  Forwards that report nothing keep it.  Results never depend on it.
+ *  "lane_lists" (default 2): the lists the LIGHT blend kernels walk.  1 = one list per half of a quadrant wave (forward, tracking
+ *     backward) and paired lists (mapping backward); 0 = one list per quadrant wave (rounds 1-7); 2 = by the FRAME, on the device:
+ *     the binning kernel flags a frame of big splats (mean run of tiles per Gaussian, tile row and segment above 2.5), where
+ *     nearly every entry lives in both halves of its quadrant and the finer lists cost 3 % for nothing, in the frame's state;
+ *     forward and backward branch on that word.  Images never depend on it; gradients differ by summation order only.
+ *     (DGR_FWD_HALVES = 0 / 1 in the environment sets the initial value.)
  *  "lds_count" (default 1): how the forward bins a frame's tile instances.  1 = the two-level segment binning
  *     (csrc/segment_binning.hip: pairs per 16-, 8- or 4-tile row segment, tile lists built and sorted in LDS; no global
  *     atomics, no cleared counters) whenever the frame's segment tables fit LDS (up to 8 192 four-tile segments, i.e.

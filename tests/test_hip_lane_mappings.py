@@ -5,8 +5,9 @@ walks half-wave lists from those tags, the mapping backward pairs list entries b
 backward and are not reached by the other parity tests:
   * alpha_mode 2 (glibc's expf in the double pipe, kept for A/B): half-wave forward, but a backward with one list per quadrant
     wave from the 4-bit tags (the half-wave forms spill a register there) -- held against the oracle in ITS exp mode 1;
-  * DGR_FWD_HALVES=0 (rounds 1-7's mapping in forward and backward) is a per-process switch: covered by the soak
-    (profiles/r8/soak_final.txt), here only through a child process on one scene.
+  * one list per quadrant wave in forward and backward (rounds 1-7's mapping): since round 9 the choice of the FRAME -- its binning
+    kernel flags a frame of big splats in the frame's state, forward and backward branch on the flag (option "lane_lists":
+    0 / 1 force one, 2 = by the frame; DGR_FWD_HALVES = 0 / 1 sets the initial value, covered through a child process).
 Every mode of the backward (mapping + tracking, mapping only, tracking only) at the bars of tests/test_hip_light_parity.py:
 threshold-carrying images bit for bit, gradients at 1e-5 of scale with no outlier rows."""
 import os
@@ -50,6 +51,52 @@ def test_heavy_tailed_scene_in_every_backward_mode(oracle, mode):
     from dgr_amd.synth import heavy_tail_scene
     s = heavy_tail_scene(make_scene(30000, 640, 480, 4), frac=0.05, sigma_px=(10, 200), seed=9)
     check_backward(oracle, s, 2, what="heavy tail, lane mappings", **mode)
+
+
+@pytest.fixture
+def lane_lists():
+    from dgr_amd import _capi
+    _capi.load()
+    yield lambda v: _capi.set_option("lane_lists", v)
+    _capi.set_option("lane_lists", 2)
+
+
+def quadrant_flag(s, d):
+    return int(hh.hip_state("sched_flag", s, d)[0] >> 2) & 1
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("lists", [0, 1])
+def test_either_lane_mapping_forced(oracle, lane_lists, lists, mode):
+    """lane_lists = 0 / 1: the frame's flag says what was asked for, and forward and backward that branch on it meet the bars."""
+    s = make_scene(20000, 320, 200, 3)
+    lane_lists(lists)
+    d, st, ref = check_backward(oracle, s, 3, what=f"lane_lists={lists}", **mode)
+    assert quadrant_flag(s, d) == 1 - lists
+    assert_images_carry_the_references_bits(d, st, ref, s)
+
+
+def test_the_frame_decides_its_lane_lists(oracle, lane_lists):
+    """lane_lists = 2 (the default): small splats -> half-wave lists, big splats -> quadrant lists, decided by the binning kernel for
+    the frame at hand; the images are the same bits whichever it takes."""
+    import numpy as np
+    from dgr_amd.synth import heavy_tail_scene
+    small = make_scene(100000, 640, 480, 0)
+    big = heavy_tail_scene(make_scene(30000, 640, 480, 4), frac=0.05, sigma_px=(10, 200), seed=9)
+    for s, want in ((small, 0), (big, 1), (small, 0)):
+        lane_lists(2)
+        _, d = hh.hip_forward(s, 3)
+        assert quadrant_flag(s, d) == want
+        lane_lists(want)                                   # the OTHER mapping, forced (option 0 = quadrant lists = flag 1)
+        _, e = hh.hip_forward(s, 3)
+        assert quadrant_flag(s, e) == 1 - want
+        for k in ("color", "depth", "depth_median", "opacity_map", "gau_related_pixels"):
+            assert np.array_equal(d[k], e[k]), k
+        for name in ("n_contrib", "point_list", "contribution_tags"):
+            assert np.array_equal(hh.hip_state(name, s, d), hh.hip_state(name, s, e)), name
+    lane_lists(2)
+    check_backward(oracle, big, 2, what="big splats, the frame's own choice")
+    check_backward(oracle, small, 3, what="small splats, the frame's own choice")
 
 
 def test_the_old_lane_mapping_in_a_child_process():
