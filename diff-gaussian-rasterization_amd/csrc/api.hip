@@ -565,15 +565,15 @@ __global__ void export_geom_kernel(int kind, int P, dgr::GeometryView g, void* d
     const bool vis = g.radii[i] > 0;
     switch (kind) {
         case EX_MEANS2D: {
-            const float4 q = g.rec[3 * (size_t)i];
+            const float4 q = g.rec[DGR_REC_STRIDE * (size_t)i];
             ((float2*)dst)[i] = vis ? make_float2(q.x, q.y) : make_float2(0, 0);
         } break;
         case EX_CONIC_OPACITY: {
-            const float4 q0 = g.rec[3 * (size_t)i], q1 = g.rec[3 * (size_t)i + 1];
+            const float4 q0 = g.rec[DGR_REC_STRIDE * (size_t)i], q1 = g.rec[DGR_REC_STRIDE * (size_t)i + 1];
             ((float4*)dst)[i] = vis ? make_float4(q1.x, q1.y, q1.z, q0.w) : make_float4(0, 0, 0, 0);
         } break;
         case EX_RGB: {
-            const float4 q = g.rec[3 * (size_t)i + 2];
+            const float4 q = g.rec[DGR_REC_STRIDE * (size_t)i + 2];
             float* d = (float*)dst + 3 * (size_t)i;
             d[0] = vis ? q.x : 0; d[1] = vis ? q.y : 0; d[2] = vis ? q.z : 0;
         } break;
@@ -595,15 +595,26 @@ __global__ void export_keys_kernel(dgr::ImageView img, dgr::BinningView bin, dgr
     for (uint32_t i = rg.x + threadIdx.x; i < rg.y; i += blockDim.x)
         dst[i] = ((uint64_t)tile << 32) | __float_as_uint(g.depths[bin.point_list[i] & DGR_ID_MASK]);
 }
-// the sorted Gaussian ids without the light forward's contribution tags (top 4 bits; render_common.h)
+// the sorted Gaussian ids without the full forward's contribution tags (top 4 bits; render_common.h)
 __global__ void export_point_list_kernel(const uint32_t* src, uint32_t* dst, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i] & DGR_ID_MASK;
 }
-// ... and the tags alone (tests)
+// ... and the tags alone (tests): 4 bits, bit w = quadrant wave w -- the full variant's from the list entries, the light variant's
+// folded from its tag bytes per half (`half` = 1: the bytes as they are, bit 2 w + h)
 __global__ void export_tags_kernel(const uint32_t* src, uint8_t* dst, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = (uint8_t)(src[i] >> DGR_TAG_SHIFT);
+}
+__global__ void export_tag_bytes_kernel(const uint8_t* src, uint8_t* dst, int n, int half) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t t = src[i];
+    if (!half) {
+        t = (t | (t >> 1)) & 0x55u;
+        t = (t & 1u) | ((t >> 1) & 2u) | ((t >> 2) & 4u) | ((t >> 3) & 8u);
+    }
+    dst[i] = (uint8_t)t;
 }
 
 }  // namespace
@@ -1556,13 +1567,15 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
     if (n == "rgb") return geomk(EX_RGB) ? -1 : 3L * P;
     if (n == "clamped") return geomk(EX_CLAMPED) ? -1 : 3L * P;
     if (n == "tiles_touched") return geomk(EX_TILES_TOUCHED) ? -1 : P;
-    if (n == "point_list" || n == "contribution_tags") {
+    if (n == "point_list" || n == "contribution_tags" || n == "contribution_tags_full" || n == "half_tags") {
         if (num_rendered > 0) {
             const dim3 grid((num_rendered + 255) / 256);
             if (n == "point_list")
                 hipLaunchKernelGGL(export_point_list_kernel, grid, dim3(256), 0, st, bin.point_list, (uint32_t*)dst, num_rendered);
-            else
+            else if (n == "contribution_tags_full")
                 hipLaunchKernelGGL(export_tags_kernel, grid, dim3(256), 0, st, bin.point_list, (uint8_t*)dst, num_rendered);
+            else  // (the light variant's tag bytes: in the binning's pair_cov bytes, render_common.h)
+                hipLaunchKernelGGL(export_tag_bytes_kernel, grid, dim3(256), 0, st, bin.pair_cov, (uint8_t*)dst, num_rendered, n == "half_tags" ? 1 : 0);
             if (hipGetLastError() != hipSuccess) return -1;
         }
         return num_rendered;

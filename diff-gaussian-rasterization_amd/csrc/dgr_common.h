@@ -3,8 +3,8 @@
 // The reference carves GeometryState / BinningState / ImageState out of three byte buffers
 // (L/cuda_rasterizer/rasterizer_impl.h:29-72, rasterizer_impl.cu:155-193).  The buffers stay
 // opaque at the boundary, so the layout here is chosen for the MI355X kernels instead:
-//   geometry : one 48-byte render record per Gaussian (3 x float4, gathered as whole 16-B
-//              pieces by the blend kernels), depth, radius, tile rect (4 x u16), clamp bits (the 3D covariance is
+//   geometry : one 48-byte render record per Gaussian in a 64-byte slot (3 x float4, gathered as whole 16-B
+//              pieces by the blend kernels, from ONE L2 line), depth, radius, tile rect (4 x u16), clamp bits (the 3D covariance is
 //              NOT kept: the backward re-forms it from scale and rotation, same expression, same bits)
 //   image    : per-tile {count, fill, range} + per-pixel n_contrib (+ full: final T, n_valid)
 //   binning  : per-instance 64-bit sort keys (depth bits << 32 | gaussian id), the sorted id list, arrival ranks
@@ -43,8 +43,14 @@ __device__ inline uint32_t sched_class(uint32_t n) {
 // q0 = {x_pix, y_pix, depth, opacity}   (means2D, depths, conic_opacity.w of the reference)
 // q1 = {conic a, conic b, conic c, 0}
 // q2 = {r, g, b, 0}                     (geomState.rgb, or a copy of colors_precomp)
+// 48 bytes of data in a 64-byte slot (DGR_REC_STRIDE float4s): the blend kernels gather one record per list entry, the L2 fetches
+// whole 64-byte lines (TCC_EA0_RDREQ_32B = 0 on gfx950), and a record at a 48-byte stride lies across two lines half of the time
+// -- 1.5 lines per gather against exactly one (profiles/r9/fwd_traffic.txt).  The fourth float4 is never written or read.
+#ifndef DGR_REC_STRIDE
+#define DGR_REC_STRIDE 4
+#endif
 struct GeometryView {
-    float4* rec;        // [3P]
+    float4* rec;        // [DGR_REC_STRIDE * P]
     float* depths;      // [P]
     int* radii;         // [P] internal copy (the caller's `radii` may be NULL)
     ushort4* rect;      // [P] {xmin, ymin, xmax, ymax} in tiles; all-zero when culled
@@ -61,7 +67,7 @@ struct GeometryView {
 __host__ __device__ inline GeometryView carve_geometry(char* base, int P) {
     GeometryView g;
     size_t o = 0;
-    g.rec = (float4*)(base + o);      o = align_up(o + sizeof(float4) * 3 * (size_t)P, 256);
+    g.rec = (float4*)(base + o);      o = align_up(o + sizeof(float4) * DGR_REC_STRIDE * (size_t)P, 256);
     g.depths = (float*)(base + o);    o = align_up(o + sizeof(float) * (size_t)P, 256);
     g.radii = (int*)(base + o);       o = align_up(o + sizeof(int) * (size_t)P, 256);
     g.rect = (ushort4*)(base + o);    o = align_up(o + sizeof(ushort4) * (size_t)P, 256);

@@ -391,7 +391,7 @@ __device__ __forceinline__ FwdGeom fwd_view_geometry(const PreprocessFwdArgs& a,
                 }
                 rect = make_ushort4((unsigned short)tx0, (unsigned short)ty0, (unsigned short)tx1, (unsigned short)ty1);
                 a.geom.depths[idx] = p_view.z;
-                float4* rec = a.geom.rec + 3 * (size_t)idx;
+                float4* rec = a.geom.rec + DGR_REC_STRIDE * (size_t)idx;
                 rec[0] = make_float4(pix, piy, p_view.z, a.opacities[idx]);
                 rec[1] = make_float4(conic.x, conic.y, conic.z, 0.0f);
                 if (!need_sh) rec[2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
@@ -443,7 +443,7 @@ __device__ __forceinline__ void fwd_view_colour(const PreprocessFwdArgs& a, int 
     }
     a.geom.clamped[idx] = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
     rgb = make_float3(fmaxf(res.x, 0.0f), fmaxf(res.y, 0.0f), fmaxf(res.z, 0.0f));
-    a.geom.rec[3 * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
+    a.geom.rec[DGR_REC_STRIDE * (size_t)idx + 2] = make_float4(rgb.x, rgb.y, rgb.z, 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -116,9 +116,9 @@ __device__ __forceinline__ unsigned reach_code(const float4& q0, const float4& q
 template <int AM, bool HALF_CODES = false, class S>
 __device__ __forceinline__ unsigned stage_one(S& s, int slot, uint32_t gid, const float4* __restrict__ rec,
                                               float tile_x0, float tile_y0) {
-    const float4 q0 = rec[3 * (size_t)gid + 0];
-    const float4 q1 = rec[3 * (size_t)gid + 1];
-    const float4 q2 = rec[3 * (size_t)gid + 2];
+    const float4 q0 = rec[DGR_REC_STRIDE * (size_t)gid + 0];
+    const float4 q1 = rec[DGR_REC_STRIDE * (size_t)gid + 1];
+    const float4 q2 = rec[DGR_REC_STRIDE * (size_t)gid + 2];
     const float o = q0.w;
     // log-domain threshold: alpha >= 15/255 <=> p2 >= log2(15/(255 o)); the loop compares against a slightly lower
     // value and re-tests alpha itself on the rare path, so decisions are those of the linear-domain test.
@@ -166,45 +166,54 @@ __device__ __forceinline__ unsigned reach_code(const float4& q0, const float4& q
     return (xl && yt ? 1u : 0u) | (xr && yt ? 2u : 0u) | (xl && yb ? 4u : 0u) | (xr && yb ? 8u : 0u);
 }
 
-// Contribution tags.  The forward blend kernel marks every tile-list entry with the set of quadrant waves in which at
-// least one pixel blended it (4 bits, kept in the top bits of the point_list entry: Gaussian ids stay below 2^28).
-// A (pixel, Gaussian) pair is valid in the backward exactly when the forward blended it (same alpha expression, and
-// position <= the pixel's last contributor), so the backward builds its per-wave lists from the tags: no bounding-box
-// test, no wave-level pre-test, and instances no pixel blended are never loaded.
+// Contribution tags.  The forward blend kernel marks every tile-list entry with the set of quadrant waves in which at least one
+// pixel blended it.  A (pixel, Gaussian) pair is valid in the backward exactly when the forward blended it (same alpha
+// expression, and position <= the pixel's last contributor), so the backward builds its per-wave lists from the tags: no
+// bounding-box test, no wave-level pre-test, and instances no pixel blended are never loaded.
+//   full variant : 4 bits (bit w = quadrant wave w) in the top bits of the point_list entry (Gaussian ids stay below 2^28);
+//   light variant: one BYTE per list entry, per HALF of a quadrant (bit 2 w + h: half h -- pixel rows 4 h .. 4 h + 3, lanes
+//       32 h .. -- of quadrant wave w), in an instance-major byte array beside the list; the list itself is not written by the
+//       blend (round 9: the tag write-back into point_list was 6.4 MB of render_fwd's HBM writes per 1080p view, and the byte
+//       array carried a superset of it already -- profiles/r9/fwd_traffic.txt).  A forward that walked quadrant lists sets both
+//       halves' bits of a quadrant; a backward that walks quadrant lists folds the two bits of each quadrant.
 constexpr int TAG_SHIFT = DGR_TAG_SHIFT;
 constexpr uint32_t ID_MASK = DGR_ID_MASK;
+enum { TAGS_IN_LIST = 0, TAGS_BYTES_QUADRANT = 1, TAGS_BYTES_HALVES = 2 };
 
-// The instance-major byte array of tags per HALF of a quadrant (bit 2 w + h: half h -- pixel rows 4 h .. 4 h + 3, lanes 32 h .. --
-// of quadrant wave w), written by the light forward beside the 4-bit tag for the backward's half-wave lists.  It lives in the
-// binning buffer's `pair_cov` / `ranks` bytes, which the binning is done with when the blend runs; both blend kernels find it
-// from the capacity the binning kernel left in cursor[2] (sched_flag = cursor + 3).
+// The light variant's tag bytes live in the binning buffer's `pair_cov` / `ranks` bytes, which the binning is done with when the
+// blend runs; both blend kernels find them from the capacity the binning kernel left in cursor[2] (sched_flag = cursor + 3).
+// INVARIANT: the light forward writes the byte of EVERY entry of every tile list of its frame (zero for entries nobody blended,
+// and for the tail of a list whose tile finished early) -- the bytes underneath are the binning's, and nothing else clears them.
+// Whoever keeps a view's state between forward and backward must treat ranks / pair_cov as clobbered by the blend (BinningView,
+// dgr_common.h).
 __device__ __forceinline__ uint8_t* half_tags(const uint32_t* point_list, const uint32_t* sched_flag) {
     return carve_binning(reinterpret_cast<char*>(const_cast<uint32_t*>(point_list)), (size_t)sched_flag[-1]).pair_cov;
 }
+// bit w of a 4-bit quadrant code -> bit 2 w (the upper half's place in a tag byte), and back (either half set)
+__device__ __forceinline__ uint32_t spread4(uint32_t c) { return (c & 1u) | ((c & 2u) << 1) | ((c & 4u) << 2) | ((c & 8u) << 3); }
+__device__ __forceinline__ uint32_t fold8(uint32_t t) {
+    t = (t | (t >> 1)) & 0x55u;
+    return (t & 1u) | ((t >> 1) & 2u) | ((t >> 2) & 4u) | ((t >> 3) & 8u);
+}
 
-// backward staging: returns the entry's tag; untagged entries are not loaded.
-// HALF_CODES (half-wave lists): returns the forward's tag per HALF of a quadrant instead (bit 2 w + h; `tag8` = half_tags()).
-// INVARIANT: *tag8 is read only for an entry whose 4-bit point_list tag is non-zero -- the byte array shares its bytes with the
-// binning's ranks / pair_cov, which the forward's binning leaves there and NOTHING clears: a byte is a tag only where the same
-// forward's blend wrote it, and it wrote it exactly where it also set the 4-bit tag (render_light.hip: flush_slot).  Whoever keeps a
-// view's state between forward and backward must treat ranks / pair_cov as clobbered by the blend (BinningView, dgr_common.h).
-template <int AM, bool HALF_CODES = false, class S>
+// backward staging: returns the entry's tag (TAGS: where it lives and in which form it is wanted); untagged entries are not loaded.
+template <int AM, int TAGS = TAGS_IN_LIST, class S>
 __device__ __forceinline__ unsigned stage_tagged(S& s, int slot, uint32_t entry, const float4* __restrict__ rec,
                                                  const uint8_t* __restrict__ tag8 = nullptr) {
     constexpr float PSCALE = AlphaPath<AM>::PSCALE;
-    unsigned code = entry >> TAG_SHIFT;
+    unsigned code = TAGS == TAGS_IN_LIST ? entry >> TAG_SHIFT : (unsigned)*tag8;
     if (code == 0u) return 0u;
+    if (TAGS == TAGS_BYTES_QUADRANT) code = fold8(code);
     const uint32_t gid = entry & ID_MASK;
-    const float4 q0 = rec[3 * (size_t)gid + 0];
-    const float4 q1 = rec[3 * (size_t)gid + 1];
-    const float4 q2 = rec[3 * (size_t)gid + 2];
+    const float4 q0 = rec[DGR_REC_STRIDE * (size_t)gid + 0];
+    const float4 q1 = rec[DGR_REC_STRIDE * (size_t)gid + 1];
+    const float4 q2 = rec[DGR_REC_STRIDE * (size_t)gid + 2];
     s.rec[2 * slot] = make_float4(q0.x, q0.y, -0.5f * PSCALE * q1.x, -0.5f * PSCALE * q1.z);
     // (.z: 4 * slot = the byte offset of the slot's accumulator column; .w: byte offset of its rgbd entry -- the backward
     //  kernels address LDS with both directly, and compare .z with 4 * (slots at or before the pixel's last contributor))
     s.rec[2 * slot + 1] = make_float4(-PSCALE * q1.y, q0.w, __int_as_float(slot * 4), __int_as_float(slot * 16));
     s.rgbd[slot] = make_float4(q2.x, q2.y, q2.z, q0.z);
     s.id[slot] = gid;
-    if (HALF_CODES) code = *tag8;
     return code;
 }
 
@@ -283,7 +292,7 @@ __device__ __forceinline__ int build_half_lists(S& s, unsigned code, int tid, in
 // pixel still meets its Gaussians in list order -- and the step's reduction stops before the stage that adds the halves
 // (wave_reduce.h).  Every entry is still delivered exactly once with twelve lane-atomics (half-wave lists, where an entry of both
 // halves is delivered twice, drown in them: DESIGN.md Appendix A).
-//   code8 : stage_tagged<AM, true>'s code (bit 2 w + h: half h of quadrant wave w)
+//   code8 : stage_tagged<AM, TAGS_BYTES_HALVES>'s code (bit 2 w + h: half h of quadrant wave w)
 //   phase 1: the four compacted quadrant lists as in build_lists, entry = record offset | type (1 upper, 2 lower, 3 both);
 //   phase 2: every wave pairs its own list (of at most 64 entries: one rank per lane; longer lists stay unpaired): ranks
 //            (2 m, 2 m + 1) first, then (2 m + 1, 2 m + 2) where neither was taken -- a window of five entries, read through

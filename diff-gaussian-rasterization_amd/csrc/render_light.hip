@@ -6,7 +6,7 @@
 // Shape of the computation on CDNA4 (wave64, LDS 160 KB/CU, ONE scalar unit per CU):
 //  * one 256-thread workgroup per tile, wave w owns the 8x8-pixel quadrant (w&1, w>>1);
 //  * the sorted tile list is staged 256 instances at a time into LDS: a 32-byte traversal record
-//    {x, y, a2, b2 | c2, opacity, slot, -} plus {r, g, b, depth} and the Gaussian id, one 48-byte gather
+//    {x, y, a2, b2 | c2, opacity, slot, -} plus {r, g, b, depth} and the Gaussian id, one 48-byte gather (one 64-byte line)
 //    per thread;
 //  * while staging, every thread bounds the region where its Gaussian can reach alpha >= 15/255 (the
 //    ellipse q(d) <= 2 ln(255 o / 15), boxed with a safety margin) and tests it against the eight
@@ -54,34 +54,29 @@ struct StagedFwd {
 };
 
 // Per-slot results of the batch staged at list position `pos0`: the median statistics go to the Gaussian, the
-// contribution tag into the top bits of the list entry (render_common.h).
+// contribution tag into the entry's tag byte (render_common.h).
 // four 0/1 bytes -> four bits
 __device__ __forceinline__ uint32_t pack4(uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); }
 
 template <class SF>
 __device__ __forceinline__ void flush_slot(const SF& sf, const RenderFwdLightArgs& a, uint8_t* tag8, uint32_t pos0, int tid, bool staged) {
     if (!staged) return;
-    uint32_t tag = pack4(sf.hit[tid]);
-    if constexpr (!SF::staged_t::HAS_ID) {  // (the half-wave kernel) lower halves: the bytes of the record's third word
+    const uint32_t up = pack4(sf.hit[tid]);
+    uint32_t t8;  // bit 2 w <- upper half of wave w, bit 2 w + 1 <- its lower half
+    if constexpr (!SF::staged_t::HAS_ID) {  // (the half-wave body) lower halves: the bytes of the record's third word
         const uint32_t lo = pack4(__float_as_uint(sf.f.rec[2 * tid + 1].z));
-        if ((tag | lo) != 0u) {
-            // bit 2 w <- upper half of wave w, bit 2 w + 1 <- its lower half
-            const uint32_t up = tag;
-            const uint32_t t8 = (up & 1u) | ((up & 2u) << 1) | ((up & 4u) << 2) | ((up & 8u) << 3) |
-                                ((lo & 1u) << 1) | ((lo & 2u) << 2) | ((lo & 4u) << 3) | ((lo & 8u) << 4);
-            tag8[pos0 + tid] = (uint8_t)t8;
-        }
-        tag |= lo;
+        t8 = spread4(up) | (spread4(lo) << 1);
+    } else {                                // (the quadrant body) a quadrant's tag stands for both of its halves
+        t8 = spread4(up) * 3u;
     }
-    if (tag == 0u) return;  // nothing blended this instance
-    uint32_t gid;
-    if constexpr (SF::staged_t::HAS_ID) gid = sf.f.id[tid];
-    else gid = a.point_list[pos0 + tid];  // (untagged still: this thread is the entry's only writer)
-    if (sf.cnt[tid] != 0u) {
+    tag8[pos0 + tid] = (uint8_t)t8;         // every staged entry, blended or not: the byte underneath is the binning's
+    if (sf.cnt[tid] != 0u) {                // (which implies a tag)
+        uint32_t gid;
+        if constexpr (SF::staged_t::HAS_ID) gid = sf.f.id[tid];
+        else gid = a.point_list[pos0 + tid];
         atomicAdd(&a.gau_uncertainty[gid], sf.unc[tid]);
         atomicAdd(&a.gau_related_pixels[gid], (int)sf.cnt[tid]);
     }
-    a.point_list[pos0 + tid] = gid | (tag << TAG_SHIFT);
 }
 
 template <int AM, bool HALVES>
@@ -98,7 +93,7 @@ __device__ __forceinline__ void render_fwd_light_body(const RenderFwdLightArgs& 
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
     const int my_list = HALVES ? 2 * wave + (lane >> 5) : wave;
     // where this lane marks "blended": byte `wave` of hit[j] -- HALVES: lanes 32-63 in byte `wave` of the record's spare word
-    uint8_t* const tag8 = HALVES ? half_tags(a.point_list, a.sched_flag) : nullptr;
+    uint8_t* const tag8 = half_tags(a.point_list, a.sched_flag);
     unsigned char* const mark_base = (HALVES && lane >= 32) ? reinterpret_cast<unsigned char*>(&s.rec[1].z) + wave
                                                              : reinterpret_cast<unsigned char*>(sf.hit) + wave;
     const int mark_stride = (HALVES && lane >= 32) ? 32 : 4;
@@ -171,6 +166,8 @@ __device__ __forceinline__ void render_fwd_light_body(const RenderFwdLightArgs& 
     }
     __syncthreads();
     if (have_flush) flush_slot(sf, a, tag8, range.x + last_base, tid, tid < total - last_base);
+    // the tail of a list whose tile finished early was never staged: nobody blended it (render_common.h: the tag bytes' invariant)
+    for (int p = (have_flush ? last_base + DGR_TILE_PIX : 0) + tid; p < total; p += DGR_TILE_PIX) tag8[range.x + p] = 0;
 
     // A forward whose binning buffer was too small has rendered EMPTY tile lists (bin_tiles left every range {0, 0}): in lazy mode
     // the host learns of it a call or two later, so the images must not look like a frame -- they are NaN, every value
@@ -342,7 +339,7 @@ __device__ __forceinline__ void render_bwd_light_body(const RenderBwdLightArgs& 
         my_comp = ((lane & 15) == 0 && c < 3) ? (c == 0 ? 4 : c == 1 ? 5 : 13) : -1;
     }
     const int my_list = HALVES ? 2 * wave + (lane >> 5) : wave;
-    const uint8_t* const tag8 = HALVES ? half_tags(a.point_list, a.sched_flag) : nullptr;
+    const uint8_t* const tag8 = half_tags(a.point_list, a.sched_flag);
 
     // this lane's accumulator row (column = slot); DET: in its wave's own plane
     float* const my_acc = sb.acc + (DET ? wave * SB::PLANE : 0) + (my_comp >= 0 ? my_comp : 0) * BWD_LD;
@@ -353,7 +350,7 @@ __device__ __forceinline__ void render_bwd_light_body(const RenderBwdLightArgs& 
         const int cnt = hi - lo;
         __syncthreads();  // previous batch fully flushed / consumed
         unsigned code = 0;
-        if (tid < cnt) code = stage_tagged<AM, HALVES>(s, tid, a.point_list[range.x + lo + tid], a.rec, tag8 + (range.x + lo + tid));
+        if (tid < cnt) code = stage_tagged<AM, HALVES ? TAGS_BYTES_HALVES : TAGS_BYTES_QUADRANT>(s, tid, a.point_list[range.x + lo + tid], a.rec, tag8 + (range.x + lo + tid));
         if (!DET) {  // (DET: a plane's column is written by its wave iff the entry's tag names the wave -- nothing to clear)
 #pragma unroll
             for (int k = 0; k < NACC_LIGHT; k++)

@@ -34,9 +34,9 @@ def test_state_sizes_scale_as_documented():
     lib = _capi.load()
     assert lib.dgr_geometry_bytes(0) == 0
     g1, g2 = lib.dgr_geometry_bytes(1000), lib.dgr_geometry_bytes(2000)
-    # 48 (rec) + 4 (depth) + 4 (radius) + 8 (rect) + 1 (clamped) + 4 (goff) + 48 (SH direction derivatives) B per
-    # Gaussian, plus the per-256-Gaussian block totals and 256-byte alignment of each array
-    assert 117 * 1000 <= g1 <= 117 * 1000 + 10 * 256 and g2 > g1
+    # 64 (rec: 48 bytes of data in a 64-byte slot, one L2 line per gather) + 4 (depth) + 4 (radius) + 8 (rect) + 1 (clamped) +
+    # 4 (goff) + 48 (SH direction derivatives) B per Gaussian, plus the per-256-Gaussian block totals and 256-byte alignment of each array
+    assert 133 * 1000 <= g1 <= 133 * 1000 + 10 * 256 and g2 > g1
     # 24 B per instance (list, key scratch, ranks / pair columns, pair keys) + the segment binning's tables: per tile row
     # of a 64x64 frame (4 tiles: one 16-tile segment) one word per bin_segments workgroup (256) for the run starts (+ one
     # closing row) and one for the running instance counts
