@@ -181,14 +181,15 @@ __host__ __device__ inline BinningView carve_binning(char* base, size_t cap) {
 // Forward-only workspace of the segment binning (segment_binning.hip), carved behind the binning arrays.  A tile row is cut
 // into segments of 16, 8 or 4 tiles (chosen per call; the tables are carved for 4); workgroup w of bin_segments (at most
 // SEG_MAX_WGS) leaves
-//   pair_off[s][w]  start of its run of pairs for segment s (row nseg: end of its region), and
+//   pair_off[s][w]  start of its run of pairs for segment s (row nseg: end of its region; row nseg + 1: how many of its Gaussians
+//                   are on screen -- the frame's instances per visible Gaussian decide the blend kernels' lane lists), and
 //   inst_pre[s][w]  its instances in the segments 0..s (a running sum): the column sums are the list starts.
 #define SEG_TILES_MAX 16
 #define SEG_TILES_MIN 4
 #define SEG_MAX_WGS 256
 #define SEG_K1_LDS_MAX (128 * 1024)  // bin_segments holds 16 bytes per segment in LDS
 struct SegmentTables {
-    uint32_t* pair_off;  // [(nseg + 1) * SEG_MAX_WGS]
+    uint32_t* pair_off;  // [(nseg + 2) * SEG_MAX_WGS]
     uint32_t* inst_pre;  // [nseg * SEG_MAX_WGS]
     size_t bytes;
 };
@@ -198,7 +199,7 @@ __host__ __device__ inline SegmentTables carve_segment_tables(char* base, int W,
     const size_t nseg = gy * ((gx + SEG_TILES_MIN - 1) / SEG_TILES_MIN);
     size_t o = 0;
     if (gx == 0 || gy == 0 || nseg * 16 > SEG_K1_LDS_MAX) { t.pair_off = nullptr; t.inst_pre = nullptr; t.bytes = 0; return t; }
-    t.pair_off = (uint32_t*)(base + o); o = align_up(o + 4 * (nseg + 1) * SEG_MAX_WGS, 256);
+    t.pair_off = (uint32_t*)(base + o); o = align_up(o + 4 * (nseg + 2) * SEG_MAX_WGS, 256);
     t.inst_pre = (uint32_t*)(base + o); o = align_up(o + 4 * nseg * SEG_MAX_WGS, 256);
     t.bytes = o;
     return t;

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(K1_THREADS) bin_segments_kernel(int P, int per
     // (pairs; then the start of each segment's run, then the fill cursors) | inst[nseg]
     extern __shared__ unsigned long long lds64[];
     __shared__ uint32_t wsum[K1_THREADS / 64];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_base, s_vis;
     __shared__ uint32_t s_qn;        // the queue of big rectangles (below)
     __shared__ uint4 s_q[BIGQ];      // {x0 | y0 << 16, x1 | y1 << 16, depth bits, Gaussian id}
     const int SEG = 1 << seg_shift;
@@ -169,13 +169,16 @@ __global__ void __launch_bounds__(K1_THREADS) bin_segments_kernel(int P, int per
                 atomicAdd(&both[y * sgx + sx],
                           1ull | ((unsigned long long)(min((int)r.z, sx * SEG + SEG) - max((int)r.x, sx * SEG)) << 32));
     };
+    uint32_t on_screen = 0;  // this thread's Gaussians with a tile rectangle
     for (int first = g0; first < g1; first += NH * K1_THREADS) {
         if (!hold) load_group(first, false);
         if (tid == 0) s_qn = 0u;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NH; k++)
+        for (int k = 0; k < NH; k++) {
+            on_screen += (hr[k].z > hr[k].x && hr[k].w > hr[k].y) ? 1u : 0u;
             if (pairs_of(hr[k]) <= BIG_PAIRS || !enqueue(hr[k], 0.f, 0)) count(hr[k]);
+        }
         __syncthreads();
         const int nq = min((int)s_qn, BIGQ);
         for (int q = tid >> 6; q < nq; q += K1_THREADS / 64) {
@@ -192,10 +195,14 @@ __global__ void __launch_bounds__(K1_THREADS) bin_segments_kernel(int P, int per
         __syncthreads();  // (the queue is rewritten by the next group)
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (tid == 0) s_base = 0u;
+    for (int off = 32; off > 0; off >>= 1) {
+        part += __shfl_xor(part, off, 64);
+        on_screen += __shfl_xor(on_screen, off, 64);
+    }
+    if (tid == 0) { s_base = 0u; s_vis = 0u; }
     __syncthreads();
     if (lane == 0 && part) atomicAdd(&s_base, part);
+    if (lane == 0 && on_screen) atomicAdd(&s_vis, on_screen);
     for (int i = tid; i < nseg; i += K1_THREADS) {
         const unsigned long long v = both[i];
         cnt[i] = (uint32_t)v;
@@ -210,7 +217,10 @@ __global__ void __launch_bounds__(K1_THREADS) bin_segments_kernel(int P, int per
         tb.pair_off[(size_t)s * nwg + wg] = base + cnt[s];
         tb.inst_pre[(size_t)s * nwg + wg] = inst[s];
     }
-    if (tid == 0) tb.pair_off[(size_t)nseg * nwg + wg] = base + total_pairs;
+    if (tid == 0) {
+        tb.pair_off[(size_t)nseg * nwg + wg] = base + total_pairs;
+        tb.pair_off[(size_t)(nseg + 1) * nwg + wg] = s_vis;
+    }
     __syncthreads();
     // ---- pass B: place the pairs; cnt[] now serves as the fill cursors
     auto place = [&](ushort4 r, float depth, int idx) {
@@ -374,17 +384,18 @@ __global__ void __launch_bounds__(K2_THREADS, 6) bin_tiles_kernel(ImageView img,
     const uint32_t gcount = upto - before;
     if (s == 0 && part == 0 && wave == 0) {  // (one wave of one workgroup: the frame's status word and blend flags)
         // bit 2 of the flags: the light blend kernels walk one list per QUADRANT wave instead of one per half-wave (render_common.h:
-        // blend_slot) -- forced by the caller (BLEND_LISTS_QUADRANT) or, with BLEND_LISTS_AUTO, decided here for THIS frame: a frame of
-        // big splats (mean run of tiles per Gaussian, tile row and segment above 2.5; the uniform scene has 1.7-1.9, the heavy-tailed
-        // one 2.9-4.6 depending on the segment size) has nearly every entry in both halves of its quadrants -- nothing for half-wave
-        // lists to skip, nothing to pair -- and pays 3 % for the finer lists (profiles/r8/ab_scenes_halves.txt, r9/ab_lists_fused.txt)
+        // blend_slot) -- forced by the caller (BLEND_LISTS_QUADRANT) or, with BLEND_LISTS_AUTO, decided here for THIS frame: where a
+        // Gaussian on screen touches more than ten tiles on average, nearly every list entry lives in both halves of its quadrants --
+        // nothing for half-wave lists to skip, nothing to pair -- and the finer lists cost more than they save.  The crossing lies
+        // between 8.4 and 11.3 tiles per Gaussian on synth-v1 with scaled splats and between 6.3 and 11.9 on the heavy-tailed scene
+        // with a growing share of big ones (profiles/r9/lists_sweep.txt; either side of it the two mappings differ by < 1 %).
         bool quadrant_lists = (sched_on & BLEND_LISTS_QUADRANT) != 0;
         if (sched_on & BLEND_LISTS_AUTO) {
-            uint32_t runs = 0;  // every (Gaussian, tile row, segment) run of the frame: the ends of the workgroups' pair regions less their starts
-            for (int w = lane; w < nwg; w += 64) runs += tb.pair_off[(size_t)nseg * nwg + w] - tb.pair_off[w];
+            uint32_t vis = 0;  // Gaussians on screen: bin_segments' workgroups left their counts in the tables' last row
+            for (int w = lane; w < nwg; w += 64) vis += tb.pair_off[(size_t)(nseg + 1) * nwg + w];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) runs += __shfl_xor(runs, off, 64);
-            quadrant_lists = 2ull * total > 5ull * runs;
+            for (int off = 32; off > 0; off >>= 1) vis += __shfl_xor(vis, off, 64);
+            quadrant_lists = (unsigned long long)total > 10ull * vis;
         }
         if (lane == 0) {
             img.status[0] = (int)total;

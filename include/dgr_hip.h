@@ -299,7 +299,7 @@ int dgr_l1_loss_backward(void* stream, long n_color, const float* color, const f
  *     launch and 11 us in front of the blend for nothing.  Forwards that report nothing keep it.  Results never depend on it.
  *  "lane_lists" (default 2): the lists the LIGHT blend kernels walk.  1 = one list per half of a quadrant wave (forward, tracking
  *     backward) and paired lists (mapping backward); 0 = one list per quadrant wave (rounds 1-7); 2 = by the FRAME, on the device:
- *     the binning kernel flags a frame of big splats (mean run of tiles per Gaussian, tile row and segment above 2.5), where
+ *     the binning kernels flag a frame of big splats (more than ten tiles per Gaussian on screen, profiles/r9/lists_sweep.txt), where
  *     nearly every entry lives in both halves of its quadrant and the finer lists cost 3 % for nothing, in the frame's state;
  *     forward and backward branch on that word.  Images never depend on it; gradients differ by summation order only.
  *     (DGR_FWD_HALVES = 0 / 1 in the environment sets the initial value.)
