@@ -60,6 +60,11 @@ def test_options_round_trip_and_reject_unknown_names():
     keep = lib.dgr_get_option(b"lds_count")
     assert lib.dgr_set_option(b"lds_count", 2) == 0 and lib.dgr_get_option(b"lds_count") == 2
     assert lib.dgr_set_option(b"lds_count", keep) == 0
+    keep = lib.dgr_get_option(b"lane_lists")   # 2 (the frame picks the blend kernels' lane lists) unless DGR_FWD_HALVES forced one
+    assert keep in (0, 1, 2)
+    for v, want in ((0, 0), (1, 1), (2, 2), (7, 2), (-3, 0)):
+        assert lib.dgr_set_option(b"lane_lists", v) == 0 and lib.dgr_get_option(b"lane_lists") == want
+    assert lib.dgr_set_option(b"lane_lists", keep) == 0
     assert lib.dgr_set_option(b"no_such_option", 1) == _capi.DGR_ERR_BAD_ARGUMENT
     assert b"no_such_option" in lib.dgr_last_error()
     with pytest.raises(ValueError):

@@ -47,13 +47,19 @@ def sh_to_rgb(deg, sh, d):
     return torch.clamp(r + 0.5, min=0.0)
 
 
-def torch_light(s, deg, vis, point_list, ranges, n_contrib, grads):
+def torch_light(s, deg, vis, point_list, ranges, n_contrib, grads, colors_precomp=None, cov3D_precomp=None):
     """Returns (loss, leaves dict, images dict).  `vis`, `point_list`, `ranges`, `n_contrib` come from the oracle's
-    integer path (pinned separately by SURVEY Appendix C); everything float is recomputed here in float64."""
+    integer path (pinned separately by SURVEY Appendix C); everything float is recomputed here in float64.
+    `colors_precomp` [P, 3] / `cov3D_precomp` [P, 6] (xx, xy, xz, yy, yz, zz) replace the SH evaluation / R diag(s^2) R^T as in the
+    reference (L/cuda_rasterizer/forward.cu:208-218, 242-247); their gradients are then leaves `colors` / `cov3D`."""
     f = lambda a: torch.tensor(np.asarray(a, np.float64))  # noqa: E731
     W, H = s.W, s.H
     leaves = dict(means3D=f(s.means), scales=f(s.scales), rotations=f(s.rots), opacities=f(s.opac), shs=f(s.shs),
                   view_ndc=f(s.view), view_depth=f(s.view))
+    if colors_precomp is not None:
+        leaves["colors"] = f(colors_precomp)
+    if cov3D_precomp is not None:
+        leaves["cov3D"] = f(cov3D_precomp)
     for v in leaves.values():
         v.requires_grad_(True)
     view_o, persp, campos, bg, gt = f(s.view), f(s.persp), f(s.campos), f(s.bg), f(s.gt)
@@ -76,6 +82,9 @@ def torch_light(s, deg, vis, point_list, ranges, n_contrib, grads):
                      2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
     sc = leaves["scales"][idx]
     Sigma = R @ torch.diag_embed(sc * sc) @ R.transpose(1, 2)
+    if cov3D_precomp is not None:  # (an off-diagonal value stands at two places of Sigma: its gradient is their sum, backward.cu:281-283)
+        c6 = leaves["cov3D"][idx]
+        Sigma = torch.stack([c6[:, 0], c6[:, 1], c6[:, 2], c6[:, 1], c6[:, 3], c6[:, 4], c6[:, 2], c6[:, 4], c6[:, 5]], 1).reshape(-1, 3, 3)
     # A-P 4 / A-G: cov2D = A Sigma A^T + 0.3 I, A = Ju Rcam, t.x/t.z clamped to +-1.3 tanfov
     fx, fy = W / (2.0 * s.tanfovx), H / (2.0 * s.tanfovy)
     limx, limy = 1.3 * s.tanfovx, 1.3 * s.tanfovy
@@ -93,7 +102,7 @@ def torch_light(s, deg, vis, point_list, ranges, n_contrib, grads):
     # A-P 9
     dirs = m - campos
     dirs = dirs / dirs.norm(dim=1, keepdim=True)
-    rgb = sh_to_rgb(deg, leaves["shs"][idx], dirs)
+    rgb = sh_to_rgb(deg, leaves["shs"][idx], dirs) if colors_precomp is None else leaves["colors"][idx]
     opac = leaves["opacities"][idx, 0]
     slot = np.full(s.P, -1, np.int64)
     slot[np.nonzero(vis)[0]] = np.arange(len(idx))
