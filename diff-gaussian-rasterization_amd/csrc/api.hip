@@ -715,6 +715,12 @@ int dgr_light_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bi
                 gau_related_pixels, radii};
     int rc = check_common(c);
     if (rc) return rc;
+    // The callback entry points block the host to size the binning buffer, as the reference does (rasterizer_impl.cu:287): on a
+    // capturing stream that synchronisation would fail AND invalidate the capture -- refuse before anything touches the stream.
+    if (dgr_stream_is_capturing(stream)) {
+        g_last_error = "the resize-callback forward blocks the host (it sizes the binning buffer): it cannot be captured into a graph -- use the presized entry point";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
     if (P == 0) return zero_outputs(c, st);
     char* gptr = geometryBuffer(dgr_geometry_bytes(P), alloc_user);
     char* iptr = imageBuffer(dgr_image_bytes(width, height), alloc_user);
@@ -867,6 +873,12 @@ int dgr_full_forward(void* stream, dgr_alloc_fn geometryBuffer, dgr_alloc_fn bin
     if (num_related_primitives) *num_related_primitives = 0;
     int rc = check_common(c);
     if (rc) return rc;
+    // The callback entry points block the host to size the binning buffer, as the reference does (rasterizer_impl.cu:287): on a
+    // capturing stream that synchronisation would fail AND invalidate the capture -- refuse before anything touches the stream.
+    if (dgr_stream_is_capturing(stream)) {
+        g_last_error = "the resize-callback forward blocks the host (it sizes the binning buffer): it cannot be captured into a graph -- use the presized entry point";
+        return DGR_ERR_BAD_ARGUMENT;
+    }
     if (P == 0) return zero_outputs(c, st);
     char* gptr = geometryBuffer(dgr_geometry_bytes(P), alloc_user);
     char* iptr = imageBuffer(dgr_image_bytes(width, height), alloc_user);

@@ -159,6 +159,40 @@ def test_strict_mode_refuses_a_capturing_stream(monkeypatch):
     rast(**args)  # and the rasterizer is usable afterwards
 
 
+@pytest.mark.parametrize("variant", ["light", "full"])
+def test_callback_entry_points_refuse_a_capturing_stream(monkeypatch, variant):
+    """The resize-callback forwards (the reference's own interface: DGR_FORWARD_MODE=callback) block the host to size the binning
+    buffer.  On a capturing stream that synchronisation fails AND invalidates the capture -- before round 9 every later call of
+    the process on that stream failed with it; now the entry point refuses before it touches the stream, and everything is usable
+    afterwards."""
+    from dgr_amd import full, light
+    from dgr_amd.multiview import make_settings
+    monkeypatch.setenv("DGR_FORWARD_MODE", "callback")
+    s = make_scene(3000, 96, 64, 1)
+    dev = hh.dev()
+    if variant == "light":
+        rast = light.GaussianRasterizer(make_settings(s, 3, dev))
+    else:
+        rast = full.GaussianRasterizer(full.GaussianRasterizationSettings(
+            image_height=s.H, image_width=s.W, tanfovx=s.tanfovx, tanfovy=s.tanfovy, bg=T(s.bg), scale_modifier=1.0, viewmatrix=T(s.view),
+            projmatrix=T(s.proj), sh_degree=3, campos=T(s.campos), prefiltered=False, perspec_matrix=T(s.persp)))
+    args = dict(means3D=T(s.means), means2D=torch.zeros((s.P, 3), device=dev), opacities=T(s.opac), shs=T(s.shs), scales=T(s.scales),
+                rotations=T(s.rots), viewmatrix=T(s.view), gt_depth=T(s.gt))
+    ref = rast(**args)[0].clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with pytest.raises(RuntimeError, match="captured"):
+            with torch.cuda.graph(g, stream=side):
+                rast(**args)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):                       # the stream, and the process, are not left in a failed capture
+        again = rast(**args)[0]
+    torch.cuda.synchronize()
+    assert torch.equal(again, ref)
+
+
 def forward_under(option, s, deg):
     _capi.set_option("tile_schedule", option)
     try:
