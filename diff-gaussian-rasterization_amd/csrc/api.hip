@@ -819,7 +819,7 @@ int dgr_light_backward(void* stream, int P, int D, int M, int R, const float* ba
     b.dL_ddepth = dL_ddepth; b.dL_dmean3D = dL_dmean3D; b.dL_dcov3D = dL_dcov3D; b.dL_dsh = dL_dsh;
     b.dL_dscale = dL_dscale; b.dL_drot = dL_drot; b.pose_part = sc.pose_part; b.ticket = sc.ticket; b.dL_dview = dL_dview;
     { ScopedStage t(ST_PRE_BWD, st); HIP_TRY(dgr::launch_preprocess_bwd(b, st)); }
-    if (debug) HIP_TRY(hipStreamSynchronize(st));
+    if (debug && !dgr_stream_is_capturing(stream)) HIP_TRY(hipStreamSynchronize(st));  // (CHECK_CUDA(..., debug); a capturing stream cannot be waited for -- and the attempt would invalidate the capture)
     return DGR_OK;
 }
 
