@@ -525,9 +525,9 @@ __device__ __forceinline__ void render_bwd_light_body(const RenderBwdLightArgs& 
 }
 
 // BY_FRAME: half-wave / paired lists or quadrant lists by the frame's flag (render_fwd_light_kernel above: the forward that wrote the
-// tags took the same branch; the half-wave body needs the tags per half that only the half-wave forward writes).  Without it:
-// quadrant lists, which the 4-bit tags of either forward serve -- the deterministic kernels (LDS for the planes) and the glibc form
-// (an A/B mode that spills a register with eight lists).
+// tags took the same branch -- a quadrant-list forward sets both halves' bits of a quadrant, which a half-wave backward could walk
+// correctly but to no gain).  Without it: quadrant lists, for which the tag bytes of either forward are folded to four bits -- the
+// deterministic kernels (LDS for the planes) and the glibc form (an A/B mode that spills a register with eight lists).
 template <int AM, bool DO_MAP, bool DO_POSE, bool DET = false, bool LEAN = false, bool BY_FRAME = false>
 __global__ void __launch_bounds__(256, 8) render_bwd_light_kernel(RenderBwdLightArgs a) {
     static_assert(!BY_FRAME || !DET, "the deterministic kernel walks quadrant lists");
