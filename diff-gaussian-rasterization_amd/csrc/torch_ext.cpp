@@ -481,7 +481,7 @@ FullFwd full_forward_core(const Tensor& background, const Tensor& means3D_, cons
                           const Tensor& scales_, const Tensor& rotations_, double scale_modifier, const Tensor& cov3D_,
                           const Tensor& viewmatrix_, const Tensor& gt_depth_, const Tensor& projmatrix_, double tan_fovx,
                           double tan_fovy, long H, long W, const Tensor& sh_, long degree, const Tensor& campos_,
-                          bool prefiltered, long capacity, long mode) {
+                          bool prefiltered, long capacity, long mode, bool want_related = true) {
     if (means3D_.dim() != 2 || means3D_.size(1) != 3) throw std::runtime_error("means3D must have dimensions (num_points, 3)");
     const c10::Device dev = means3D_.device();
     if (!dev.is_cuda()) throw std::runtime_error("dgr_hip runs on the GPU only (no CPU path exists, as in the reference)");
@@ -562,8 +562,12 @@ FullFwd full_forward_core(const Tensor& background, const Tensor& means3D_, cons
     }
     o.cap = cap;
     // num_related (the reference's NG) is produced by the forward blend: the reference's second blocking read
-    // (F/cuda_rasterizer/rasterizer_impl.cu:498)
-    o.related = o.status.to(at::kCPU).data_ptr<int>()[3];
+    // (F/cuda_rasterizer/rasterizer_impl.cu:498) -- a wait for the whole forward.  The `_C.rasterize_gaussians` mirror returns the
+    // number, as the reference's does; the autograd node does not wait for it: NG only sizes the reference's pair lists in ITS
+    // backward (F/__init__.py:91,100,130), which this backward does not have (csrc/render_full.hip), and no caller of
+    // GaussianRasterizer.forward ever sees it.  The strict forward then returns as soon as num_rendered is known, the blend
+    // still running (config 2, one view at a time in the default mode: 0.205 -> 0.17 ms).
+    if (want_related) o.related = o.status.to(at::kCPU).data_ptr<int>()[3];
     return o;
 }
 
@@ -778,7 +782,7 @@ struct FullNode : public torch::autograd::Function<FullNode> {
         (void)means2D;
         FullFwd o = full_forward_core(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier, cov3Ds_precomp,
                                       viewmatrix, gt_depth, projmatrix, tanfovx, tanfovy, H, W, sh, degree, campos, prefiltered,
-                                      capacity, mode);
+                                      capacity, mode, /*want_related=*/false);
         g_report.rendered = o.rendered; g_report.related = o.related; g_report.ticket = o.ticket; g_report.cap = o.cap;
         g_report.status = o.status;
         // F/__init__.py:89-90

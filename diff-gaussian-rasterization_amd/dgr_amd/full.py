@@ -232,7 +232,8 @@ def _rasterize_compiled(means3D, means2D, sh, colors_precomp, opacities, scales,
             _light._capture_keepalive.append(status)
     elif mode == 1:
         _capacity_cache[key] = max(cap, rendered)
-        _light._last_status[key] = [rendered, 0, 0, related]
+        # (the strict node does not wait for num_related -- csrc/torch_ext.cpp: full_forward_core -- and reports -1: keep the last one read)
+        _light._last_status[key] = [rendered, 0, 0, related if related >= 0 else _light._last_status.get(key, (0, 0, 0, 0))[3]]
     return tuple(out)
 
 
