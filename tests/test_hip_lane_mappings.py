@@ -99,6 +99,57 @@ def test_the_frame_decides_its_lane_lists(oracle, lane_lists):
     check_backward(oracle, small, 3, what="small splats, the frame's own choice")
 
 
+def test_a_replayed_graph_follows_the_frames_lane_lists(monkeypatch, lane_lists):
+    """The choice is made on the device, per frame: a step recorded into a hipGraph takes whichever mapping the frame at hand asks for on
+    every replay -- no re-capture when the splats grow past the threshold or shrink below it (a host-side policy would have frozen the
+    captured step's kernels)."""
+    import numpy as np
+    import torch
+    from dgr_amd import light as D
+    from dgr_amd.multiview import CapturedStep, make_settings
+    from util import assert_grad_close
+    lane_lists(2)
+    s = make_scene(20000, 320, 240, 6)
+    flags = {}
+    for f in (1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0, 5.0):   # where does this scene cross ten tiles per Gaussian on screen?
+        sf = s._replace(scales=s.scales * np.float32(f))
+        _, d = hh.hip_forward(sf, 3)
+        flags[f] = (quadrant_flag(sf, d), d["num_rendered"])
+    lo = max(f for f, (q, _) in flags.items() if q == 0)
+    hi = min(f for f, (q, _) in flags.items() if q == 1 and f > lo)
+    monkeypatch.setenv("DGR_SYNC_MODE", "lazy")           # (the strict forwards above taught the shape its largest count)
+    dev = hh.dev()
+    rast = D.GaussianRasterizer(make_settings(s, 3, dev))
+    means3D, shs, opac = hh.T(s.means).requires_grad_(), hh.T(s.shs).requires_grad_(), hh.T(s.opac).requires_grad_()
+    scales, rots, view = hh.T(s.scales * np.float32(hi)).requires_grad_(), hh.T(s.rots).requires_grad_(), hh.T(s.view).requires_grad_()
+    means2D = torch.zeros((s.P, 3), device=dev, requires_grad=True)
+    gt, gC, gD = hh.T(s.gt), hh.T(s.gC), hh.T(s.gD[None])
+    leaves = [means3D, shs, opac, scales, rots, view]
+
+    def step():
+        for t in leaves + [means2D]:
+            t.grad = None
+        outs = rast(means3D=means3D, means2D=means2D, opacities=opac, shs=shs, scales=scales, rotations=rots, viewmatrix=view, gt_depth=gt)
+        torch.autograd.backward([outs[0], outs[2]], [gC, gD])
+        return [outs[0].detach()] + [t.grad for t in leaves]
+
+    def snapshot(tensors):
+        torch.cuda.synchronize()
+        return [t.cpu().numpy().copy() for t in tensors]
+
+    cap = CapturedStep(step)                               # recorded on the frame of BIG splats (quadrant lists)
+    for f in (hi, lo, hi, lo):
+        with torch.no_grad():
+            scales.copy_(hh.T(s.scales * np.float32(f)))
+        want = snapshot(step())                            # eager: this frame's own choice
+        got = snapshot(cap.replay())
+        cap.check()
+        assert np.array_equal(got[0], want[0]), f
+        for a, b in zip(got[1:], want[1:]):
+            assert_grad_close(a, b, f"replay at scale x {f}", rel_to_max=2e-6, elem_rtol=1e-3, elem_frac=1e-3)
+    D.check_async_errors()
+
+
 def test_the_old_lane_mapping_in_a_child_process():
     """DGR_FWD_HALVES=0 is read once per process: one scene, all three backward modes, in a child."""
     code = ("import sys; sys.path[:0] = [%r, %r]\n"
