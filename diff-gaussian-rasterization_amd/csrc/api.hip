@@ -595,17 +595,13 @@ __global__ void export_keys_kernel(dgr::ImageView img, dgr::BinningView bin, dgr
     for (uint32_t i = rg.x + threadIdx.x; i < rg.y; i += blockDim.x)
         dst[i] = ((uint64_t)tile << 32) | __float_as_uint(g.depths[bin.point_list[i] & DGR_ID_MASK]);
 }
-// the sorted Gaussian ids without the full forward's contribution tags (top 4 bits; render_common.h)
+// the sorted Gaussian ids (the mask: rounds 3-8 kept contribution tags in the top 4 bits; nothing writes them any more)
 __global__ void export_point_list_kernel(const uint32_t* src, uint32_t* dst, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i] & DGR_ID_MASK;
 }
-// ... and the tags alone (tests): 4 bits, bit w = quadrant wave w -- the full variant's from the list entries, the light variant's
-// folded from its tag bytes per half (`half` = 1: the bytes as they are, bit 2 w + h)
-__global__ void export_tags_kernel(const uint32_t* src, uint8_t* dst, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = (uint8_t)(src[i] >> DGR_TAG_SHIFT);
-}
+// ... and the contribution tags (tests): the blend forward's tag bytes (bit 2 w + h: half h of quadrant wave w; `half` = 1: as they
+// are), or folded to 4 bits, bit w = quadrant wave w
 __global__ void export_tag_bytes_kernel(const uint8_t* src, uint8_t* dst, int n, int half) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1579,14 +1575,12 @@ long dgr_state_export(void* stream, const char* name, int P, int width, int heig
     if (n == "rgb") return geomk(EX_RGB) ? -1 : 3L * P;
     if (n == "clamped") return geomk(EX_CLAMPED) ? -1 : 3L * P;
     if (n == "tiles_touched") return geomk(EX_TILES_TOUCHED) ? -1 : P;
-    if (n == "point_list" || n == "contribution_tags" || n == "contribution_tags_full" || n == "half_tags") {
+    if (n == "point_list" || n == "contribution_tags" || n == "half_tags") {
         if (num_rendered > 0) {
             const dim3 grid((num_rendered + 255) / 256);
             if (n == "point_list")
                 hipLaunchKernelGGL(export_point_list_kernel, grid, dim3(256), 0, st, bin.point_list, (uint32_t*)dst, num_rendered);
-            else if (n == "contribution_tags_full")
-                hipLaunchKernelGGL(export_tags_kernel, grid, dim3(256), 0, st, bin.point_list, (uint8_t*)dst, num_rendered);
-            else  // (the light variant's tag bytes: in the binning's pair_cov bytes, render_common.h)
+            else  // (the tag bytes: in the binning's pair_cov bytes, render_common.h)
                 hipLaunchKernelGGL(export_tag_bytes_kernel, grid, dim3(256), 0, st, bin.pair_cov, (uint8_t*)dst, num_rendered, n == "half_tags" ? 1 : 0);
             if (hipGetLastError() != hipSuccess) return -1;
         }

@@ -211,7 +211,7 @@ struct RenderFwdFullArgs {
     const uint4* sched;    // [tiles] {tile, list start, list end, -} of workgroup b (ImageView::tile_sched)
     const uint2* ranges;   // [tiles] ... and without a schedule (ImageView::cursor[3] == 0): block -> tile by the static XCD band
     const uint32_t* sched_flag;  // map, list from the range table (render_common.h: blend_slot)
-    uint32_t* point_list;  // read; the kernel writes the contribution tags into the top bits
+    uint32_t* point_list;  // read only (the contribution tags go into the byte array beside it: render_common.h, half_tags)
     const float4* rec;
     const float* bg;
     float* out_color;

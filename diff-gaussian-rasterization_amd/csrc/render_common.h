@@ -170,19 +170,18 @@ __device__ __forceinline__ unsigned reach_code(const float4& q0, const float4& q
 // pixel blended it.  A (pixel, Gaussian) pair is valid in the backward exactly when the forward blended it (same alpha
 // expression, and position <= the pixel's last contributor), so the backward builds its per-wave lists from the tags: no
 // bounding-box test, no wave-level pre-test, and instances no pixel blended are never loaded.
-//   full variant : 4 bits (bit w = quadrant wave w) in the top bits of the point_list entry (Gaussian ids stay below 2^28);
-//   light variant: one BYTE per list entry, per HALF of a quadrant (bit 2 w + h: half h -- pixel rows 4 h .. 4 h + 3, lanes
-//       32 h .. -- of quadrant wave w), in an instance-major byte array beside the list; the list itself is not written by the
-//       blend (round 9: the tag write-back into point_list was 6.4 MB of render_fwd's HBM writes per 1080p view, and the byte
-//       array carried a superset of it already -- profiles/r9/fwd_traffic.txt).  A forward that walked quadrant lists sets both
-//       halves' bits of a quadrant; a backward that walks quadrant lists folds the two bits of each quadrant.
+// One BYTE per list entry, per HALF of a quadrant (bit 2 w + h: half h -- pixel rows 4 h .. 4 h + 3, lanes 32 h .. -- of quadrant
+// wave w), in an instance-major byte array beside the list; the list itself is not written by any blend kernel (rounds 3-8 kept a
+// 4-bit tag in the top bits of the point_list entry as well: 6.4 MB of the light forward's HBM writes per 1080p view for a subset of
+// the byte's information -- profiles/r9/fwd_traffic.txt; Gaussian ids still stay below 2^28).  A forward that walked quadrant lists
+// sets both halves' bits of a quadrant; a backward that walks quadrant lists folds the two bits of each quadrant.
 constexpr int TAG_SHIFT = DGR_TAG_SHIFT;
 constexpr uint32_t ID_MASK = DGR_ID_MASK;
-enum { TAGS_IN_LIST = 0, TAGS_BYTES_QUADRANT = 1, TAGS_BYTES_HALVES = 2 };
+enum { TAGS_BYTES_QUADRANT = 1, TAGS_BYTES_HALVES = 2 };
 
-// The light variant's tag bytes live in the binning buffer's `pair_cov` / `ranks` bytes, which the binning is done with when the
+// The tag bytes live in the binning buffer's `pair_cov` / `ranks` bytes, which the binning is done with when the
 // blend runs; both blend kernels find them from the capacity the binning kernel left in cursor[2] (sched_flag = cursor + 3).
-// INVARIANT: the light forward writes the byte of EVERY entry of every tile list of its frame (zero for entries nobody blended,
+// INVARIANT: the forward blend writes the byte of EVERY entry of every tile list of its frame (zero for entries nobody blended,
 // and for the tail of a list whose tile finished early) -- the bytes underneath are the binning's, and nothing else clears them.
 // Whoever keeps a view's state between forward and backward must treat ranks / pair_cov as clobbered by the blend (BinningView,
 // dgr_common.h).
@@ -196,12 +195,19 @@ __device__ __forceinline__ uint32_t fold8(uint32_t t) {
     return (t & 1u) | ((t >> 1) & 2u) | ((t >> 2) & 4u) | ((t >> 3) & 8u);
 }
 
+// four 0/1 bytes -> four bits
+__device__ __forceinline__ uint32_t pack4(uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); }
+// The forward's marks of one staged instance -> its tag byte.  A half-wave forward marks byte w of `up` from the lanes 0-31 of
+// quadrant wave w and byte w of `lo` from its lanes 32-63 (the light and the full forward keep `up` in an LDS word per slot and
+// `lo` in the spare third word of the staged record: stage_one<AM, true>).
+__device__ __forceinline__ uint32_t tag_byte(uint32_t up, uint32_t lo) { return spread4(pack4(up)) | (spread4(pack4(lo)) << 1); }
+
 // backward staging: returns the entry's tag (TAGS: where it lives and in which form it is wanted); untagged entries are not loaded.
-template <int AM, int TAGS = TAGS_IN_LIST, class S>
+template <int AM, int TAGS, class S>
 __device__ __forceinline__ unsigned stage_tagged(S& s, int slot, uint32_t entry, const float4* __restrict__ rec,
-                                                 const uint8_t* __restrict__ tag8 = nullptr) {
+                                                 const uint8_t* __restrict__ tag8) {
     constexpr float PSCALE = AlphaPath<AM>::PSCALE;
-    unsigned code = TAGS == TAGS_IN_LIST ? entry >> TAG_SHIFT : (unsigned)*tag8;
+    unsigned code = (unsigned)*tag8;
     if (code == 0u) return 0u;
     if (TAGS == TAGS_BYTES_QUADRANT) code = fold8(code);
     const uint32_t gid = entry & ID_MASK;

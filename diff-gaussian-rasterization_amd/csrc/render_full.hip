@@ -20,20 +20,19 @@ namespace dgr {
 namespace {
 
 // ================================================================================ forward
-// contribution tag of the batch staged at list position pos0 -> top bits of the point_list entry (render_common.h)
+// contribution tags of the batch staged at list position pos0 -> the entries' tag bytes, per half of a quadrant (render_common.h:
+// tag_byte; render_light.hip: flush_slot).  Every staged entry gets its byte, blended or not: the bytes underneath are the binning's.
 template <class S>
-__device__ __forceinline__ void flush_tags(const S& s, const uint32_t* hit, uint32_t* point_list, uint32_t pos0, int tid) {
-    const uint32_t h = hit[tid];
-    if (h == 0u) return;
-    const uint32_t tag = (h & 1u) | ((h >> 7) & 2u) | ((h >> 14) & 4u) | ((h >> 21) & 8u);
-    point_list[pos0 + tid] = s.id[tid] | (tag << TAG_SHIFT);
+__device__ __forceinline__ void flush_tags(const S& s, const uint32_t* hit, uint8_t* tag8, uint32_t pos0, int tid, bool staged) {
+    if (staged) tag8[pos0 + tid] = (uint8_t)tag_byte(hit[tid], __float_as_uint(s.rec[2 * tid + 1].z));
 }
 
 // Lists: one per HALF of a quadrant, a loop step serves both half-waves (render_common.h: build_half_lists; render_light.hip)
 template <int AM>
 __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullArgs a) {
     __shared__ StagedT<DGR_TILE_PIX, unsigned short, 8> s;
-    __shared__ uint32_t hit[DGR_TILE_PIX];  // byte w of word j: quadrant wave w blended staged instance j
+    __shared__ uint32_t hit[DGR_TILE_PIX];  // byte w of word j: the UPPER half (lanes 0-31) of quadrant wave w blended staged instance j
+                                            // (the lower halves mark byte w of the staged record's spare third word: render_light.hip)
     __shared__ int s_nvalid;
     __shared__ uint64_t exptab[32];         // ALPHA_GLIBC: exact_math.h
     if (a.rep.host && blockIdx.x == 0 && threadIdx.x == 0) report_status(a.rep, a.status);
@@ -49,6 +48,9 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     const f2 pxy = {(float)px, (float)py};
     const float tile_x0 = (float)(tx * DGR_BLOCK_X), tile_y0 = (float)(ty * DGR_BLOCK_Y);
     const int my_list = 2 * wave + (lane >> 5);
+    uint8_t* const tag8 = half_tags(a.point_list, a.sched_flag);
+    unsigned char* const mark_base = lane >= 32 ? reinterpret_cast<unsigned char*>(&s.rec[1].z) + wave : reinterpret_cast<unsigned char*>(hit) + wave;
+    const int mark_stride = lane >= 32 ? 32 : 4;
 
     const uint2 range = make_uint2(slot.y, slot.z);
     const int total = (int)(range.y - range.x);
@@ -66,7 +68,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     int last_base = 0;
     for (int base = 0; base < total; base += DGR_TILE_PIX) {
         if (__syncthreads_and(ub < 0.f)) break;
-        if (have_flush) flush_tags(s, hit, a.point_list, range.x + base - DGR_TILE_PIX, tid);
+        if (have_flush) flush_tags(s, hit, tag8, range.x + base - DGR_TILE_PIX, tid, true);  // (an earlier batch is always full)
         hit[tid] = 0u;
         have_flush = true;
         last_base = base;
@@ -88,7 +90,7 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
 #pragma clang fp contract(off)  // T (1 - alpha) and the sum of alpha T round as the reference's do (forward.cu:366-381)
                     const int j = __float_as_int(q1[u].w) & 0xFF;  // (stage_one<AM, true>: the slot rides in the threshold's low bits)
                     const float4 cd = s.rgbd[j];
-                    reinterpret_cast<unsigned char*>(hit)[4 * j + wave] = 1;  // contribution tag
+                    mark_base[j * mark_stride] = 1;  // contribution tag of this lane's half
                     const float w = alpha * T;
                     C0 = __builtin_fmaf(cd.x, w, C0); C1 = __builtin_fmaf(cd.y, w, C1); C2 = __builtin_fmaf(cd.z, w, C2);
                     Dd = __builtin_fmaf(cd.w, w, Dd);
@@ -106,7 +108,9 @@ __global__ void __launch_bounds__(256, 8) render_fwd_full_kernel(RenderFwdFullAr
     }
 
     __syncthreads();
-    if (have_flush) flush_tags(s, hit, a.point_list, range.x + last_base, tid);
+    if (have_flush) flush_tags(s, hit, tag8, range.x + last_base, tid, tid < total - last_base);
+    // the tail of a list whose tile finished early was never staged: nobody blended it (render_common.h: the tag bytes' invariant)
+    for (int p = (have_flush ? last_base + DGR_TILE_PIX : 0) + tid; p < total; p += DGR_TILE_PIX) tag8[range.x + p] = 0;
 
     // (an overflowed forward rendered empty lists: NaN images instead of a plausible empty frame -- render_light.hip)
     if (overflowed) {
@@ -148,21 +152,27 @@ struct StagedBwdFull {
     static constexpr int NB = DET ? 64 : 128;
     static constexpr int LD = NB + 1;
     static constexpr int PLANE = NACC_FULL * LD;
-    StagedT<NB, uint32_t> f;
+    typedef StagedT<NB, uint32_t, DET ? 4 : 8> staged_t;  // (paired lists: two list rows per quadrant wave, render_common.h)
+    staged_t f;
     float acc[(DET ? 4 : 1) * PLANE];
     uint32_t inst[DET ? NB : 1];
     int max_last;
     uint64_t exptab[32];  // ALPHA_GLIBC: exact_math.h
 };
 
+// Paired lists (round 9, as the light mapping backward: render_light.hip, render_common.h: build_paired_lists): from the forward's
+// tags per half, neighbouring entries of a quadrant's list that live in different halves share a loop step, whose sixteen sums are
+// reduced per half (wave_reduce16d_head + quad sums) and delivered to each half's own entry.  Not in the deterministic kernel
+// (its planes take the LDS).
 // LEAN (round 9, as in the light variant): the caller passed no gradient image for the "uncertainty" output (NULL: the loss did not
 // use it) -- the variance recurrence and its two terms drop out: bit-identical to the kernel fed an all-zero image.
 template <int AM, bool DET = false, bool LEAN = false>
 __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullArgs a) {
     typedef StagedBwdFull<DET> SB;
     constexpr int BWD_NB = SB::NB, BWD_LD = SB::LD;
+    constexpr bool PAIRED = !DET;
     __shared__ SB sb;
-    StagedT<SB::NB, uint32_t>& s = sb.f;
+    typename SB::staged_t& s = sb.f;
     const uint4 slot = blend_slot(a.sched, a.ranges, a.sched_flag, a.grid_x * a.grid_y);  // {tile, list start, list end}
     const int tile = (int)slot.x;
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -214,6 +224,7 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
     const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
     const int c16 = wave_reduce16d_comp(lane);
     const int my_comp = ((lane & 3) == 0 && c16 < NACC_FULL) ? c16 : -1;
+    const uint8_t* const tag8 = half_tags(a.point_list, a.sched_flag);
     // this lane's accumulator row (column = slot); DET: in its wave's own plane
     float* const my_acc = sb.acc + (DET ? wave * SB::PLANE : 0) + (my_comp >= 0 ? my_comp : 0) * BWD_LD;
 
@@ -222,22 +233,32 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
         const int cnt = hi - lo;
         __syncthreads();
         unsigned code = 0;
-        if (tid < cnt) code = stage_tagged<AM>(s, tid, a.point_list[range.x + lo + tid], a.rec);
+        if (tid < cnt) code = stage_tagged<AM, PAIRED ? TAGS_BYTES_HALVES : TAGS_BYTES_QUADRANT>(s, tid, a.point_list[range.x + lo + tid], a.rec, tag8 + (range.x + lo + tid));
         if (!DET) {  // (DET: a plane's column is written by its wave iff the entry's tag names the wave -- nothing to clear)
 #pragma unroll
             for (int k = 0; k < NACC_FULL; k++)
                 if (tid < BWD_NB) sb.acc[k * BWD_LD + tid] = 0.f;
         }
-        const int n = build_lists(s, code, tid, wave, lane);
+        unsigned long long split[2] = {0ull, 0ull};  // PAIRED: the steps that serve two entries
+        const int n = PAIRED ? build_paired_lists(s, code, tid, wave, lane, split) : build_lists(s, code, tid, wave, lane);
         // (the staged record carries 4 * slot: render_common.h, stage_tagged)
         const int rel_last4 = 4 * (last_contributor - lo);
         const int rel_first4 = 4 * (first_contributor - 1 - lo);  // 4 * slot of the front-most valid contributor, if in this batch
 
-        for (int k = ((n + 1) & ~1) - 2; k >= 0; k -= 2) {
+        // PAIRED: one step per iteration, its list row by half-wave (render_light.hip: the mapping backward)
+        constexpr int U = PAIRED ? 1 : 2;
+        const int my_list = PAIRED ? 2 * wave + (lane >> 5) : wave;
+        for (int k = ((n + U - 1) / U) * U - U; k >= 0; k -= U) {
             float4 q0[2], q1[2];
-            load2(s, wave, k, q0, q1);
+            if (U == 2) {
+                load2(s, my_list, k, q0, q1);
+            } else {
+                const unsigned off = s.list[my_list][k];
+                q0[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rec) + off);
+                q1[0] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s.rec) + off + 16);
+            }
 #pragma unroll
-            for (int u = 1; u >= 0; u--) {
+            for (int u = U - 1; u >= 0; u--) {
                 f2 dxy;
                 const float p2 = pair_p2<AM>(q0[u], q1[u], pxy, dxy);
                 const int j4 = __float_as_int(q1[u].z);
@@ -293,7 +314,25 @@ __global__ void __launch_bounds__(256, 6) render_bwd_full_kernel(RenderBwdFullAr
                 g[13] = fq * dx;  // front-most depth sums
                 g[14] = fq * dy;
                 g[15] = 0.f;
-                const float tot = wave_reduce16d(g);  // (within-row stages first: wave_reduce.h)
+                float tot;
+                if (PAIRED) {
+                    float u0, u1;
+                    wave_reduce16d_head(g, u0, u1);
+                    const int st = k + u;  // (wave-uniform: scalar code)
+                    if ((split[st >> 6] >> (st & 63)) & 1ull) {
+                        // a pair: each half's own totals to its own entry's column (j4 is uniform in each half)
+                        const float r0 = quad_sum(u0), r1 = quad_sum(u1);
+                        const int c0 = (lane & 3) == 0 ? wave_reduce16d_half_slot0(lane) : -1;
+                        const int c1 = ((lane & 3) == 0 && wave_reduce16d_half_slot1(lane) < NACC_FULL) ? wave_reduce16d_half_slot1(lane) : -1;
+                        char* const col = reinterpret_cast<char*>(sb.acc) + j4;
+                        if (c0 >= 0) atomicAdd(reinterpret_cast<float*>(col + c0 * (BWD_LD * 4)), r0);
+                        if (c1 >= 0) atomicAdd(reinterpret_cast<float*>(col + c1 * (BWD_LD * 4)), r1);
+                        continue;
+                    }
+                    tot = wave_reduce16d_tail(u0, u1);
+                } else {
+                    tot = wave_reduce16d(g);  // (within-row stages first: wave_reduce.h)
+                }
                 if (my_comp >= 0) {
                     float* const cell = reinterpret_cast<float*>(reinterpret_cast<char*>(my_acc) + j4);
                     if (DET) *cell = tot; else atomicAdd(cell, tot);

@@ -55,19 +55,15 @@ struct StagedFwd {
 
 // Per-slot results of the batch staged at list position `pos0`: the median statistics go to the Gaussian, the
 // contribution tag into the entry's tag byte (render_common.h).
-// four 0/1 bytes -> four bits
-__device__ __forceinline__ uint32_t pack4(uint32_t w) { return (w & 1u) | ((w >> 7) & 2u) | ((w >> 14) & 4u) | ((w >> 21) & 8u); }
 
 template <class SF>
 __device__ __forceinline__ void flush_slot(const SF& sf, const RenderFwdLightArgs& a, uint8_t* tag8, uint32_t pos0, int tid, bool staged) {
     if (!staged) return;
-    const uint32_t up = pack4(sf.hit[tid]);
     uint32_t t8;  // bit 2 w <- upper half of wave w, bit 2 w + 1 <- its lower half
     if constexpr (!SF::staged_t::HAS_ID) {  // (the half-wave body) lower halves: the bytes of the record's third word
-        const uint32_t lo = pack4(__float_as_uint(sf.f.rec[2 * tid + 1].z));
-        t8 = spread4(up) | (spread4(lo) << 1);
+        t8 = tag_byte(sf.hit[tid], __float_as_uint(sf.f.rec[2 * tid + 1].z));
     } else {                                // (the quadrant body) a quadrant's tag stands for both of its halves
-        t8 = spread4(up) * 3u;
+        t8 = spread4(pack4(sf.hit[tid])) * 3u;
     }
     tag8[pos0 + tid] = (uint8_t)t8;         // every staged entry, blended or not: the byte underneath is the binning's
     if (sf.cnt[tid] != 0u) {                // (which implies a tag)

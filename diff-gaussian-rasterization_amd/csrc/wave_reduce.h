@@ -97,7 +97,7 @@ __device__ __forceinline__ int wave_reduce16d_comp(int lane) {
     const int b = (lane >> 2) & 3;
     return 4 * (lane >> 4) + ((b == 1) ? 2 : (b == 2) ? 1 : b);
 }
-__device__ __forceinline__ float wave_reduce16d(float (&x)[16]) {
+__device__ __forceinline__ void wave_reduce16d_head(float (&x)[16], float& u0, float& u1) {
     asm volatile("s_nop 1\n\t"
                  DGR_MERGE(0, 1, "row_mirror", "0x3", "0xc") DGR_MERGE(2, 3, "row_mirror", "0x3", "0xc")
                  DGR_MERGE(4, 5, "row_mirror", "0x3", "0xc") DGR_MERGE(6, 7, "row_mirror", "0x3", "0xc")
@@ -109,11 +109,26 @@ __device__ __forceinline__ float wave_reduce16d(float (&x)[16]) {
                    "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), "+v"(x[11]), "+v"(x[12]), "+v"(x[13]), "+v"(x[14]), "+v"(x[15]));
     float z0 = x[0], z1 = x[4], z2 = x[8], z3 = x[12];
     asm volatile("s_nop 1\n\t" DGR_SWAP16(0, 1) DGR_SWAP16(2, 3) : "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
-    float u0 = z0 + z1;  // rows 0, 2: values 0..3 ; rows 1, 3: values 4..7
-    float u1 = z2 + z3;  // rows 0, 2: values 8..11 ; rows 1, 3: values 12..15
+    u0 = z0 + z1;  // rows 0, 2: values 0..3 ; rows 1, 3: values 4..7
+    u1 = z2 + z3;  // rows 0, 2: values 8..11 ; rows 1, 3: values 12..15
+}
+__device__ __forceinline__ float wave_reduce16d_tail(float u0, float u1) {
     asm volatile("s_nop 1\n\t" DGR_SWAP32(0, 1) : "+v"(u0), "+v"(u1));
     return quad_sum(u0 + u1);   // row r: values 4 r .. 4 r + 3
 }
+__device__ __forceinline__ float wave_reduce16d(float (&x)[16]) {
+    float u0, u1;
+    wave_reduce16d_head(x, u0, u1);
+    return wave_reduce16d_tail(u0, u1);
+}
+// ... or, without the last stage, the sixteen sums of each HALF of the wave on its own (paired lists of the full backward, as
+// wave_reduce12d_half_slot*): r0 = quad_sum(u0) holds the half's values 0..3 in its even row and 4..7 in its odd row, r1 =
+// quad_sum(u1) its values 8..11 / 12..15; quad b holds value {0, 2, 1, 3}[b].
+__device__ __forceinline__ int wave_reduce16d_half_slot0(int lane) {
+    const int b = (lane >> 2) & 3;
+    return 4 * ((lane >> 4) & 1) + ((b == 1) ? 2 : (b == 2) ? 1 : b);
+}
+__device__ __forceinline__ int wave_reduce16d_half_slot1(int lane) { return 8 + wave_reduce16d_half_slot0(lane); }
 
 // x[0..3] per lane -> total of value {0,2,1,3}[lane >> 4] in every lane of that 16-lane row (10 instructions).
 __device__ __forceinline__ int wave_reduce4_comp(int lane) {

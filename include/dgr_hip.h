@@ -182,8 +182,8 @@ int dgr_full_backward(void* stream, int P, int D, int M, int R, const float* bac
 /* ---- stage-wise access for tests and profiling (views into the opaque state buffers) ---- */
 /* Copies one named array of a state buffer to `dst` (device or host pointer).  Names: "depths", "radii",
  * "means2D", "conic_opacity", "rgb", "clamped", "tiles_touched" (geometry); "point_list", "keys" (binning); "contribution_tags"
- * (one byte per list entry, bit w = some pixel of quadrant w of the tile blended it: the light forward's tag bytes folded),
- * "half_tags" (those bytes as they are: bit 2 w + h = half h of quadrant w), "contribution_tags_full" (the full forward's tags);
+ * (one byte per list entry, bit w = some pixel of quadrant w of the tile blended it: the forward blend's tag bytes folded),
+ * "half_tags" (those bytes as they are: bit 2 w + h = half h of quadrant w);
  * "ranges", "tile_sched", "sched_flag" (one word, the frame's blend flags: bit 0 = its blend kernels use the schedule, bit 1 = the
  * binning buffer overflowed, bit 2 = quadrant lane lists: option "lane_lists"), "n_contrib", "n_valid",
  * "final_T" (image; the last two: full variant).  Layout conversion to the reference's element types is done on the fly.
