@@ -27,7 +27,8 @@ def oracle():
 #       status mode, no hipGraph capture, nothing left queued when the call returns;
 #   DGR_BINDING=ctypes        -- the compiled extension is not loaded: the tests OF the compiled binding have no subject.
 _NEEDS_PRESIZED = ("test_lazy_status_mode_matches_strict", "test_captured_step", "test_strict_mode_refuses_a_capturing_stream",
-                   "test_inputs_made_on_the_callers_stream", "test_hip_lazy_safety.py", "test_tracking_iteration_replayed_from_a_hipgraph")
+                   "test_inputs_made_on_the_callers_stream", "test_hip_lazy_safety.py", "test_tracking_iteration_replayed_from_a_hipgraph",
+                   "test_a_replayed_graph_follows_the_frames_lane_lists")
 _NEEDS_COMPILED = ("test_hip_binding_guard.py", "test_compiled_and_ctypes_bindings_agree",
                    "test_callback_entry_points_match_the_presized_path[compiled]")
 
