@@ -1178,6 +1178,10 @@ int dgr_debug_half_reduce(void* stream, const float* in, float* r0, float* r1, f
     HIP_TRY(dgr::launch_half_reduce_test(in, r0, r1, h3, slot0, slot1, comp3, (hipStream_t)stream));
     return DGR_OK;
 }
+int dgr_debug_half_reduce16(void* stream, const float* in, float* r0, float* r1, int* slot0, int* slot1) {
+    HIP_TRY(dgr::launch_half_reduce16_test(in, r0, r1, slot0, slot1, (hipStream_t)stream));
+    return DGR_OK;
+}
 int dgr_debug_lane_lists(void* stream, const unsigned char* codes, unsigned* paired, unsigned* halves) {
     HIP_TRY(dgr::launch_lane_lists_test(codes, paired, halves, (hipStream_t)stream));
     return DGR_OK;

@@ -309,6 +309,7 @@ hipError_t launch_render_fwd_full(const RenderFwdFullArgs& a, int alpha_mode, hi
 hipError_t launch_render_bwd_full(const RenderBwdFullArgs& a, int alpha_mode, hipStream_t stream, bool deterministic = false);
 hipError_t launch_det_offsets(int P, const ushort4* rect, uint32_t* blk, uint32_t* goff, hipStream_t stream);
 hipError_t launch_det_gather(int P, const ushort4* rect, const uint32_t* goff, const float* rows, uint32_t R, float* acc, hipStream_t stream);
+hipError_t launch_half_reduce16_test(const float* in, float* r0, float* r1, int* slot0, int* slot1, hipStream_t stream);
 hipError_t launch_half_reduce_test(const float* in, float* r0, float* r1, float* h3, int* slot0, int* slot1, int* comp3, hipStream_t stream);
 hipError_t launch_lane_lists_test(const unsigned char* codes, uint32_t* paired, uint32_t* halves, hipStream_t stream);
 hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out12, float* out4, int* comp16, int* comp12, int* comp4,

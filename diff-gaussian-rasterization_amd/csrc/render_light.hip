@@ -628,6 +628,20 @@ __global__ void __launch_bounds__(64) half_reduce_test_kernel(const float* in, f
     comp3[lane] = half_reduce3_comp(lane);
 }
 
+// ... and of the sixteen-value network stopped before its cross-half stage (the paired step of the FULL backward): in[c * 64 + lane]
+__global__ void __launch_bounds__(64) half_reduce16_test_kernel(const float* in, float* r0, float* r1, int* slot0, int* slot1) {
+    const int lane = threadIdx.x;
+    float g[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) g[k] = in[k * 64 + lane];
+    float u0, u1;
+    wave_reduce16d_head(g, u0, u1);
+    r0[lane] = quad_sum(u0);
+    r1[lane] = quad_sum(u1);
+    slot0[lane] = wave_reduce16d_half_slot0(lane);
+    slot1[lane] = wave_reduce16d_half_slot1(lane);
+}
+
 // self-test of the list builders of render_common.h on one batch of 128 staged slots: codes[slot] = the eight bits "half h of
 // quadrant wave w" (bit 2 w + h).  paired[w] / halves[w] (280 words each) = {steps or length, split[0] lo, hi, split[1] lo, hi,
 // list 2 w [0..135], list 2 w + 1 [0..135]} as wave w leaves them (dgr_debug_lane_lists).
@@ -750,6 +764,10 @@ hipError_t launch_wave_reduce_test(const float* in, float* out16, float* out12, 
 
 hipError_t launch_half_reduce_test(const float* in, float* r0, float* r1, float* h3, int* slot0, int* slot1, int* comp3, hipStream_t stream) {
     launch(half_reduce_test_kernel, dim3(1), dim3(64), stream, in, r0, r1, h3, slot0, slot1, comp3);
+    return hipGetLastError();
+}
+hipError_t launch_half_reduce16_test(const float* in, float* r0, float* r1, int* slot0, int* slot1, hipStream_t stream) {
+    launch(half_reduce16_test_kernel, dim3(1), dim3(64), stream, in, r0, r1, slot0, slot1);
     return hipGetLastError();
 }
 hipError_t launch_lane_lists_test(const unsigned char* codes, uint32_t* paired, uint32_t* halves, hipStream_t stream) {

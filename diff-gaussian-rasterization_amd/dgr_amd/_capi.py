@@ -103,6 +103,7 @@ _SIGS = {
     "dgr_debug_wave_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dgr_debug_exact_math": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "dgr_debug_half_reduce": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dgr_debug_half_reduce16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "dgr_debug_lane_lists": (_i, [_vp, _vp, _vp, _vp]),
     "dgr_debug_bin_tiles_trace": (_i, [_vp]),
     "dgr_profile_select": (_i, [C.c_char_p]),

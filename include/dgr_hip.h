@@ -433,6 +433,9 @@ int dgr_debug_wave_reduce(void* stream, const float* in, float* out16, float* ou
  * that total belongs to (-1: none); h3 [lane]: after the three-value network of the tracking backward (the first three values),
  * comp3 [lane] the value index (-1: none).  64 entries each. */
 int dgr_debug_half_reduce(void* stream, const float* in, float* r0, float* r1, float* h3, int* slot0, int* slot1, int* comp3);
+/* ... and of the SIXTEEN-value network stopped before its cross-half stage (the paired step of the full variant's backward): `in`
+ * holds 16 values per lane as in[c * 64 + lane]; r0 / r1 [lane] what the lane holds, slot0 / slot1 [lane] the value index. */
+int dgr_debug_half_reduce16(void* stream, const float* in, float* r0, float* r1, int* slot0, int* slot1);
 /* Self-test of the per-wave list builders of the blend kernels (csrc/render_common.h: build_paired_lists, build_half_lists) on one
  * batch of 128 staged slots.  codes[slot] (128 device bytes): bit 2 w + h set <=> half h (lanes 32 h ..) of quadrant wave w takes
  * the slot.  paired / halves (4 x 280 device words, one block per wave): {steps or length, split mask 0 lo, hi, split mask 1 lo,

@@ -184,3 +184,42 @@ def test_half_reductions_one_hot(comp):
         assert np.array_equal(r0, np.where(mine & (s0 == comp), 3.0, 0.0))
         assert np.array_equal(np.where(s1 >= 0, r1, 0.0), np.where(mine & (s1 == comp), 3.0, 0.0))
         assert np.array_equal(np.where(c3 >= 0, h3, 0.0), np.where(mine & (c3 == comp), 3.0, 0.0))
+
+
+def half_reduce16(x):
+    lib = _capi.load()
+    dev = torch.device("cuda:0")
+    t = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    f = [torch.zeros(64, device=dev) for _ in range(2)]
+    i = [torch.zeros(64, dtype=torch.int32, device=dev) for _ in range(2)]
+    rc = lib.dgr_debug_half_reduce16(_capi.stream_handle(), t.data_ptr(), *[o.data_ptr() for o in f], *[o.data_ptr() for o in i])
+    assert rc == 0, _capi.last_error()
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() for o in f], [o.cpu().numpy() for o in i]
+
+
+def test_sixteen_value_half_reductions_sum_each_half_on_its_own():
+    """The paired step of the FULL backward (csrc/render_full.hip): wave_reduce16d_head + quad sums leave every half's sixteen totals in
+    its own lanes -- values 0..7 through r0, 8..15 through r1, each named by wave_reduce16d_half_slot0 / 1."""
+    rng = np.random.default_rng(4)
+    x = rng.integers(-64, 64, size=(16, 64)).astype(np.float32)  # integer-valued: every order sums exactly
+    (r0, r1), (s0, s1) = half_reduce16(x)
+    for half in range(2):
+        lanes = slice(32 * half, 32 * half + 32)
+        tot = x[:, lanes].sum(1)
+        assert np.array_equal(r0[lanes], tot[s0[lanes]]) and np.array_equal(r1[lanes], tot[s1[lanes]])
+        assert sorted(set(s0[lanes].tolist())) == list(range(8)) and sorted(set(s1[lanes].tolist())) == list(range(8, 16))
+        # the lanes that deliver (lane % 4 == 0) cover every value exactly once per half
+        d0, d1 = s0[lanes][::4], s1[lanes][::4]
+        assert sorted(d0.tolist()) == list(range(8)) and sorted(d1.tolist()) == list(range(8, 16))
+
+
+@pytest.mark.parametrize("comp", range(16))
+def test_sixteen_value_half_reductions_one_hot(comp):
+    for lane in (0, 5, 15, 16, 31, 32, 40, 47, 48, 63):
+        x = np.zeros((16, 64), np.float32)
+        x[comp, lane] = 3.0
+        (r0, r1), (s0, s1) = half_reduce16(x)
+        mine = np.arange(64) // 32 == lane // 32
+        assert np.array_equal(r0, np.where(mine & (s0 == comp), 3.0, 0.0))
+        assert np.array_equal(r1, np.where(mine & (s1 == comp), 3.0, 0.0))
