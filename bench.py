@@ -445,7 +445,7 @@ def main():
         R = int(_capi_last_num_rendered(P, H, W, dev))
         N = W * H
         # secondary figure of SURVEY.md s8(d): (pixel, Gaussian) pairs evaluated = 2 x sum of n_contrib per view (fwd + bwd)
-        pair_evals = None
+        pair_evals, lane_lists = None, None
         if args.variant == "light":
             st_ = light._C.rasterize_gaussians(
                 settings.bg, means3D.detach(), torch.empty(0, device=dev), opac.detach(), scales.detach(), rots.detach(),
@@ -457,6 +457,11 @@ def main():
             if lib_.dgr_state_export(_capi.stream_handle(), b"n_contrib", P, W, H, int(st_[0]), cap_, st_[7].data_ptr(),
                                      st_[8].data_ptr(), st_[9].data_ptr(), nc.data_ptr()) >= 0:
                 pair_evals = 2 * int(nc.to(torch.int64).sum().item())
+            # which lane lists this frame's blend kernels walked (option "lane_lists" = 2: decided per frame on the device)
+            fl = torch.zeros(1, dtype=torch.int32, device=dev)
+            if lib_.dgr_state_export(_capi.stream_handle(), b"sched_flag", P, W, H, int(st_[0]), cap_, st_[7].data_ptr(),
+                                     st_[8].data_ptr(), st_[9].data_ptr(), fl.data_ptr()) >= 0:
+                lane_lists = "quadrant" if (int(fl.item()) >> 2) & 1 else "half-wave / paired"
         views_per_s = world * args.steps * max(1, Vb) / elapsed
         dom_ms = dom_tot / max(dom_n, 1)
         live = dom_n > 0
@@ -533,7 +538,7 @@ def main():
                        "ms_per_view_strict_one_stream": strict_serial_ms,
                        # which binding ran (the per-step figures depend on it): the compiled autograd node with raw TensorImpl
                        # output views (1), with at::from_blob windows (0), or the ctypes binding (None)
-                       "binding": {"compiled": light._C is light._CompiledC, "raw_views": (light._CompiledC.ext.raw_views() if light._CompiledC.ext is not None else None)}, "views_per_step": max(1, Vb),
+                       "binding": {"compiled": light._C is light._CompiledC, "raw_views": (light._CompiledC.ext.raw_views() if light._CompiledC.ext is not None else None)}, "views_per_step": max(1, Vb), "lane_lists": lane_lists,
                        "ms_per_view": 1e3 * elapsed / args.steps / max(1, Vb), "hipgraph_replay": bool(args.graph),
                        "binning": "two-level segment binning (csrc/segment_binning.hip)" if _capi.get_option("lds_count") else "global tile counters (csrc/binning.hip)",
                        "pair_evals_per_view": pair_evals,
